@@ -1,0 +1,112 @@
+"""Helpers shared by the parity tests: rebuild a fixture's initial state and compare probes.
+
+TEST INFRASTRUCTURE ONLY (see oracle/sr_oracle.py header).
+"""
+import os
+import re
+from collections import OrderedDict
+
+import torch
+
+from . import detrand
+from . import sr_oracle
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLDEN_DIR, name + ".pt"), map_location="cpu", weights_only=False)
+
+
+def initial_state(keys, seed, **fill_kw):
+    sd = OrderedDict()
+    for k, shape in keys:
+        dt = torch.int64 if k.endswith("num_batches_tracked") else torch.float32
+        sd[k] = torch.zeros(shape, dtype=dt)
+    return detrand.fill_state_dict_(sd, seed, **fill_kw)
+
+
+def vgg_state(seed):
+    sd = sr_oracle.vgg19_seeded_state()            # only for keys/shapes
+    return detrand.fill_state_dict_(sd, seed, gain=1.0, bias_amp=0.05)
+
+
+def initial_states(fx):
+    g = initial_state(fx["g_keys"], fx["seeds"]["G"])
+    d = initial_state(fx["d_keys"], fx["seeds"]["D"]) if fx["d_keys"] else None
+    f = vgg_state(fx["seeds"]["F"]) if fx["spec"]["yaml"].get("feature", True) else None
+    return g, d, f
+
+
+def batches(fx):
+    y = fx["spec"]["yaml"]
+    for s in range(1, fx["spec"]["steps"] + 1):
+        yield s, detrand.synthetic_pair(y["batch"], y["crop"], fx["seeds"]["data"] + s)
+
+
+def oracle_for(fx):
+    y = fx["spec"]["yaml"]
+    g, d, f = initial_states(fx)
+    ng = fx["network_G"]
+    nd = fx["network_D"]
+    return sr_oracle.OracleSRStep(
+        g, d, f, arch=ng["type"], nb=ng["nb"], d_size=(nd["size"] if nd else 0),
+        d_nf=(nd["base_nf"] if nd else 0), pixel_weight=y.get("pixel_weight", 1e-2),
+        feature_weight=1.0 if y.get("feature", True) else 0.0,
+        gan_weight=5e-3 if y.get("gan", True) else 0.0,
+        upsample_mode=ng.get("upsample_mode", "upconv"))
+
+
+def probe_error(t, pr):
+    """max |sample diff| / (max |sample| + tiny) and relative L2-norm error against a probe."""
+    f = t.detach().flatten().to(torch.float64).cpu()
+    s = f[::pr["stride"]][:pr["samples"].numel()]
+    scale = pr["samples"].abs().max().item() + 1e-12
+    e_s = (s - pr["samples"]).abs().max().item() / scale
+    e_n = abs(f.norm().item() - pr["l2"]) / (pr["l2"] + 1e-12)
+    return e_s, e_n
+
+
+def bn_shadowed_biases(keys):
+    """Conv biases that feed a BatchNorm (Discriminator_VGG, discriminators.py:24-34): their true
+    gradient is exactly zero (BN subtracts the batch mean), so what any implementation computes
+    is rounding noise, which Adam turns into +-lr updates of arbitrary sign.  They are excluded
+    from post-step weight comparisons (their forward effect is nil as well)."""
+    names = [k for k, _ in keys]
+    out = set()
+    for k in names:
+        m = re.match(r"features\.(\d+)\.bias$", k)
+        if m and ("features.%d.running_mean" % (int(m.group(1)) + 1)) in names:
+            out.add(k)
+    return out
+
+
+def state_error(sd, probes, skip=(), lr_steps=1e-4):
+    """Post-step weights vs probes, in units of the largest possible Adam displacement
+    (lr * steps).  Adam divides each gradient element by its own running magnitude, so elements
+    whose gradient is rounding noise move by +-lr whatever the implementation; we therefore
+    report (worst |dp|/(lr*steps), mean |dp|/(lr*steps), worst key) and the tests bound the
+    mean tightly and the worst loosely."""
+    worst, worst_k, tot, cnt = 0.0, None, 0.0, 0
+    for k, pr in probes.items():
+        if k in skip or k.endswith("num_batches_tracked"):
+            continue
+        f = sd[k].detach().flatten().to(torch.float64).cpu()
+        s_ = f[::pr["stride"]][:pr["samples"].numel()]
+        d = (s_ - pr["samples"]).abs() / lr_steps
+        tot += d.sum().item()
+        cnt += d.numel()
+        if d.max().item() > worst:
+            worst, worst_k = d.max().item(), k
+    return worst, tot / max(cnt, 1), worst_k
+
+
+def buffers_error(sd, probes):
+    """BatchNorm running statistics: plain relative comparison (not Adam-driven)."""
+    worst = (0.0, None)
+    for k, pr in probes.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            e_s, e_n = probe_error(sd[k].float(), pr)
+            if max(e_s, e_n) > worst[0]:
+                worst = (max(e_s, e_n), k)
+    return worst

@@ -1,0 +1,106 @@
+"""Generate tests/golden/*.pt from the REAL reference (run in the build container only).
+
+TEST INFRASTRUCTURE ONLY.  Usage:  python -m oracle.make_golden [case ...]
+
+For every case the reference's own `options.parse` + `create_model('sr')` build SRModel on
+CPU (oracle/ref_harness.py); all weights are then overwritten with the bit-reproducible fill
+of oracle/detrand.py (the reference's kaiming RNG stream cannot travel: SURVEY.md 8(b)),
+inputs come from detrand.synthetic_pair, and `feed_data` + `optimize_parameters` run K steps.
+Recorded per case: the per-step `log_dict`, fake_H of the last step, gradient probes of step 1
+(captured by optimizer pre-step hooks, i.e. after clip_grad_norm_), and probes (strided
+samples + L2 norm) of every tensor of the post-step G / D state_dicts.
+"""
+import os
+import sys
+import torch
+
+from . import ref_harness as R
+from . import detrand
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # BASELINE.json configs[0]: SRResNet x4, batch 2, 32->128, L1 only
+    "cfg1_srresnet": dict(yaml=dict(model_G="sr_resnet", nb=16, nf=64, batch=2, crop=128, gan=False,
+                                    feature=False, pixel_weight=1.0), steps=3, seed=11),
+    # reduced ESRGAN recipe: every loss, BN discriminator, 3 steps
+    "esrgan_nb1_crop64": dict(yaml=dict(nb=1, batch=2, crop=64, d_nf=16), steps=3, seed=21),
+    # pixel-shuffle upsampler variant (block.py:374-387,434-460)
+    "esrgan_nb1_pixelshuffle": dict(yaml=dict(nb=1, batch=2, crop=64, gan=False, feature=False,
+                                              upsample_mode="pixelshuffle"), steps=2, seed=31),
+    # full RRDBNet-23 + Discriminator_VGG(128, nf 64) + VGG19, one step at batch 2
+    "esrgan_nb23_crop128": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64), steps=1, seed=41),
+}
+
+G_SEED, D_SEED, F_SEED = 101, 202, 77
+
+
+def probe(t, n=48):
+    f = t.detach().flatten().to(torch.float64)
+    stride = max(1, f.numel() // n)
+    return {"samples": f[::stride][:n].clone(), "stride": stride, "l2": f.norm().item(),
+            "sum": f.sum().item(), "numel": f.numel()}
+
+
+def probe_state(sd):
+    return {k: probe(v.float()) for k, v in sd.items()}
+
+
+def run_case(name, spec):
+    yml = R.esrgan_yaml(name="golden_" + name, **spec["yaml"])
+    opt, model = R.build_reference_model(yml, seed=0)
+    detrand.fill_state_dict_(model.netG.state_dict(), G_SEED)
+    has_d = bool(getattr(model, "cri_gan", False))
+    if has_d:
+        detrand.fill_state_dict_(model.netD.state_dict(), D_SEED)
+    netF = R.reference_netF(model)
+    if netF is not None:
+        fsd = {k: v for k, v in netF.state_dict().items() if k.startswith("feature_net")}
+        detrand.fill_state_dict_(fsd, F_SEED, gain=1.0, bias_amp=0.05)
+
+    crop, batch = spec["yaml"]["crop"], spec["yaml"]["batch"]
+    grads = {}
+
+    def grab(tag, net):
+        def hook(optim, args, kwargs):
+            if tag not in grads:
+                grads[tag] = {k: probe(p.grad) for k, p in net.named_parameters() if p.grad is not None}
+        return hook
+
+    model.optimizer_G.register_step_pre_hook(grab("G", model.netG))
+    if has_d:
+        model.optimizer_D.register_step_pre_hook(grab("D", model.netD))
+
+    logs = []
+    for s in range(1, spec["steps"] + 1):
+        LR, HR = detrand.synthetic_pair(batch, crop, spec["seed"] + s)
+        logs.append(R.reference_step(model, LR, HR, s))
+    fx = {
+        "name": name, "spec": spec, "network_G": dict(opt["network_G"]),
+        "network_D": dict(opt["network_D"]) if has_d else None,
+        "seeds": {"G": G_SEED, "D": D_SEED, "F": F_SEED, "data": spec["seed"]},
+        "logs": logs, "fake_H": model.fake_H.detach().clone(),
+        "grads_step1": grads,
+        "g_state": probe_state(model.netG.state_dict()),
+        "d_state": probe_state(model.netD.state_dict()) if has_d else None,
+        "g_keys": [(k, tuple(v.shape)) for k, v in model.netG.state_dict().items()],
+        "d_keys": [(k, tuple(v.shape)) for k, v in model.netD.state_dict().items()] if has_d else None,
+        "torch": torch.__version__,
+    }
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(fx, path)
+    print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+    for l in logs:
+        print("   ", {k: round(v, 6) for k, v in l.items()})
+
+
+def main(argv):
+    torch.set_num_threads(os.cpu_count() or 1)
+    names = argv or list(CASES)
+    for n in names:
+        run_case(n, CASES[n])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,115 @@
+"""Drive the REAL reference (victorca25/traiNNer, read-only at /root/reference) on CPU.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product path (trainner_amd/).
+Only usable in the build container (the GPU box has no /root/reference); it is what
+`oracle/make_golden.py` uses to produce the committed fixtures in tests/golden/ and what
+pins `oracle/sr_oracle.py` (the travelling CPU restatement).
+
+Recipe = SURVEY.md 8(c) / Appendix A:
+  * stubs for cv2 / torchvision first on sys.path, then /root/reference/codes
+  * cwd = /root/reference/codes (preset lookup is relative: codes/options/options.py:177)
+  * gpu_ids: [] (CPU, no DataParallel: codes/models/base_model.py:76-81), use_amp: false
+  * network_G gaussian: false (codes/models/modules/architectures/block.py:592 is CUDA-only)
+"""
+import os
+import sys
+import tempfile
+import contextlib
+
+REF_ROOT = "/root/reference"
+REF_CODES = os.path.join(REF_ROOT, "codes")
+STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
+
+
+def reference_available():
+    return os.path.isdir(REF_CODES)
+
+
+@contextlib.contextmanager
+def reference_env():
+    """sys.path / cwd set up so `import models, options` resolve to the reference."""
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_CODES)
+    sys.dont_write_bytecode = True
+    old_path, old_cwd = list(sys.path), os.getcwd()
+    sys.path.insert(0, REF_CODES)
+    sys.path.insert(0, STUBS)
+    os.chdir(REF_CODES)
+    try:
+        yield
+    finally:
+        os.chdir(old_cwd)
+        sys.path[:] = old_path
+
+
+def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, model_G="esrgan",
+                gan=True, feature=True, pixel_weight=1e-2, grad_clip=True, upsample_mode=None,
+                out_root=None):
+    """A train_sr.yml-shaped config (codes/options/sr/train_sr.yml:1-195) for CPU."""
+    out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
+    if model_G == "esrgan":
+        netg = "network_G:\n  type: esrgan\n  gaussian: false\n  nb: %d\n  nf: %d\n" % (nb, nf)
+        if upsample_mode:
+            netg += "  upsample_mode: %s\n" % upsample_mode
+    else:
+        netg = "network_G:\n  type: sr_resnet\n  nb: %d\n  nf: %d\n" % (nb, nf)
+    netd = "network_D:\n  type: discriminator_vgg\n  nf: %d\n" % d_nf if gan else ""
+    train = [
+        "  optim_G: adam", "  optim_D: adam", "  lr_scheme: MultiStepLR",
+        "  lr_steps: [50000, 100000]", "  lr_gamma: 0.5",
+        "  pixel_criterion: l1", "  pixel_weight: %g" % pixel_weight,
+    ]
+    if feature:
+        train += ["  feature_criterion: l1", "  feature_weight: 1"]
+    if gan:
+        train += ["  gan_type: vanilla", "  gan_weight: 5e-3"]
+    train += ["  manual_seed: 0", "  niter: 500000", "  val_freq: 5000"]
+    if grad_clip:
+        train += ["  grad_clip: norm", "  grad_clip_value: 0.1"]
+    txt = "\n".join([
+        "name: %s" % name, "use_tb_logger: false", "model: sr", "scale: 4", "gpu_ids: []",
+        "use_amp: false", "use_swa: false", "use_cem: false", "use_atg: false",
+        "datasets:", "  train:", "    name: synth", "    mode: aligned",
+        "    dataroot_HR: /tmp/none_hr", "    dataroot_LR: /tmp/none_lr", "    znorm: false",
+        "    n_workers: 0", "    batch_size: %d" % batch, "    virtual_batch_size: %d" % batch,
+        "    preprocess: crop", "    crop_size: %d" % crop, "    image_channels: 3",
+        "path:", "  root: %s" % out_root,
+        netg.rstrip("\n"), netd.rstrip("\n"),
+        "train:", *train,
+        "logger:", "  print_freq: 1", "  save_checkpoint_freq: 1000000", ""])
+    path = os.path.join(out_root, name + ".yml")
+    with open(path, "w") as f:
+        f.write(txt)
+    return path
+
+
+def build_reference_model(yaml_path, seed=0):
+    """-> (opt, model) built by the reference's own options.parse / create_model."""
+    with reference_env():
+        for m in [k for k in sys.modules if k.split(".")[0] in
+                  ("models", "options", "utils", "dataops", "data", "cv2", "torchvision")]:
+            del sys.modules[m]
+        import options.options as O
+        from models import create_model
+        from utils import util
+        with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
+            opt = O.parse(yaml_path, is_train=True)
+        util.set_random_seed(seed)
+        model = create_model(opt, verbose=False)
+    return opt, model
+
+
+def reference_step(model, LR, HR, step):
+    """feed_data + optimize_parameters (codes/models/sr_model.py:115-128,195-267)."""
+    with reference_env():
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(step)
+    return dict(model.get_current_log())
+
+
+def reference_netF(model):
+    """The VGG FeatureExtractor inside GeneratorLoss (codes/models/losses.py:117-128)."""
+    for l in model.generatorlosses.loss_list:
+        if "fea" in l["name"]:
+            return l["function"].network
+    return None

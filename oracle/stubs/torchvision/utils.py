@@ -1,0 +1,2 @@
+def make_grid(*a, **k):
+    raise NotImplementedError("torchvision stub")

@@ -1,0 +1,53 @@
+"""Pin the CPU oracle (oracle/sr_oracle.py) to the REAL reference.
+
+tests/golden/*.pt were produced by oracle/make_golden.py from /root/reference itself
+(SRModel.feed_data + optimize_parameters on CPU).  The oracle restatement must reproduce the
+reference's logs, fake_H, step-1 gradients and post-step weights on the same inputs.
+Both sides are fp32 torch-CPU, so the tolerance is tight (summation-order noise only).
+"""
+import pytest
+import torch
+
+from oracle import fixtures as FX
+
+CASES = ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"]
+LOG_RTOL = 2e-5
+STATE_MEAN = 0.01     # mean |dp| in units of lr*steps (the largest possible Adam displacement)
+STATE_WORST = 0.6     # a noise-gradient element may flip sign once: bounded, not tight
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference(case):
+    torch.set_num_threads(8)
+    fx = FX.load(case)
+    orc = FX.oracle_for(fx)
+    for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
+        log = orc.step(LR, HR)
+        for k, v in ref_log.items():
+            assert k in log, k
+            assert abs(log[k] - v) <= LOG_RTOL * max(1.0, abs(v)) + 2e-6, (case, s, k, log[k], v)
+        if s == 1:
+            names = [k for k, _ in fx["g_keys"]]
+            for k, g in zip(names, orc.last_g_grads):
+                e_s, e_n = FX.probe_error(g, fx["grads_step1"]["G"][k])
+                assert e_s < 2e-3 and e_n < 2e-3, (case, "G grad", k, e_s, e_n)
+            if fx["d_keys"]:
+                pnames = [k for k, _ in fx["d_keys"] if k in fx["grads_step1"]["D"]]
+                shadow = FX.bn_shadowed_biases(fx["d_keys"])
+                for k, g in zip(pnames, orc.last_d_grads):
+                    if k in shadow:
+                        continue
+                    e_s, e_n = FX.probe_error(g, fx["grads_step1"]["D"][k])
+                    assert e_s < 2e-3 and e_n < 2e-3, (case, "D grad", k, e_s, e_n)
+    ref = fx["fake_H"]
+    diff = (orc.fake_H.detach() - ref).abs()
+    assert diff.max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), diff.max().item()
+    lr_steps = 1e-4 * fx["spec"]["steps"]
+    worst, mean, k = FX.state_error(orc.g_state(), fx["g_state"], lr_steps=lr_steps)
+    assert mean < STATE_MEAN and worst < STATE_WORST, ("G state", k, worst, mean)
+    if fx["d_keys"]:
+        worst, mean, k = FX.state_error(orc.d_state(), fx["d_state"], FX.bn_shadowed_biases(fx["d_keys"]),
+                                        lr_steps=lr_steps)
+        assert mean < STATE_MEAN and worst < STATE_WORST, ("D state", k, worst, mean)
+        e, k = FX.buffers_error(orc.d_state(), fx["d_state"])
+        assert e < 2e-3, ("D running stats", k, e)   # carries the BN-shadowed conv bias random walk
