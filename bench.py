@@ -1,0 +1,232 @@
+"""bench.py -- HR images/sec of the full G+D step (SRModel.optimize_parameters), ESRGAN x4 128->512.
+
+    python bench.py --gpus N --steps K --warmup W
+(N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce.)
+
+Workload = BASELINE.json configs[1]: RRDBNet-23 + Discriminator_VGG(512) + VGG19->conv5_4, batch 16
+per GPU (weak scaling), L1 + perceptual + relativistic GAN, clip + Adam -- fp32 on the matrix cores.
+Synthetic HR in [0,1), LR = avg_pool(HR, 4), resident in HBM before the timed region; random-init
+(kaiming x0.1) G/D and seeded VGG weights (no network access).  One JSON line on rank 0, with
+  roofline     : the dominant kernel family (3x3 implicit-GEMM, forward + data-gradient launches),
+                 algorithmic FLOP of every launch / HIP-event time of that launch, both summed over a
+                 separate instrumented pass of the same steps (events on the launch stream);
+  cpu_baseline : the CPU oracle (a port of the reference step) on this host's cores, batch 1, same
+                 shapes (N=1 runs only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_IMG = 3.0327e12           # full optimize_parameters, fp32, 128->512
+BATCH_PER_GPU = 16
+CROP = 512
+
+YAML = """
+name: bench_esrgan
+use_tb_logger: false
+model: sr
+scale: 4
+gpu_ids: [0]
+use_amp: false
+datasets:
+  train:
+    name: synthetic
+    mode: aligned
+    dataroot_HR: /tmp/none_hr
+    dataroot_LR: /tmp/none_lr
+    znorm: false
+    n_workers: 0
+    batch_size: {batch}
+    virtual_batch_size: {batch}
+    preprocess: crop
+    crop_size: {crop}
+path:
+  root: {root}
+network_G:
+  type: esrgan
+  gaussian: false
+network_D: discriminator_vgg
+train:
+  optim_G: adam
+  optim_D: adam
+  lr_scheme: MultiStepLR
+  lr_steps_rel: [0.1, 0.2, 0.4, 0.6]
+  lr_gamma: 0.5
+  pixel_criterion: l1
+  pixel_weight: 1e-2
+  feature_criterion: l1
+  feature_weight: 1
+  gan_type: vanilla
+  gan_weight: 5e-3
+  manual_seed: 0
+  niter: 5e5
+  val_freq: 5e3
+  grad_clip: norm
+  grad_clip_value: 0.1
+logger:
+  print_freq: 200
+  save_checkpoint_freq: 5e3
+"""
+
+
+def make_model(batch, crop, rank):
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    root = tempfile.mkdtemp(prefix="tnr_bench_r%d_" % rank)
+    path = os.path.join(root, "bench.yml")
+    with open(path, "w") as f:
+        f.write(YAML.format(batch=batch, crop=crop, root=root))
+    torch.manual_seed(1234)                       # identical replicas on every rank
+    opt = options.parse(path, is_train=True)
+    model = create_model(opt, verbose=False)
+    # VGG19: seeded He-normal weights (ImageNet weights cannot be downloaded here)
+    netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+    g = torch.Generator().manual_seed(1234)
+    sd = netF.state_dict()
+    for k, v in sd.items():
+        if k.endswith("weight") and v.dim() == 4:
+            fan_in = v.shape[1] * 9
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif k.endswith("bias"):
+            sd[k] = torch.zeros_like(v)
+    netF.load_state_dict(sd)
+    return model
+
+
+def synthetic(batch, crop, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    hr = torch.rand(batch, 3, crop, crop, generator=g)
+    lr = torch.nn.functional.avg_pool2d(hr, 4)
+    return lr.to(device), hr.to(device)
+
+
+def cpu_baseline(crop, steps=2):
+    """The reference step as ported in oracle/sr_oracle.py, timed on this host's cores (batch 1)."""
+    from oracle import detrand, sr_oracle as O
+    from trainner_amd.models.modules.architectures import RRDBNet_arch, discriminators
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = {k: v.detach().clone() for k, v in RRDBNet_arch.RRDBNet(3, 3, 64, 23).state_dict().items()}
+    d = {k: v.detach().clone() for k, v in discriminators.Discriminator_VGG(crop, 3, 64).state_dict().items()}
+    detrand.fill_state_dict_(g, 101, gain=0.1)
+    detrand.fill_state_dict_(d, 202, gain=0.1)
+    orc = O.OracleSRStep(g, d, O.vgg19_seeded_state(), arch="rrdb_net", nb=23, d_size=crop, d_nf=64)
+    LR, HR = detrand.synthetic_pair(1, crop, 7)
+    orc.step(LR, HR)                                # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        orc.step(LR, HR)
+    dt = (time.time() - t0) / steps
+    return {"value": round(1.0 / dt, 4), "unit": "HR img/s", "cores": cores, "kind": "port",
+            "sample": "oracle/sr_oracle.py OracleSRStep (port of SRModel.optimize_parameters), ESRGAN RRDBNet-23 + "
+                      "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--crop", type=int, default=CROP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    from trainner_amd import hip, ops
+    hip.require_device()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    model = make_model(args.batch, args.crop, rank)
+    LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)
+    data = {"LR": LR, "HR": HR}
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    log = model.get_current_log()
+
+    roof = None
+    if not args.no_roofline:
+        # separate instrumented pass: HIP events around every implicit-GEMM launch, on the launch stream
+        prof = ops.ConvProfile()
+        ops.PROFILE = prof
+        nprof = min(2, args.steps)
+        for _ in range(nprof):
+            step += 1
+            model.feed_data(data)
+            model.optimize_parameters(step)
+        ops.PROFILE = None
+        summ = prof.summary()
+        dom = summ.get("conv_tile_3x3")
+        if dom:
+            tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
+            roof = {"bound": "mfma", "kernel": "conv_tile_kernel<3x3> (forward + data-gradient launches)",
+                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"] // nprof,
+                    "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+                    "flop_per_launch_avg": dom["flops"] / dom["launches"],
+                    "kernel_ms_per_step": per_step_ms}
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        out = {
+            "metric": "HR images/sec (G+D step), ESRGAN x4 128->512",
+            "value": round(imgs / dt, 3), "unit": "HR img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
+                                   "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "step_tflops": round(FLOP_PER_IMG * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
+            "roofline": roof,
+            "losses": {k: round(v, 6) for k, v in log.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.crop)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/*
+ * trainner_hip.h -- C ABI of libtrainner_hip.so: the MI355X (gfx950) kernels behind the
+ * ESRGAN/RRDBNet SR training step of victorca25/traiNNer.
+ *
+ * The reference has NO native boundary (it is 100 % Python on stock ATen kernels), so this ABI
+ * is the boundary a maintainer would bind with ctypes.  Every entry point
+ * names the reference call site whose arithmetic it replaces; paths are relative to
+ * /root/reference/codes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers
+ *     owned by the caller; nothing is allocated inside (workspaces are passed in explicitly).
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void*; 0 = null stream).
+ *   - return value: 0 = ok, negative = TNR_E*; tnr_last_error() gives a message.
+ *   - activations are fp32 NHWC "views": element (n,y,x,c) of a view lives at
+ *         ptr[ ((n*H + y)*W + x) * ctot + coff + c ]
+ *     so a dense-block buffer (ctot = 192) is addressed in place -- torch.cat
+ *     (RRDBNet_arch.py:152-160) never materialises.  ctot and coff are multiples of 4.
+ *   - weights cross the boundary in PyTorch's OIHW layout (state_dict compatible) and are
+ *     re-laid out on device by tnr_pack_weights into the K-chunked [tap][kout][kin] form.
+ */
+#ifndef TRAINNER_HIP_H
+#define TRAINNER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNR_OK 0
+#define TNR_EINVAL (-1)   /* bad argument / unsupported shape */
+#define TNR_ELAUNCH (-2)  /* HIP launch / runtime error */
+
+enum { TNR_ACT_NONE = 0, TNR_ACT_LRELU = 1, TNR_ACT_RELU = 2 };
+
+/* conv geometries on the path */
+enum {
+    TNR_CONV_3x3 = 0,      /* k3 s1 p1: every G / VGG conv, D odd layers (block.py:214-256)              */
+    TNR_CONV_3x3_UP2 = 1,  /* nearest x2 (block.py:326-371,390-404) folded into the k3 s1 p1 gather       */
+    TNR_CONV_4x4_S2 = 2,   /* k4 s2 p1: Discriminator_VGG even layers (discriminators.py:24-34)           */
+    TNR_DGRAD_4x4_S2 = 3   /* data-gradient of k4 s2 p1 (aten convolution_backward), parity-decomposed    */
+};
+
+/* weight packings produced by tnr_pack_weights */
+enum {
+    TNR_PACK_FWD = 0,       /* [kh*kw][KoutP][KinP]            <- W[co][ci][ky][kx]                         */
+    TNR_PACK_DGRAD_3x3 = 1, /* [9][KoutP=ci][KinP=co]          <- W[co][ci][2-ky][2-kx]                     */
+    TNR_PACK_FWD_S2D = 2,   /* [4][KoutP][4*KinP] (space-to-depth view of k4 s2)                           */
+    TNR_PACK_DGRAD_S2 = 3   /* [4 parities][4][KoutP=ci][KinP=co]                                          */
+};
+
+typedef struct tnr_view {
+    float *ptr;
+    int32_t ctot; /* channels per pixel of the underlying buffer */
+    int32_t coff; /* first channel of this view                  */
+} tnr_view;
+
+/* One tiled implicit-GEMM convolution (forward, or data-gradient with dgrad-packed weights).
+ * Replaces nn.Conv2d.forward + bias + (Leaky)ReLU(inplace) of block.conv_block (block.py:214-256),
+ * the `x5*0.2 + x` / `out*0.2 + x` residuals (RRDBNet_arch.py:96,163), ShortcutBlock's add
+ * (block.py:184-195), and in the backward direction aten::convolution_backward(input) with the
+ * following leaky_relu_backward fused as a mask.
+ *   v = act(acc + bias[c]);  v = v*alpha + (c < r1_ch ? beta1*r1[c] : 0);  if r2: v = v*alpha2 + r2[c];
+ *   if m and m_lo <= c < m_hi:  v *= (m[c] > 0 ? 1 : m_slope);   y[c] = v                              */
+typedef struct tnr_conv_desc {
+    tnr_view x;            /* input activation (or incoming gradient for dgrad)               */
+    int32_t N, H, W;       /* batch and SOURCE spatial size of x                               */
+    int32_t Cin;           /* valid reduction channels in x                                    */
+    const float *wp;       /* packed weights (tnr_pack_weights)                                */
+    int32_t KinP, KoutP;   /* padded dims of the packing                                       */
+    tnr_view y;            /* output                                                           */
+    int32_t Ho, Wo, Cout;  /* output spatial size and channels stored                          */
+    int32_t mode;          /* TNR_CONV_* */
+    const float *bias;     /* [Cout] or NULL                                                   */
+    int32_t act;           /* TNR_ACT_* applied to acc+bias                                    */
+    float slope;
+    float alpha;
+    tnr_view r1; int32_t r1_ch; float beta1;   /* r1.ptr NULL = none */
+    tnr_view r2; float alpha2;                 /* r2.ptr NULL = none */
+    tnr_view m;  int32_t m_lo, m_hi; float m_slope; /* m.ptr NULL = none */
+} tnr_conv_desc;
+
+/* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
+ * (aten::convolution_backward(weight, bias)), pixel-split into deterministic partial slabs in `ws`
+ * and reduced in a fixed order.  The launch covers input channels [cin_begin, cin_begin+Cin) of a
+ * layer whose weight tensor has cin_total input channels.                                        */
+typedef struct tnr_wgrad_desc {
+    tnr_view x; int32_t N, H, W; int32_t Cin;      /* layer input view (already offset to cin_begin) */
+    tnr_view g; int32_t Ho, Wo; int32_t Cout;      /* gradient w.r.t. the conv output (pre-activation) */
+    int32_t mode;                                  /* TNR_CONV_3x3 | _3x3_UP2 | _4x4_S2               */
+    float *dw; int32_t cin_total, cin_begin;       /* OIHW gradient tensor                            */
+    float *db;                                     /* [Cout] or NULL (only with cin_begin == 0)        */
+    float alpha, beta;
+    float *ws; int64_t ws_bytes;                   /* >= tnr_wgrad_workspace_bytes()                  */
+} tnr_wgrad_desc;
+
+typedef struct tnr_pack_item {
+    const float *w;  /* OIHW */
+    float *wp;
+    int32_t Cout, Cin, kh, kw;
+    int32_t kind;    /* TNR_PACK_* */
+    int32_t KoutP, KinP;
+    int64_t n_out;   /* number of packed floats */
+} tnr_pack_item;
+
+const char *tnr_last_error(void);
+int tnr_version(void);
+
+/* --- convolution family ---------------------------------------------------------------------- */
+int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t kind,
+                  int32_t *KoutP, int32_t *KinP, int64_t *n_out);
+/* items: DEVICE array of n descriptors; max_out = max n_out over the items */
+int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
+int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
+int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
+int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
+
+/* --- layout / resampling (block.py:326-371 Upsample, :374-387,434-460 PixelShuffle; nn.MaxPool2d) */
+int tnr_nchw_to_nhwc(const float *src, int32_t N, int32_t C, int32_t H, int32_t W, tnr_view dst,
+                     int32_t Cpad, const float *scale, const float *shift, void *stream);
+int tnr_nhwc_to_nchw(tnr_view src, int32_t N, int32_t C, int32_t H, int32_t W, float *dst,
+                     const float *scale, int32_t accumulate, void *stream);
+int tnr_upsample2x_bwd(tnr_view gup, tnr_view gx, int32_t N, int32_t H, int32_t W, int32_t C,
+                       tnr_view mask, float mslope, void *stream);
+int tnr_depth_to_space(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t Cout, void *stream);
+int tnr_space_to_depth_bwd(tnr_view gy, tnr_view gx, int32_t N, int32_t H, int32_t W, int32_t Cout,
+                           tnr_view mask, float mslope, void *stream);
+int tnr_maxpool2_fwd(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, void *stream);
+int tnr_maxpool2_bwd(tnr_view gy, tnr_view x, tnr_view gx, int32_t N, int32_t H, int32_t W, int32_t C,
+                     void *stream);
+int tnr_axpby(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, float a, float b, void *stream);
+int tnr_mask_mul(tnr_view g, tnr_view y, int64_t pixels, int32_t C, float mslope, void *stream);
+int tnr_fill(float *p, int64_t n, float v, void *stream);
+
+/* --- BatchNorm2d training mode (nn.BatchNorm2d via block.norm, block.py:112-134) + LeakyReLU ---- */
+int64_t tnr_bn_workspace_bytes(int32_t C);
+int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, int64_t *num_batches,
+                     float momentum, float eps, float *save_mean, float *save_invstd, int32_t act,
+                     float slope, void *ws, void *stream);
+int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int64_t pixels, int32_t C,
+                     const float *gamma, const float *save_mean, const float *save_invstd, float mslope,
+                     float *dgamma, float *dbeta, float acc_beta, void *ws, void *stream);
+
+/* --- classifier (nn.Linear, discriminators.py:40-45) ------------------------------------------- */
+int tnr_linear_fwd(const float *x, const float *w, const float *b, float *y, int32_t N, int32_t In,
+                   int32_t Out, int32_t act, float slope, void *stream);
+int tnr_linear_bwd(const float *x, const float *w, const float *gy, const float *yact, float mslope,
+                   float *gx, float *dw, float *db, int32_t N, int32_t In, int32_t Out, float acc_beta,
+                   float *gpre_ws, void *stream);
+
+/* --- losses (nn.L1Loss losses.py:37-39; GANLoss loss.py:61-137; Adversarial losses.py:428-433,503-512) */
+int64_t tnr_reduce_workspace_bytes(void);
+int tnr_l1_mean_fwd(const float *a, const float *b, int64_t n, float scale, float *loss, void *ws,
+                    void *stream);
+int tnr_l1_mean_bwd(const float *a, const float *b, int64_t n, float scale, const float *gscale,
+                    float *ga, int32_t accumulate, void *stream);
+/* relativistic BCE, three phases so that the two 2-scalar sums can be all-reduced between them
+ * (SURVEY.md 8(e)); sums = 8 floats on device.  stage 0 = generator, 1 = discriminator.           */
+int tnr_ragan_phase_a(const float *pf, const float *pr, int32_t n, float *sums, void *stream);
+int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, int32_t stage, float *sums, void *stream);
+int tnr_ragan_phase_c(const float *pf, const float *pr, int32_t n, int32_t stage, float weight,
+                      const float *sums, float *loss_out, float *gf, float *gr, void *stream);
+int tnr_scale_by(float *dst, const float *src, int64_t n, const float *gscale, void *stream);
+
+/* --- optimiser (torch.optim.Adam optimizers.py:130-132; clip_grad_norm_ base_model.py:911-922) -- */
+int tnr_sumsq(const float *g, int64_t n, double *out, void *ws, void *stream);
+int tnr_clip_by_norm(float *g, int64_t n, const double *sumsq, float max_norm, void *stream);
+int tnr_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float step_size, float b1,
+                  float b2, float bc2_sqrt, float eps, float weight_decay, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

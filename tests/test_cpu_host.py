@@ -1,0 +1,135 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol the header
+declares, the options loader reproduces the reference's parsed network dicts, the engine's networks
+expose the reference's state_dict keys/shapes, checkpoints round-trip, and the host-side logic
+(flat parameters, fused-Adam state layout) behaves -- no kernel is launched here.
+"""
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import fixtures as FX, ref_harness
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_match_header():
+    from trainner_amd import hip
+    lib = hip.load()
+    hdr = open(os.path.join(ROOT, "include", "trainner_hip.h")).read()
+    declared = set(re.findall(r"\b(tnr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.tnr_version() >= 1
+
+
+def test_no_device_fails_loudly():
+    from trainner_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    with pytest.raises(hip.HipEngineError):
+        hip.require_device()
+    from trainner_amd.models.modules.architectures.RRDBNet_arch import RRDBNet
+    net = RRDBNet(3, 3, 64, 1)
+    with pytest.raises(hip.HipEngineError):
+        net(torch.zeros(1, 3, 8, 8))          # no CPU / eager fallback exists
+
+
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"])
+def test_options_and_state_dict_contract(case, tmp_path):
+    """options.parse expands to the dicts the REAL reference produced (stored in the fixtures) and the
+    engine's networks carry exactly the reference's state_dict keys and shapes."""
+    from trainner_amd.options import options
+    from trainner_amd.models import networks
+    fx = FX.load(case)
+    yml = ref_harness.esrgan_yaml(name="contract", out_root=str(tmp_path), gpu_ids="[0]", **fx["spec"]["yaml"])
+    opt = options.parse(yml, is_train=True)
+    assert dict(opt["network_G"]) == fx["network_G"]
+    assert opt["train"]["no_such_key"] is None                       # NoneDict semantics
+    assert opt["path"]["models"].endswith(os.path.join("experiments", "contract", "models"))
+    netG = networks.define_G(opt)
+    assert [(k, tuple(v.shape)) for k, v in netG.state_dict().items()] == fx["g_keys"]
+    if fx["network_D"]:
+        assert dict(opt["network_D"]) == fx["network_D"]
+        netD = networks.define_D(opt)
+        assert [(k, tuple(v.shape)) for k, v in netD.state_dict().items()] == fx["d_keys"]
+
+
+def test_yaml_scientific_notation_and_json(tmp_path):
+    from trainner_amd.options import options
+    y = tmp_path / "a.yml"
+    y.write_text("a: 1e-4\nb: 5e5\nc: [0.1, 2]\nd: {e: null}\n")
+    o = options.read_yaml(str(y))
+    assert o["a"] == 1e-4 and isinstance(o["b"], float) and o["d"]["e"] is None
+    j = tmp_path / "a.json"
+    j.write_text('{ "a": 1, // comment\n "b": {"c": [1,2]} }')
+    assert options.read_json(str(j))["b"]["c"] == [1, 2]
+    nd = options.dict_to_nonedict({"x": {"y": 1}, "l": [{"z": 2}]})
+    assert nd["x"]["q"] is None and nd["l"][0]["w"] is None
+    assert options.opt_get(nd, ["x", "y"]) == 1 and options.opt_get(nd, ["x", "nope"], 7) == 7
+
+
+def test_defaults_reject_off_path_kinds():
+    from trainner_amd.options import defaults
+    with pytest.raises(NotImplementedError):
+        defaults.get_network_G_config("pan", 4, 128)
+    with pytest.raises(NotImplementedError):
+        defaults.get_network_D_config("patchgan", 4, 128, "rrdb_net")
+    g = defaults.get_network_G_config("esrgan", 4, 128)
+    assert g["type"] == "rrdb_net" and g["nb"] == 23 and g["upsample_mode"] == "upconv" and g["gaussian_noise"] is True
+    d = defaults.get_network_D_config("discriminator_vgg", 4, 128, "rrdb_net")
+    assert d["size"] == 128 and d["base_nf"] == 64 and d["arch"] == "ESRGAN"
+
+
+def test_flat_params_and_checkpoint_roundtrip(tmp_path):
+    from trainner_amd.models.modules.architectures.RRDBNet_arch import RRDBNet
+    net = RRDBNet(3, 3, 64, 1)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = net.flat_params()
+    assert fp.total >= sum(p.numel() for p in net.parameters())
+    for p in net.parameters():
+        assert p.grad is not None and p.grad.shape == p.shape
+        assert fp.flat.data_ptr() <= p.data_ptr() < fp.flat.data_ptr() + 4 * fp.total
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, before[k])
+    # legacy-format checkpoint round trip through the reference-shaped keys
+    path = tmp_path / "g.pth"
+    torch.save({k: v.cpu() for k, v in net.state_dict().items()}, str(path), _use_new_zipfile_serialization=False)
+    net2 = RRDBNet(3, 3, 64, 1)
+    net2.load_state_dict(torch.load(str(path), weights_only=False))
+    for (k1, v1), (k2, v2) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    # in-place load keeps the flat views attached
+    fp2 = net.flat_params()
+    net.load_state_dict(before)
+    assert net.flat_params() is fp2 and fp2._consistent()
+
+
+def test_fused_adam_state_layout_matches_torch_adam():
+    from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
+    from trainner_amd.models.optimizers import FusedAdam
+    net = SRResNet(3, 3, 32, 1)
+    net.flat_params()
+    opt = FusedAdam(list(net.parameters()), lr=1e-4)
+    for g in opt.param_groups:
+        opt._ensure_state(g)
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(list(net.parameters()), lr=1e-4)
+    assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "params"}
+    assert sd["param_groups"][0]["params"] == ref.state_dict()["param_groups"][0]["params"]
+    some = sd["state"][0]
+    assert set(some) == {"step", "exp_avg", "exp_avg_sq"}
+    opt.load_state_dict(sd)                                            # moments are re-homed into flat buffers
+    p0 = opt.param_groups[0]["params"][0]
+    assert opt.state[p0]["exp_avg"].shape == p0.shape
+
+
+def test_psnr_definition():
+    from oracle import sr_oracle as O
+    a = torch.zeros(1, 3, 16, 16)
+    b = torch.full((1, 3, 16, 16), 10.0 / 255.0)
+    import math
+    assert abs(O.psnr_reference(a, b) - 20 * math.log10(255.0 / 10.0)) < 1e-9

@@ -1,0 +1,387 @@
+"""Kernel-level parity (-m gpu): every C-ABI op against a plain fp32 PyTorch-CPU statement of the
+same op (F.conv2d + autograd, F.batch_norm, ...), on shapes that exercise ragged tiles, channel
+windows of wider buffers (the dense-block layout), 3/4-channel images and every conv geometry.
+Tolerance: fp32 round-off only -- max |err| <= 2e-5 * (max |ref| + 1) unless stated.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from trainner_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    from oracle.detrand import uniform
+    return uniform(shape, seed, lo, hi)
+
+
+def nhwc_buf(x_nchw, ctot=None, coff=0, fill=7.0):
+    """NCHW cpu tensor -> NHWC cuda buffer with `ctot` channels, data at [coff, coff+C)."""
+    N, C, H, W = x_nchw.shape
+    ctot = ctot or C
+    buf = torch.full((N, H, W, ctot), fill, dtype=torch.float32)
+    buf[..., coff:coff + C] = x_nchw.permute(0, 2, 3, 1)
+    return buf.to(DEV).contiguous()
+
+
+def to_nchw(buf, coff, C):
+    return buf[..., coff:coff + C].permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def close(got, ref, tol=2e-5, what=""):
+    scale = ref.abs().max().item() + 1.0
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3e)" % (what, err, scale)
+
+
+def pack(ops, w, kind):
+    p = ops.WeightPacker(torch.device(DEV))
+    i = p.add(w, kind)
+    p.run()
+    return p.get(i), p
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, x_ctot, x_coff, y_ctot, y_coff
+    (2, 20, 37, 64, 32, 192, 0, 192, 64),
+    (1, 33, 33, 96, 32, 192, 0, 192, 96),
+    (2, 16, 16, 192, 64, 192, 0, 64, 0),
+    (1, 9, 40, 4, 64, 4, 0, 64, 0),       # image input (3 valid channels + zero pad)
+    (1, 40, 9, 64, 3, 64, 0, 4, 0),       # image output
+    (2, 8, 8, 128, 96, 128, 0, 96, 0),    # Cout not a multiple of 64, small tile (TW=8)
+    (1, 18, 18, 32, 160, 32, 0, 160, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3_forward(case):
+    ops = _ops()
+    N, H, W, Cin, Cout, xct, xco, yct, yco = case
+    cin_real = 3 if Cin == 4 else Cin
+    x = rnd(N, cin_real, H, W, seed=1)
+    w = rnd(Cout, cin_real, 3, 3, seed=2, lo=-0.2, hi=0.2)
+    b = rnd(Cout, seed=3)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    xb = nhwc_buf(F.pad(x, (0, 0, 0, 0, 0, Cin - cin_real)), xct, xco, fill=0.0 if Cin == 4 else 7.0)
+    yb = torch.full((N, H, W, yct), -3.0, device=DEV)
+    wd, bd = w.to(DEV), b.to(DEV)
+    wp, _keep = pack(ops, wd, ops.PACK_FWD)
+    ops.conv(ops.View(xb, xco, Cin), wp, ops.View(yb, yco, Cout), bias=bd, act=ops.ACT_LRELU, slope=0.2)
+    torch.cuda.synchronize()
+    close(to_nchw(yb, yco, Cout), ref, what="conv3x3 fwd")
+    # channels outside the output window are untouched
+    mask = torch.ones(yct, dtype=torch.bool)
+    mask[yco:yco + Cout] = False
+    assert (yb[..., mask.to(DEV)] == -3.0).all()
+
+
+def test_conv3x3_epilogue_residuals_and_mask():
+    ops = _ops()
+    N, H, W, Cin, Cout = 2, 19, 35, 64, 64
+    x, w, b = rnd(N, Cin, H, W, seed=4), rnd(Cout, Cin, 3, 3, seed=5, lo=-0.1, hi=0.1), rnd(Cout, seed=6)
+    r1, r2, m = rnd(N, Cout, H, W, seed=7), rnd(N, Cout, H, W, seed=8), rnd(N, Cout, H, W, seed=9)
+    conv = F.conv2d(x, w, b, padding=1)
+    ref = (conv * 0.2 + 0.5 * r1)
+    ref[:, 32:] = (conv * 0.2)[:, 32:]                       # r1 applies to channels < r1_ch only
+    ref = ref * 0.3 + r2
+    mm = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    ref[:, 16:48] = ref[:, 16:48] * mm[:, 16:48]
+    xb, r1b, r2b, mb = nhwc_buf(x), nhwc_buf(r1), nhwc_buf(r2, 96, 32), nhwc_buf(m)
+    yb = torch.zeros((N, H, W, Cout), device=DEV)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_FWD)
+    ops.conv(ops.View(xb), wp, ops.View(yb), bias=b.to(DEV), alpha=0.2, r1=ops.View(r1b), r1_ch=32, beta1=0.5,
+             r2=ops.View(r2b, 32, Cout), alpha2=0.3, mask=ops.View(mb), m_lo=16, m_hi=48, m_slope=0.2)
+    close(to_nchw(yb, 0, Cout), ref, what="epilogue")
+
+
+def test_conv3x3_inplace_accumulate():
+    """dgrad-style `y += conv(x)` where y and x are disjoint channel windows of ONE buffer."""
+    ops = _ops()
+    N, H, W = 1, 24, 40
+    g = rnd(N, 192, H, W, seed=10)
+    w = rnd(160, 32, 3, 3, seed=11, lo=-0.1, hi=0.1)
+    ref = g[:, :160] + F.conv2d(g[:, 160:192], w, None, padding=1)
+    gb = nhwc_buf(g)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_FWD)
+    acc = ops.View(gb, 0, 160)
+    ops.conv(ops.View(gb, 160, 32), wp, acc, r1=acc, beta1=1.0)
+    close(to_nchw(gb, 0, 160), ref, what="in-place accumulate")
+    close(to_nchw(gb, 160, 32), g[:, 160:192], tol=0, what="input window untouched")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 21, 64, 64), (1, 16, 16, 64, 32)])
+def test_conv3x3_up2_forward(shape):
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    x, w, b = rnd(N, Cin, H, W, seed=12), rnd(Cout, Cin, 3, 3, seed=13, lo=-0.1, hi=0.1), rnd(Cout, seed=14)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    xb = nhwc_buf(x)
+    yb = torch.zeros((N, 2 * H, 2 * W, Cout), device=DEV)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_FWD)
+    ops.conv(ops.View(xb), wp, ops.View(yb), mode=ops.CONV_3x3_UP2, bias=b.to(DEV))
+    close(to_nchw(yb, 0, Cout), ref, what="conv3x3 up2")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 16, 16), (1, 64, 64, 64, 64), (2, 8, 8, 128, 96), (1, 16, 16, 32, 160)])
+def test_conv4x4s2_forward(shape):
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    x, w, b = rnd(N, Cin, H, W, seed=15), rnd(Cout, Cin, 4, 4, seed=16, lo=-0.1, hi=0.1), rnd(Cout, seed=17)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    xb = nhwc_buf(x)
+    yb = torch.zeros((N, H // 2, W // 2, Cout), device=DEV)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_FWD_S2D)
+    ops.conv(ops.View(xb), wp, ops.View(yb), mode=ops.CONV_4x4_S2, bias=b.to(DEV))
+    close(to_nchw(yb, 0, Cout), ref, what="conv4x4s2")
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64, 32), (1, 16, 16, 192, 64), (1, 12, 12, 3, 64), (1, 10, 34, 64, 3)])
+def test_dgrad3x3(shape):
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    x = rnd(N, Cin, H, W, seed=18).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=19, lo=-0.1, hi=0.1)
+    g = rnd(N, Cout, H, W, seed=20)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, padding=1), x, g)
+    cg = (Cout + 3) // 4 * 4
+    gb = nhwc_buf(F.pad(g, (0, 0, 0, 0, 0, cg - Cout)), fill=0.0)
+    co = (Cin + 3) // 4 * 4
+    yb = torch.zeros((N, H, W, co), device=DEV)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_DGRAD_3x3)
+    ops.conv(ops.View(gb), wp, ops.View(yb, 0, Cin), mode=ops.CONV_3x3)
+    close(to_nchw(yb, 0, Cin), ref, what="dgrad3x3")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48, 16, 16), (1, 16, 16, 64, 64), (1, 8, 8, 128, 96)])
+def test_dgrad4x4s2(shape):
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    x = rnd(N, Cin, H, W, seed=21).requires_grad_(True)
+    w = rnd(Cout, Cin, 4, 4, seed=22, lo=-0.1, hi=0.1)
+    g = rnd(N, Cout, H // 2, W // 2, seed=23)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, stride=2, padding=1), x, g)
+    gb = nhwc_buf(g)
+    yb = torch.zeros((N, H, W, Cin), device=DEV)
+    wp, _k = pack(ops, w.to(DEV), ops.PACK_DGRAD_S2)
+    ops.conv(ops.View(gb), wp, ops.View(yb), mode=ops.DGRAD_4x4_S2)
+    close(to_nchw(yb, 0, Cin), ref, what="dgrad4x4s2")
+
+
+WGRAD_CASES = [
+    # mode, N, H, W, Cin, Cout
+    ("3x3", 2, 20, 37, 64, 32), ("3x3", 1, 24, 24, 96, 32), ("3x3", 1, 16, 16, 128, 32), ("3x3", 2, 16, 16, 192, 64),
+    ("3x3", 1, 17, 19, 64, 64), ("3x3", 1, 12, 20, 3, 64), ("3x3", 1, 12, 20, 64, 3), ("3x3", 1, 8, 8, 128, 160),
+    ("up2", 1, 10, 12, 64, 64), ("s2", 2, 32, 48, 16, 16), ("s2", 1, 16, 16, 64, 64), ("s2", 1, 8, 8, 128, 96),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad(case):
+    ops = _ops()
+    mode, N, H, W, Cin, Cout = case
+    x = rnd(N, Cin, H, W, seed=24)
+    if mode == "3x3":
+        w = rnd(Cout, Cin, 3, 3, seed=25).requires_grad_(True)
+        y = F.conv2d(x, w, None, padding=1)
+        m = ops.CONV_3x3
+    elif mode == "up2":
+        w = rnd(Cout, Cin, 3, 3, seed=25).requires_grad_(True)
+        y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, padding=1)
+        m = ops.CONV_3x3_UP2
+    else:
+        w = rnd(Cout, Cin, 4, 4, seed=25).requires_grad_(True)
+        y = F.conv2d(x, w, None, stride=2, padding=1)
+        m = ops.CONV_4x4_S2
+    g = rnd(*y.shape, seed=26)
+    (ref_w,) = torch.autograd.grad(y, w, g)
+    ref_b = g.sum(dim=(0, 2, 3))
+    ci4, co4 = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xb = nhwc_buf(F.pad(x, (0, 0, 0, 0, 0, ci4 - Cin)), fill=0.0)
+    gb = nhwc_buf(F.pad(g, (0, 0, 0, 0, 0, co4 - Cout)), fill=0.0)
+    dw0 = rnd(*w.shape, seed=27)
+    db0 = rnd(Cout, seed=28)
+    dw, db = dw0.to(DEV), db0.to(DEV)
+    ops.wgrad(ops.View(xb, 0, Cin), ops.View(gb, 0, Cout), dw, db, mode=m, alpha=0.5, beta=1.0)
+    scale = ref_w.abs().max().item() + 1.0
+    assert (dw.cpu() - (dw0 + 0.5 * ref_w)).abs().max().item() <= 5e-5 * scale, "wgrad weights"
+    assert (db.cpu() - (db0 + 0.5 * ref_b)).abs().max().item() <= 5e-5 * (ref_b.abs().max().item() + 1), "wgrad bias"
+
+
+def test_wgrad_cin_split():
+    """160 input channels as 96 + 64 (how the dense block's conv4 is launched)."""
+    ops = _ops()
+    N, H, W, Cin, Cout = 1, 16, 24, 160, 32
+    x, g = rnd(N, Cin, H, W, seed=29), rnd(N, Cout, H, W, seed=30)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x, w, None, padding=1), w, g)
+    xb, gb = nhwc_buf(x, 192, 0), nhwc_buf(g, 192, 160)
+    dw = torch.zeros(Cout, Cin, 3, 3, device=DEV)
+    gv = ops.View(gb, 160, Cout)
+    ops.wgrad(ops.View(xb, 0, 96), gv, dw, None, cin_begin=0)
+    ops.wgrad(ops.View(xb, 96, 64), gv, dw, None, cin_begin=96)
+    close(dw.cpu(), ref, tol=5e-5, what="wgrad cin split")
+
+
+def test_layout_roundtrip_and_norm():
+    ops = _ops()
+    x = rnd(2, 3, 10, 14, seed=31)
+    scale, shift = torch.tensor([2.0, 3.0, 4.0]), torch.tensor([0.1, 0.2, 0.3])
+    buf = torch.full((2, 10, 14, 4), 9.0, device=DEV)
+    ops.nchw_to_nhwc(x.to(DEV), ops.View(buf), Cpad=4, scale=scale.to(DEV), shift=shift.to(DEV))
+    ref = x * scale.view(1, 3, 1, 1) + shift.view(1, 3, 1, 1)
+    close(to_nchw(buf, 0, 3), ref, tol=1e-6, what="nchw->nhwc")
+    assert (buf[..., 3] == 0).all()
+    out = torch.full((2, 3, 10, 14), 1.0, device=DEV)
+    ops.nhwc_to_nchw(ops.View(buf, 0, 3), out, scale=scale.to(DEV), accumulate=True)
+    close(out.cpu(), ref * scale.view(1, 3, 1, 1) + 1.0, tol=1e-6, what="nhwc->nchw")
+
+
+def test_upsample_pixelshuffle_pool():
+    ops = _ops()
+    N, H, W, C = 2, 6, 10, 64
+    # nearest x2 backward with mask
+    gup, m = rnd(N, C, 2 * H, 2 * W, seed=32), rnd(N, C, H, W, seed=33)
+    ref = F.avg_pool2d(gup, 2) * 4 * torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    gx = torch.zeros((N, H, W, C), device=DEV)
+    ops.upsample2x_bwd(ops.View(nhwc_buf(gup)), ops.View(gx), mask=ops.View(nhwc_buf(m)), mslope=0.2)
+    close(to_nchw(gx, 0, C), ref, tol=1e-6, what="upsample2x bwd")
+    # pixel shuffle forward / backward
+    x = rnd(N, 4 * C, H, W, seed=34)
+    ref = F.pixel_shuffle(x, 2)
+    y = torch.zeros((N, 2 * H, 2 * W, C), device=DEV)
+    ops.depth_to_space(ops.View(nhwc_buf(x)), ops.View(y))
+    close(to_nchw(y, 0, C), ref, tol=0, what="depth_to_space")
+    gy = rnd(N, C, 2 * H, 2 * W, seed=35)
+    mk = torch.where(ref > 0, torch.ones_like(ref), torch.zeros_like(ref))
+    refg = F.pixel_unshuffle(gy * mk, 2)
+    gxx = torch.zeros((N, H, W, 4 * C), device=DEV)
+    ops.space_to_depth_bwd(ops.View(nhwc_buf(gy)), ops.View(gxx), mask=ops.View(y), mslope=0.0)
+    close(to_nchw(gxx, 0, 4 * C), refg, tol=0, what="space_to_depth bwd")
+    # max pool forward / backward (through ReLU)
+    a = F.relu(rnd(N, C, 2 * H, 2 * W, seed=36)).requires_grad_(True)
+    pooled = F.max_pool2d(a, 2, 2)
+    gp = rnd(N, C, H, W, seed=37)
+    pre = rnd(N, C, 2 * H, 2 * W, seed=36).requires_grad_(True)
+    (refgx,) = torch.autograd.grad(F.max_pool2d(F.relu(pre), 2, 2), pre, gp)
+    ab = nhwc_buf(a.detach())
+    pb = torch.zeros((N, H, W, C), device=DEV)
+    ops.maxpool2_fwd(ops.View(ab), ops.View(pb))
+    close(to_nchw(pb, 0, C), pooled.detach(), tol=0, what="maxpool fwd")
+    gxb = torch.zeros((N, 2 * H, 2 * W, C), device=DEV)
+    ops.maxpool2_bwd(ops.View(nhwc_buf(gp)), ops.View(ab), ops.View(gxb))
+    close(to_nchw(gxb, 0, C), refgx, tol=0, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("C", [16, 64, 512])
+def test_batchnorm_train(C):
+    ops = _ops()
+    N, H, W = 4, 9, 11
+    z = (rnd(N, C, H, W, seed=38) * 3 + 0.7).requires_grad_(True)
+    gamma, beta = rnd(C, seed=39, lo=0.5, hi=1.5).requires_grad_(True), rnd(C, seed=40).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.leaky_relu(F.batch_norm(z, rm, rv, gamma, beta, True, 0.1, 1e-5), 0.2)
+    gy = rnd(N, C, H, W, seed=41)
+    gz_ref, gg_ref, gb_ref = torch.autograd.grad(y, (z, gamma, beta), gy)
+    zb = nhwc_buf(z.detach())
+    yb = torch.zeros_like(zb)
+    drm, drv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    sm, si = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    ops.bn_train_fwd(ops.View(zb), ops.View(yb), gd, bd, drm, drv, nbt, sm, si)
+    close(to_nchw(yb, 0, C), y.detach(), what="bn fwd")
+    close(drm.cpu(), rm, tol=1e-5, what="running mean")
+    close(drv.cpu(), rv, tol=1e-5, what="running var")
+    assert int(nbt) == 1
+    gzb = torch.zeros_like(zb)
+    dg, dbt = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    ops.bn_train_bwd(ops.View(nhwc_buf(gy)), ops.View(yb), ops.View(zb), ops.View(gzb), gd, sm, si, dgamma=dg, dbeta=dbt,
+                     acc_beta=1.0)
+    close(to_nchw(gzb, 0, C), gz_ref, tol=1e-4, what="bn bwd dx")
+    close(dg.cpu() - 1, gg_ref, tol=1e-4, what="bn dgamma")
+    close(dbt.cpu() - 1, gb_ref, tol=1e-4, what="bn dbeta")
+
+
+def test_linear_and_losses_and_optim():
+    ops = _ops()
+    from trainner_amd import hip
+    N, In, Out = 5, 300, 17
+    x, w, b = rnd(N, In, seed=42), rnd(Out, In, seed=43, lo=-0.1, hi=0.1).requires_grad_(True), rnd(Out, seed=44).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = F.leaky_relu(F.linear(xr, w, b), 0.2)
+    gy = rnd(N, Out, seed=45)
+    gx_r, gw_r, gb_r = torch.autograd.grad(y, (xr, w, b), gy)
+    xd, wd, bd = x.to(DEV), w.detach().to(DEV), b.detach().to(DEV)
+    yd = torch.zeros(N, Out, device=DEV)
+    ops.linear_fwd(xd, wd, bd, yd, act=ops.ACT_LRELU, slope=0.2)
+    close(yd.cpu(), y.detach(), what="linear fwd")
+    gxd, dwd, dbd = torch.zeros(N, In, device=DEV), torch.zeros(Out, In, device=DEV), torch.zeros(Out, device=DEV)
+    ops.linear_bwd(xd, wd, gy.to(DEV), yd, gx=gxd, dw=dwd, db=dbd, mslope=0.2)
+    close(gxd.cpu(), gx_r, what="linear gx")
+    close(dwd.cpu(), gw_r, what="linear dw")
+    close(dbd.cpu(), gb_r, what="linear db")
+    # L1
+    a, bb = rnd(3, 3, 20, 20, seed=46).requires_grad_(True), rnd(3, 3, 20, 20, seed=47)
+    l = F.l1_loss(a, bb)
+    (ga_r,) = torch.autograd.grad(l * 0.7, a)
+    ad, bbd = a.detach().to(DEV), bb.to(DEV)
+    out = torch.zeros((), device=DEV)
+    ops.l1_mean_fwd(ad, bbd, 1.0, out)
+    assert abs(float(out) - float(l)) < 1e-6
+    gsc = torch.tensor([0.7], device=DEV)
+    gad = torch.zeros_like(ad)
+    ops.l1_mean_bwd(ad, bbd, 1.0, gsc, gad)
+    close(gad.cpu(), ga_r, tol=1e-6, what="l1 bwd")
+    # relativistic BCE, both stages
+    from oracle import sr_oracle as O
+    lib = hip.load()
+    for stage in (0, 1):
+        pf = rnd(6, 1, seed=48).requires_grad_(True)
+        pr = rnd(6, 1, seed=49).requires_grad_(True)
+        if stage == 0:
+            loss = 5e-3 * O.ragan_g_loss(pf, pr)
+            gf_r, = torch.autograd.grad(loss, pf)
+            gr_r = torch.zeros_like(pr)
+        else:
+            lr_, lf_ = O.ragan_d_loss(pf, pr)
+            loss = (lr_ + lf_) * 0.5
+            gf_r, gr_r = torch.autograd.grad(loss, (pf, pr))
+        wgt = 5e-3 if stage == 0 else 1.0
+        pfd, prd = pf.detach().to(DEV).view(-1), pr.detach().to(DEV).view(-1)
+        sums, o5 = torch.zeros(8, device=DEV), torch.zeros(5, device=DEV)
+        gf, gr = torch.zeros(6, device=DEV), torch.zeros(6, device=DEV)
+        s = hip.stream()
+        hip.check(lib.tnr_ragan_phase_a(pfd.data_ptr(), prd.data_ptr(), 6, sums.data_ptr(), s))
+        hip.check(lib.tnr_ragan_phase_b(pfd.data_ptr(), prd.data_ptr(), 6, stage, sums.data_ptr(), s))
+        hip.check(lib.tnr_ragan_phase_c(pfd.data_ptr(), prd.data_ptr(), 6, stage, wgt, sums.data_ptr(), o5.data_ptr(),
+                                        gf.data_ptr(), gr.data_ptr(), s))
+        assert abs(float(o5[0]) - float(loss)) < 1e-6, (stage, float(o5[0]), float(loss))
+        close(gf.cpu().view(6, 1), gf_r, tol=1e-6, what="ragan gf")
+        close(gr.cpu().view(6, 1), gr_r, tol=1e-6, what="ragan gr")
+    # clip + Adam against torch
+    n = 10000
+    p0, g0 = rnd(n, seed=50), rnd(n, seed=51) * 0.01
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-4)
+    pd, gd_ = p0.to(DEV), g0.to(DEV)
+    md, vd = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t in range(1, 4):
+        pt.grad = g0.clone() * t
+        torch.nn.utils.clip_grad_norm_([pt], 0.1)
+        opt.step()
+        gcur = (g0 * t).to(DEV)
+        ss = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.sumsq(gcur, ss)
+        ops.clip_by_norm(gcur, ss, 0.1)
+        close(gcur.cpu(), pt.grad, tol=1e-6, what="clip")
+        ops.adam_step(pd, gcur, md, vd, 1e-4 / (1 - 0.9 ** t), 0.9, 0.999, math.sqrt(1 - 0.999 ** t), 1e-8)
+    assert (pd.cpu() - pt.detach()).abs().max().item() < 2e-7, "adam"

@@ -1,0 +1,148 @@
+"""Network-level parity (-m gpu): each HIP-engine network (one autograd node) against the CPU
+oracle's functional restatement driven by torch autograd, on identical seeded weights/inputs:
+outputs, input gradients, every parameter gradient, BatchNorm running statistics.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detrand, sr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(got, ref):
+    return (got.detach().cpu() - ref.detach()).abs().max().item() / (ref.detach().abs().max().item() + 1e-12)
+
+
+def seeded(net, seed, **kw):
+    sd = net.state_dict()
+    detrand.fill_state_dict_(sd, seed, **kw)
+    return {k: v.clone() for k, v in sd.items()}
+
+
+def oracle_params(sd):
+    out = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if t.is_floating_point() and not k.startswith("running") and ".running_" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+@pytest.mark.parametrize("mode", ["upconv", "pixelshuffle"])
+def test_rrdbnet_forward_backward(mode):
+    from trainner_amd.models.modules.architectures.RRDBNet_arch import RRDBNet
+    net = RRDBNet(3, 3, 64, 2, upsample_mode=mode)
+    sd = seeded(net, 5)
+    net = net.to(DEV)
+    lr = detrand.uniform((2, 3, 24, 20), 3, 0.0, 1.0)
+    gout = detrand.uniform((2, 3, 96, 80), 4, -1.0, 1.0)
+    out = net(lr.to(DEV))
+    out.backward(gout.to(DEV))
+    osd = oracle_params(sd)
+    ref = O.rrdbnet_forward(lr, osd, 2, 4, mode)
+    ref.backward(gout)
+    assert rel_err(out, ref) < 2e-5
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, osd[k].grad) < 2e-4, k
+    # no-grad inference path (buffer ring) gives the same image
+    with torch.no_grad():
+        out2 = net(lr.to(DEV))
+    assert rel_err(out2, ref) < 2e-5
+    # gradients accumulate across backward calls (virtual batch semantics)
+    net(lr.to(DEV)).backward(gout.to(DEV))
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, 2 * osd[k].grad) < 2e-4, k
+
+
+def test_srresnet_forward_backward():
+    from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
+    net = SRResNet(3, 3, 64, 3)
+    sd = seeded(net, 6)
+    net = net.to(DEV)
+    lr = detrand.uniform((2, 3, 16, 24), 7, 0.0, 1.0)
+    gout = detrand.uniform((2, 3, 64, 96), 8, -1.0, 1.0)
+    out = net(lr.to(DEV))
+    out.backward(gout.to(DEV))
+    osd = oracle_params(sd)
+    ref = O.srresnet_forward(lr, osd, 3, 4)
+    ref.backward(gout)
+    assert rel_err(out, ref) < 2e-5
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, osd[k].grad) < 2e-4, k
+
+
+@pytest.mark.parametrize("size,nf", [(64, 16), (128, 64)])
+def test_discriminator_vgg(size, nf):
+    from trainner_amd.models.modules.architectures.discriminators import Discriminator_VGG
+    net = Discriminator_VGG(size, 3, nf)
+    sd = seeded(net, 9)
+    net = net.to(DEV).train()
+    x = detrand.uniform((3, 3, size, size), 10, 0.0, 1.0)
+    gout = detrand.uniform((3, 1), 11, -1.0, 1.0)
+    xd = x.to(DEV).requires_grad_(True)
+    out = net(xd)
+    out.backward(gout.to(DEV))
+    osd = oracle_params(sd)
+    xr = x.clone().requires_grad_(True)
+    ref = O.disc_vgg_forward(xr, osd, size, nf, training=True)
+    ref.backward(gout)
+    assert rel_err(out, ref) < 5e-5
+    assert rel_err(xd.grad, xr.grad) < 5e-4
+    from oracle.fixtures import bn_shadowed_biases
+    shadow = bn_shadowed_biases([(k, None) for k in sd])
+    for k, p in net.named_parameters():
+        if k in shadow:
+            continue                                   # true gradient is exactly zero: noise on both sides
+        assert rel_err(p.grad, osd[k].grad) < 5e-4, k
+    new = net.state_dict()
+    for k in sd:
+        if "running_" in k:
+            assert rel_err(new[k], osd[k]) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(new[k]) == 1
+    # G-step usage: parameters frozen -> data gradient only, statistics still updated
+    for p in net.parameters():
+        p.requires_grad_(False)
+    before = [p.grad.clone() for p in net.parameters()]
+    xd2 = x.to(DEV).requires_grad_(True)
+    net(xd2).backward(gout.to(DEV))
+    for b, p in zip(before, net.parameters()):
+        assert torch.equal(b, p.grad)
+    assert int(net.state_dict()["features.3.num_batches_tracked"]) == 2
+
+
+def test_vgg19_features():
+    from trainner_amd.models.modules.architectures.perceptual import FeatureExtractor
+    from oracle import fixtures as FX
+    net = FeatureExtractor(["conv5_4"])
+    vsd = FX.vgg_state(77)
+    net.load_state_dict({**{k: v for k, v in net.state_dict().items() if k in ("mean", "std")}, **vsd})
+    net = net.to(DEV)
+    x = detrand.uniform((2, 3, 64, 96), 12, 0.0, 1.0)
+    xd = x.to(DEV).requires_grad_(True)
+    feat = net(xd)["conv5_4"]
+    xr = x.clone().requires_grad_(True)
+    ref = O.vgg19_conv54(xr, vsd)
+    assert feat.shape == ref.shape
+    assert rel_err(feat, ref) < 5e-5
+    g = detrand.uniform(tuple(ref.shape), 13, -1.0, 1.0)
+    feat.backward(g.to(DEV).contiguous(memory_format=torch.channels_last))
+    ref.backward(g)
+    assert rel_err(xd.grad, xr.grad) < 5e-4
+    # the perceptual criterion end to end
+    from trainner_amd.models.losses import L1Loss
+    y = detrand.uniform((2, 3, 64, 96), 14, 0.0, 1.0)
+    xd2 = x.to(DEV).requires_grad_(True)
+    with torch.no_grad():
+        fy = net(y.to(DEV))["conv5_4"]
+    loss = L1Loss()(net(xd2)["conv5_4"], fy)
+    loss.backward()
+    xr2 = x.clone().requires_grad_(True)
+    lref = F.l1_loss(O.vgg19_conv54(xr2, vsd), O.vgg19_conv54(y, vsd))
+    lref.backward()
+    assert abs(float(loss) - float(lref)) < 2e-5 * max(1.0, abs(float(lref)))
+    assert rel_err(xd2.grad, xr2.grad) < 1e-3

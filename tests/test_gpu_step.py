@@ -1,0 +1,126 @@
+"""Step-level parity (-m gpu): trainner_amd's SRModel.optimize_parameters against
+  (a) the committed golden fixtures produced by the REAL reference (tests/golden/*.pt), and
+  (b) the CPU oracle run live on the same seeded inputs at the benchmark resolution (128 -> 512),
+plus size-independent properties at BASELINE.json's full configuration (batch 16).
+Tolerances (fp32 MFMA == fmaf chains; only summation order differs from the CPU reference):
+  log_dict entries: 2e-4 relative;  fake_H per-pixel L1: mean <= 2e-5, max <= 5e-4 (x output scale);
+  |dPSNR| <= 0.05 dB (north star);  post-step weights: mean |dp| <= 2% of lr*steps.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import detrand, fixtures as FX, ref_harness, sr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def build_engine_model(fx_or_yaml_kw, tmp_path):
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    kw = dict(fx_or_yaml_kw)
+    yml = ref_harness.esrgan_yaml(name="engine_case", out_root=str(tmp_path), gpu_ids="[0]", **kw)
+    opt = options.parse(yml, is_train=True)
+    return opt, create_model(opt, verbose=False)
+
+
+def load_initial(model, g, d, f):
+    model.netG.load_state_dict(g)
+    if d is not None:
+        model.netD.load_state_dict(d)
+    if f is not None:
+        netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+        sd = netF.state_dict()
+        sd.update(f)
+        netF.load_state_dict(sd)
+
+
+def check_logs(log, ref_log, tol=2e-4):
+    for k, v in ref_log.items():
+        assert k in log, k
+        assert abs(log[k] - v) <= tol * max(1.0, abs(v)) + 5e-6, (k, log[k], v)
+
+
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"])
+def test_step_matches_reference_golden(case, tmp_path):
+    fx = FX.load(case)
+    opt, model = build_engine_model(fx["spec"]["yaml"], tmp_path)
+    assert dict(opt["network_G"]) == fx["network_G"]
+    if fx["network_D"]:
+        assert dict(opt["network_D"]) == fx["network_D"]
+    g, d, f = FX.initial_states(fx)
+    load_initial(model, g, d, f)
+    for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+        check_logs(model.get_current_log(), ref_log)
+    ref = fx["fake_H"]
+    got = model.fake_H.detach().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    diff = (got - ref).abs()
+    assert diff.mean().item() <= 2e-5 * scale and diff.max().item() <= 5e-4 * scale, (diff.mean().item(), diff.max().item())
+    _, HR = detrand.synthetic_pair(fx["spec"]["yaml"]["batch"], fx["spec"]["yaml"]["crop"],
+                                   fx["seeds"]["data"] + fx["spec"]["steps"])
+    assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
+    lr_steps = 1e-4 * fx["spec"]["steps"]
+    gs = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+    worst, mean, k = FX.state_error(gs, fx["g_state"], lr_steps=lr_steps)
+    assert mean < 0.02 and worst < 1.5, ("G state", k, worst, mean)
+    if fx["d_keys"]:
+        ds = {k: v.detach().cpu() for k, v in model.netD.state_dict().items()}
+        worst, mean, k = FX.state_error(ds, fx["d_state"], FX.bn_shadowed_biases(fx["d_keys"]), lr_steps=lr_steps)
+        assert mean < 0.02 and worst < 1.5, ("D state", k, worst, mean)
+        e, k = FX.buffers_error(ds, fx["d_state"])
+        assert e < 2e-3, ("D running stats", k, e)
+
+
+def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
+    """ESRGAN RRDBNet-23 + Discriminator_VGG(512) + VGG19, 128 -> 512, batch 1: two live steps."""
+    kw = dict(nb=23, batch=1, crop=512, d_nf=64)
+    opt, model = build_engine_model(kw, tmp_path)
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+    d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+    f = FX.vgg_state(77)
+    load_initial(model, g, d, f)
+    orc = O.OracleSRStep(g, d, f, arch="rrdb_net", nb=23, d_size=512, d_nf=64)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for s in (1, 2):
+        LR, HR = detrand.synthetic_pair(1, 512, 900 + s)
+        ref_log = orc.step(LR, HR)
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+        check_logs(model.get_current_log(), ref_log, tol=5e-4)
+        got, ref = model.fake_H.detach().cpu(), orc.fake_H.detach()
+        scale = max(1.0, ref.abs().max().item())
+        diff = (got - ref).abs()
+        assert diff.mean().item() <= 5e-5 * scale and diff.max().item() <= 2e-3 * scale
+        assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
+
+
+def test_full_config_properties(tmp_path):
+    """BASELINE.json configs[1] (batch 16, 128 -> 512, all losses): properties that do not need the CPU
+    oracle at full size -- finiteness, run-to-run bit reproducibility, and batch linearity of the
+    mean-reduced generator losses (the same 8 images twice == the 8-image batch)."""
+    kw = dict(nb=23, batch=16, crop=512, d_nf=64)
+    LR, HR = detrand.synthetic_pair(8, 512, 4242)
+    LR16, HR16 = torch.cat([LR, LR]), torch.cat([HR, HR])
+    logs, fakes = [], []
+    for rep in range(2):
+        opt, model = build_engine_model(kw, tmp_path / ("r%d" % rep))
+        g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+        d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+        load_initial(model, g, d, FX.vgg_state(77))
+        model.feed_data({"LR": LR16, "HR": HR16})
+        model.optimize_parameters(1)
+        logs.append(model.get_current_log())
+        fakes.append(model.fake_H.detach().clone())
+        gw = model.netG.state_dict()["model.1.sub.22.RDB3.conv5.0.weight"].clone()
+        del model
+        torch.cuda.empty_cache()
+    assert all(torch.isfinite(torch.tensor(list(l.values()))).all() for l in logs)
+    assert logs[0] == logs[1], "step is not bit-reproducible"
+    assert torch.equal(fakes[0], fakes[1])
+    assert torch.equal(fakes[0][:8], fakes[0][8:]), "identical images must map to identical outputs"
+    assert torch.isfinite(gw).all()

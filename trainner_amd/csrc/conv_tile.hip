@@ -1,0 +1,293 @@
+// Tiled implicit-GEMM convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32,
+// exact f32 == an fmaf chain), NHWC views, fused bias / activation / residual / mask epilogue.
+//
+// One workgroup = 256 threads = 4 waves (one per SIMD), two workgroups per CU (LDS <= 80 KiB).
+//   M  = 256 output pixels (TH x TW spatial tile; TW in {32,16,8}); wave w owns pixels
+//        [64w, 64w+64) = two 32-row MFMA tiles
+//   N  = NT*32 output channels (NT in {1,2})
+//   K  = taps x Cin, streamed in chunks of 16 channels: the (TH+KH-1) x (TW+KW-1) halo tile of the
+//        chunk and the chunk's [tap][cout][16] weight slab are staged in LDS with a 20-dword pixel
+//        stride, so every A / B fragment fetch is one conflict-free ds_read_b128 that feeds four
+//        MFMA k-steps (lane-half h supplies channels 4h..4h+3 of an 8-channel group).
+// Geometries (all reduce to "small dense tap set over a halo tile"):
+//   3x3 s1 p1            9 taps, halo +1            (also data-gradient, with flipped packed weights)
+//   3x3 s1 p1 of up2(x)  same, stager reads x[Y>>1][X>>1]          (block.py upconv_block)
+//   4x4 s2 p1            as a 2x2 s1 conv over the space-to-depth view: chunk = (parity, 16 ch)
+//   dgrad of 4x4 s2 p1   per output parity (py,px): 4 of the 9 halo taps, output scattered at stride 2
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+    const float *x; int x_ct, x_co;
+    int N, H, W, Cin;
+    const float *wp; int KinP, KoutP;
+    float *y; int y_ct, y_co; int Ho, Wo, Cout;
+    const float *bias; int act; float slope; float alpha;
+    const float *r1; int r1_ct, r1_co, r1_ch; float beta1;
+    const float *r2; int r2_ct, r2_co; float alpha2;
+    const float *m; int m_ct, m_co, m_lo, m_hi; float m_slope;
+    int tiles_x, tiles_y, ncb;
+    int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
+};
+
+template <int MODE, int TW, int NT>
+__global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
+    constexpr int TH = 256 / TW;
+    constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
+    constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
+    constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
+    constexpr int KH = S2D ? 2 : 3;
+    constexpr int NTAPS = (S2D || DG2) ? 4 : 9;
+    constexpr int HT = TH + KH - 1, WT = TW + KH - 1;
+    constexpr int NC = NT * 32;
+    constexpr int PST = TNR_PST, CK = TNR_CK;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_in = smem;                 // HT*WT*PST
+    float *s_w = smem + HT * WT * PST;  // NTAPS*NC*PST
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int cb = bid % a.ncb;
+    bid /= a.ncb;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    bid /= a.tiles_y;
+    int par = 0;
+    if (DG2) {
+        par = bid & 3;
+        bid >>= 2;
+    }
+    const int n = bid;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const int py = par >> 1, px = par & 1;
+
+    const float *wbase = a.wp + (DG2 ? (size_t)par * 4 * a.KoutP * a.KinP : (size_t)0);
+    const int nck = a.KinP / CK;
+    const int nchunks = S2D ? 4 * nck : nck;
+
+    // per-lane A offsets (dwords) of the two M-tiles this wave owns
+    int aoff[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int p = (wave * 2 + mi) * 32 + li;
+        const int r = p / TW, c = p - r * TW;
+        aoff[mi] = (r * WT + c) * PST + half * 4;
+    }
+    const int boff = li * PST + half * 4;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nn][r] = 0.f;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        int c0, pp = 0;
+        if (S2D) {
+            pp = chunk / nck;
+            c0 = (chunk - pp * nck) * CK;
+        } else {
+            c0 = chunk * CK;
+        }
+        __syncthreads();  // previous chunk's fragments are consumed
+        // ---- stage the halo tile of this chunk: one float4 (4 channels) per item
+        for (int i = tid; i < HT * WT * 4; i += 256) {
+            const int pix = i >> 2, q = i & 3;
+            const int hr = pix / WT, hc = pix - hr * WT;
+            int Y, X;
+            bool ok;
+            if (S2D) {
+                Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
+                X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            } else if (UP) {
+                Y = ty0 + hr - 1;
+                X = tx0 + hc - 1;
+                ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                Y >>= 1;
+                X >>= 1;
+            } else {
+                Y = ty0 + hr - 1;
+                X = tx0 + hc - 1;
+                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            }
+            const int c = c0 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && c < a.Cin)
+                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)(n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c);
+            *reinterpret_cast<f32x4 *>(s_in + pix * PST + q * 4) = v;
+        }
+        // ---- stage the weight slab [tap][cout][16]
+        for (int i = tid; i < NTAPS * NC * 4; i += 256) {
+            const int row = i >> 2, q = i & 3;
+            const int t = row / NC, co = row - t * NC;
+            const int cog = cb * NC + co;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cog < a.KoutP) {
+                const size_t off = S2D ? ((size_t)(t * a.KoutP + cog) * (4 * a.KinP) + (size_t)pp * a.KinP + c0 + q * 4)
+                                       : ((size_t)(t * a.KoutP + cog) * a.KinP + c0 + q * 4);
+                v = *reinterpret_cast<const f32x4 *>(wbase + off);
+            }
+            *reinterpret_cast<f32x4 *>(s_w + row * PST + q * 4) = v;
+        }
+        __syncthreads();
+        // ---- MFMA over taps x 16 channels
+#pragma unroll 1
+        for (int t = 0; t < NTAPS; ++t) {
+            int pos_y, pos_x;
+            if (DG2) {
+                pos_y = 1 + py - (t >> 1);
+                pos_x = 1 + px - (t & 1);
+            } else if (S2D) {
+                pos_y = t >> 1;
+                pos_x = t & 1;
+            } else {
+                pos_y = t / 3;
+                pos_x = t - pos_y * 3;
+            }
+            const int tapoff = (pos_y * WT + pos_x) * PST;
+            const float *wt = s_w + t * NC * PST + boff;
+#pragma unroll
+            for (int kk = 0; kk < CK / 8; ++kk) {
+                f32x4 av[2], bv[NT];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    av[mi] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + kk * 8);
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+                    bv[nn] = *reinterpret_cast<const f32x4 *>(wt + nn * 32 * PST + kk * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn)
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[nn][j], acc[mi][nn], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        const int co = cb * NC + nn * 32 + li;
+        const bool cok = co < a.Cout;
+        const float bval = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
+        const bool use_r1 = (a.r1 != nullptr) && (co < a.r1_ch);
+        const bool use_m = (a.m != nullptr) && (co >= a.m_lo) && (co < a.m_hi);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int p = (wave * 2 + mi) * 32 + i;
+                const int rr = p / TW, cc = p - rr * TW;
+                const int sy = ty0 + rr, sx = tx0 + cc;
+                if (!cok || sy >= a.th_space || sx >= a.tw_space) continue;
+                const int oy = DG2 ? 2 * sy + py : sy;
+                const int ox = DG2 ? 2 * sx + px : sx;
+                const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+                float v = acc[mi][nn][r] + bval;
+                v = tnr_act(v, a.act, a.slope);
+                v = v * a.alpha;
+                if (use_r1) v = v + a.beta1 * a.r1[pix * a.r1_ct + a.r1_co + co];
+                if (a.r2 != nullptr) v = v * a.alpha2 + a.r2[pix * a.r2_ct + a.r2_co + co];
+                if (use_m) {
+                    const float mv = a.m[pix * a.m_ct + a.m_co + co];
+                    v *= (mv > 0.f ? 1.f : a.m_slope);
+                }
+                a.y[pix * a.y_ct + a.y_co + co] = v;
+            }
+        }
+    }
+}
+
+template <int MODE, int TW, int NT>
+int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
+    constexpr int TH = 256 / TW;
+    constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
+    constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
+    constexpr size_t lds = (size_t)((TH + KH - 1) * (TW + KH - 1) + NTAPS * NT * 32) * TNR_PST * sizeof(float);
+    static bool attr_done = false;
+    auto fn = conv_tile_kernel<MODE, TW, NT>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            tnr_set_error("conv_tile: cannot raise dynamic LDS to %zu bytes", lds);
+            return TNR_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(tiles), dim3(256), lds, s, k);
+    return tnr_check_launch("conv_tile");
+}
+
+template <int MODE>
+int dispatch_conv(const ConvK &k, int tw, int nt, int tiles, hipStream_t s) {
+    if (tw == 32) return nt == 2 ? launch_conv<MODE, 32, 2>(k, tiles, s) : launch_conv<MODE, 32, 1>(k, tiles, s);
+    if (tw == 16) return nt == 2 ? launch_conv<MODE, 16, 2>(k, tiles, s) : launch_conv<MODE, 16, 1>(k, tiles, s);
+    return nt == 2 ? launch_conv<MODE, 8, 2>(k, tiles, s) : launch_conv<MODE, 8, 1>(k, tiles, s);
+}
+
+}  // namespace
+
+extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
+    TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
+    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_DGRAD_4x4_S2, "conv: bad mode %d", d->mode);
+    TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->Cin % 4) == 0,
+                "conv: input view must be 4-channel aligned (ctot %d coff %d Cin %d)", d->x.ctot, d->x.coff, d->Cin);
+    TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
+    TNR_REQUIRE(d->Cin <= d->KinP && d->Cout <= d->KoutP, "conv: Cin/Cout exceed the packing");
+    ConvK k;
+    k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+    k.wp = d->wp; k.KinP = d->KinP; k.KoutP = d->KoutP;
+    k.y = d->y.ptr; k.y_ct = d->y.ctot; k.y_co = d->y.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.bias = d->bias; k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+    k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
+    k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
+    k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+
+    int sh, sw;  // tile space
+    switch (d->mode) {
+        case TNR_CONV_3x3:
+            TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3: output must match input size");
+            sh = d->Ho; sw = d->Wo;
+            break;
+        case TNR_CONV_3x3_UP2:
+            TNR_REQUIRE(d->Ho == 2 * d->H && d->Wo == 2 * d->W, "conv3x3_up2: output must be 2x input");
+            sh = d->Ho; sw = d->Wo;
+            break;
+        case TNR_CONV_4x4_S2:
+            TNR_REQUIRE(2 * d->Ho == d->H && 2 * d->Wo == d->W, "conv4x4s2: output must be input/2");
+            sh = d->Ho; sw = d->Wo;
+            break;
+        default:  // TNR_DGRAD_4x4_S2
+            TNR_REQUIRE(d->Ho == 2 * d->H && d->Wo == 2 * d->W, "dgrad4x4s2: output must be 2x gout size");
+            sh = d->H; sw = d->W;
+            break;
+    }
+    k.th_space = sh; k.tw_space = sw;
+    const int tw = sw >= 32 ? 32 : (sw >= 16 ? 16 : 8);
+    const int th = 256 / tw;
+    const int nt = d->Cout > 32 ? 2 : 1;
+    k.tiles_x = tnr_cdiv(sw, tw);
+    k.tiles_y = tnr_cdiv(sh, th);
+    k.ncb = tnr_cdiv(d->Cout, nt * 32);
+    const int64_t tiles = (int64_t)k.tiles_x * k.tiles_y * k.ncb * d->N * (d->mode == TNR_DGRAD_4x4_S2 ? 4 : 1);
+    TNR_REQUIRE(tiles > 0 && tiles < (1LL << 31), "conv: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->mode) {
+        case TNR_CONV_3x3: return dispatch_conv<TNR_CONV_3x3>(k, tw, nt, (int)tiles, s);
+        case TNR_CONV_3x3_UP2: return dispatch_conv<TNR_CONV_3x3_UP2>(k, tw, nt, (int)tiles, s);
+        case TNR_CONV_4x4_S2: return dispatch_conv<TNR_CONV_4x4_S2>(k, tw, nt, (int)tiles, s);
+        default: return dispatch_conv<TNR_DGRAD_4x4_S2>(k, tw, nt, (int)tiles, s);
+    }
+}

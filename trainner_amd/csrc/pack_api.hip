@@ -1,0 +1,111 @@
+// Error plumbing + weight re-layout (OIHW state_dict tensors -> K-chunked [tap][kout][kin] slabs).
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void tnr_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int tnr_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tnr_set_error("%s: %s", what, hipGetErrorString(e));
+        return TNR_ELAUNCH;
+    }
+    return TNR_OK;
+}
+
+extern "C" const char *tnr_last_error(void) { return g_err; }
+extern "C" int tnr_version(void) { return 1; }
+
+extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t kind, int32_t *KoutP,
+                             int32_t *KinP, int64_t *n_out) {
+    int ko, ki;
+    int64_t n;
+    switch (kind) {
+        case TNR_PACK_FWD:
+            ko = tnr_round_up(Cout, 32); ki = tnr_round_up(Cin, TNR_CK);
+            n = (int64_t)kh * kw * ko * ki;
+            break;
+        case TNR_PACK_DGRAD_3x3:
+            TNR_REQUIRE(kh == 3 && kw == 3, "pack dgrad3x3: kernel must be 3x3");
+            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(Cout, TNR_CK);
+            n = (int64_t)9 * ko * ki;
+            break;
+        case TNR_PACK_FWD_S2D:
+            TNR_REQUIRE(kh == 4 && kw == 4, "pack s2d: kernel must be 4x4");
+            ko = tnr_round_up(Cout, 32); ki = tnr_round_up(Cin, TNR_CK);
+            n = (int64_t)4 * ko * 4 * ki;
+            break;
+        case TNR_PACK_DGRAD_S2:
+            TNR_REQUIRE(kh == 4 && kw == 4, "pack dgrad s2: kernel must be 4x4");
+            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(Cout, TNR_CK);
+            n = (int64_t)16 * ko * ki;
+            break;
+        default:
+            tnr_set_error("pack: bad kind %d", kind);
+            return TNR_EINVAL;
+    }
+    if (KoutP) *KoutP = ko;
+    if (KinP) *KinP = ki;
+    if (n_out) *n_out = n;
+    return TNR_OK;
+}
+
+namespace {
+__global__ void pack_weights_kernel(const tnr_pack_item *items) {
+    const tnr_pack_item it = items[blockIdx.y];
+    const int Cout = it.Cout, Cin = it.Cin, kh = it.kh, kw = it.kw, ko = it.KoutP, ki = it.KinP;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < it.n_out; e += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (it.kind == TNR_PACK_FWD) {
+            const int ci = (int)(e % ki);
+            int64_t q = e / ki;
+            const int co = (int)(q % ko);
+            const int t = (int)(q / ko);
+            if (co < Cout && ci < Cin) v = it.w[((size_t)co * Cin + ci) * kh * kw + t];
+        } else if (it.kind == TNR_PACK_DGRAD_3x3) {
+            const int co = (int)(e % ki);  // reduction channel of the dgrad conv = forward cout
+            int64_t q = e / ki;
+            const int ci = (int)(q % ko);  // produced channel = forward cin
+            const int t = (int)(q / ko);
+            const int ky = 2 - t / 3, kx = 2 - t % 3;
+            if (co < Cout && ci < Cin) v = it.w[(((size_t)co * Cin + ci) * 3 + ky) * 3 + kx];
+        } else if (it.kind == TNR_PACK_FWD_S2D) {
+            const int vch = (int)(e % (4 * ki));
+            int64_t q = e / (4 * ki);
+            const int co = (int)(q % ko);
+            const int t = (int)(q / ko);
+            const int pp = vch / ki, ci = vch - pp * ki;
+            const int ky = 2 * (t >> 1) + (pp >> 1), kx = 2 * (t & 1) + (pp & 1);
+            if (co < Cout && ci < Cin) v = it.w[(((size_t)co * Cin + ci) * 4 + ky) * 4 + kx];
+        } else {  // TNR_PACK_DGRAD_S2: [par][t][ci][co]
+            const int co = (int)(e % ki);
+            int64_t q = e / ki;
+            const int ci = (int)(q % ko);
+            q /= ko;
+            const int t = (int)(q & 3);
+            const int par = (int)(q >> 2);
+            const int py = par >> 1, px = par & 1;
+            const int ky = ((py + 1) & 1) + 2 * (t >> 1), kx = ((px + 1) & 1) + 2 * (t & 1);
+            if (co < Cout && ci < Cin) v = it.w[(((size_t)co * Cin + ci) * 4 + ky) * 4 + kx];
+        }
+        it.wp[e] = v;
+    }
+}
+}  // namespace
+
+extern "C" int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out, void *stream) {
+    TNR_REQUIRE(items_dev != nullptr && n > 0 && max_out > 0, "pack: bad arguments");
+    int64_t bx = tnr_cdiv64(max_out, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return tnr_check_launch("pack_weights");
+}

@@ -1,0 +1,339 @@
+// Weight gradient as a pixel-reduction GEMM on the fp32 matrix cores:
+//     dW[tap][co][ci] = sum_pixels g[p][co] * x[p + tap][ci]
+// MFMA 32x32x2: A[i=co][k=pixel parity], B[k][j=ci]; both fragments are conflict-free ds_read_b32
+// from NHWC LDS tiles (lanes = consecutive channels).  A workgroup (4 waves, 2 per CU) owns a
+// (32*A_T couts) x (32*B_T cins) x all-taps block and walks a contiguous range of TH x 16 pixel
+// tiles (its "split"), keeping every accumulator in registers; the A_T*B_T*taps 32x32 tiles are
+// dealt round-robin to the 4 waves.  Each split writes one partial slab
+//     ws[split][tap][KoutP][KinVP]
+// and wgrad_reduce sums the slabs in a fixed order (deterministic split-K) into the OIHW gradient.
+// The 4x4 s2 convolution is handled in its space-to-depth form (2x2 taps over 4*Cin virtual
+// channels), exactly like conv_tile.hip.
+#include "common.h"
+
+namespace {
+
+struct WgK {
+    const float *x; int x_ct, x_co; int N, H, W, Cin;
+    const float *g; int g_ct, g_co; int Ho, Wo, Cout;
+    float *ws; int KoutP, KinVP;  // slab dims
+    int cinp32;                   // per-parity padded channel count (S2D); == KinVP otherwise
+    float *dbp;                   // partial bias sums [split][KoutP] or null
+    int tiles_x, tiles_y, tiles_total, tiles_per_split;
+};
+
+template <int MODE, int A_T, int B_T, int THG>
+__global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
+    constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
+    constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
+    constexpr int TWG = 16, PX = THG * TWG;
+    constexpr int KH = S2D ? 2 : 3;
+    constexpr int NTAPS = KH * KH;
+    constexpr int HT = THG + KH - 1, WT = TWG + KH - 1;
+    constexpr int COB = 32 * A_T, CIB = 32 * B_T;
+    constexpr int AB = A_T * B_T;
+    constexpr int T = AB * NTAPS, J = (T + 3) / 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_g = smem;             // PX * COB
+    float *s_x = smem + PX * COB;  // HT*WT * CIB
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
+    const int lane = tid & 63, li = lane & 31, half = lane >> 5;
+    const int split = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+
+    // tile list of this wave (wave-uniform scalars)
+    int t_ok[J], t_tap[J], t_aa[J], t_boff[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int t = wave + 4 * j;
+        t_ok[j] = t < T;
+        const int tt = t_ok[j] ? t : 0;
+        const int tap = tt / AB, ab = tt - tap * AB;
+        const int aa = ab / B_T, bb = ab - aa * B_T;
+        const int ty = tap / KH, tx = tap - ty * KH;
+        t_tap[j] = tap * 1024 + aa * 32 + bb;  // packed for the store phase
+        t_aa[j] = aa;
+        t_boff[j] = (ty * WT + tx) * CIB + bb * 32;
+    }
+
+    f32x16 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bacc = 0.f;
+    const bool want_bias = (a.dbp != nullptr) && (cib == 0);
+
+    const int t_begin = split * a.tiles_per_split;
+    int t_end = t_begin + a.tiles_per_split;
+    if (t_end > a.tiles_total) t_end = a.tiles_total;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int q = tile;
+        const int tx = q % a.tiles_x;
+        q /= a.tiles_x;
+        const int ty = q % a.tiles_y;
+        const int n = q / a.tiles_y;
+        const int ty0 = ty * THG, tx0 = tx * TWG;
+        __syncthreads();
+        // ---- stage g tile [PX][COB]
+        for (int i = tid; i < PX * (COB / 4); i += 256) {
+            const int p = i / (COB / 4), c4 = i - p * (COB / 4);
+            const int r = p / TWG, c = p - r * TWG;
+            const int oy = ty0 + r, ox = tx0 + c;
+            const int co = cob * COB + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < a.Ho && ox < a.Wo && co < a.Cout)
+                v = *reinterpret_cast<const f32x4 *>(a.g + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.g_ct + a.g_co + co);
+            *reinterpret_cast<f32x4 *>(s_g + p * COB + c4 * 4) = v;
+        }
+        // ---- stage x halo tile [HT*WT][CIB]; each 32-channel sub-block may be its own parity (S2D)
+        for (int i = tid; i < HT * WT * (CIB / 4); i += 256) {
+            const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
+            const int hr = pix / WT, hc = pix - hr * WT;
+            const int vb = cib * B_T + (c4 >> 3);  // global 32-wide virtual block index
+            int Y, X, c;
+            bool ok;
+            if (S2D) {
+                const int nb32 = a.cinp32 >> 5;
+                const int pp = vb / nb32;
+                c = (vb - pp * nb32) * 32 + (c4 & 7) * 4;
+                Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
+                X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                ok = (pp < 4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            } else if (UP) {
+                c = vb * 32 + (c4 & 7) * 4;
+                Y = ty0 + hr - 1;
+                X = tx0 + hc - 1;
+                ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                Y >>= 1;
+                X >>= 1;
+            } else {
+                c = vb * 32 + (c4 & 7) * 4;
+                Y = ty0 + hr - 1;
+                X = tx0 + hc - 1;
+                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && c < a.Cin)
+                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)(n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c);
+            *reinterpret_cast<f32x4 *>(s_x + pix * CIB + c4 * 4) = v;
+        }
+        __syncthreads();
+        if (want_bias && tid < COB) {
+            float sacc = 0.f;
+            for (int p = 0; p < PX; ++p) sacc += s_g[p * COB + tid];
+            bacc += sacc;
+        }
+        // ---- K loop: two pixels per MFMA
+#pragma unroll 2
+        for (int s = 0; s < PX / 2; ++s) {
+            const int p = 2 * s + half;
+            const int r = p / TWG, c = p - r * TWG;
+            const int gbase = p * COB;
+            const int xbase = (r * WT + c) * CIB;
+            float av[A_T];
+#pragma unroll
+            for (int aa = 0; aa < A_T; ++aa) av[aa] = s_g[gbase + aa * 32 + li];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (t_ok[j]) {
+                    float aval = av[0];
+                    if (A_T > 1) aval = t_aa[j] ? av[A_T - 1] : av[0];
+                    const float bval = s_x[xbase + t_boff[j] + li];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- write the partial slab
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (!t_ok[j]) continue;
+        const int tap = t_tap[j] >> 10, aa = (t_tap[j] >> 5) & 31, bb = t_tap[j] & 31;
+        const int civ = (cib * B_T + bb) * 32 + li;
+        if (civ >= a.KinVP) continue;
+        float *slab = a.ws + ((size_t)split * NTAPS + tap) * a.KoutP * a.KinVP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = cob * COB + aa * 32 + i;
+            if (co < a.KoutP) slab[(size_t)co * a.KinVP + civ] = acc[j][r];
+        }
+    }
+    if (want_bias && tid < COB) {
+        const int co = cob * COB + tid;
+        if (co < a.KoutP) a.dbp[(size_t)split * a.KoutP + co] = bacc;
+    }
+}
+
+struct RedK {
+    const float *ws; const float *dbp;
+    int splits, ntaps, KoutP, KinVP, cinp32;
+    float *dw; float *db;
+    int Cout, Cin, cin_total, cin_begin, kh, kw, s2d;
+    float alpha, beta;
+};
+
+__global__ void wgrad_reduce_kernel(const RedK a) {
+    const int64_t total = (int64_t)a.ntaps * a.KoutP * a.KinVP;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total) {
+        const int civ = (int)(e % a.KinVP);
+        const int64_t q = e / a.KinVP;
+        const int co = (int)(q % a.KoutP);
+        const int tap = (int)(q / a.KoutP);
+        int ci, ky, kx;
+        if (a.s2d) {
+            const int pp = civ / a.cinp32;
+            ci = civ - pp * a.cinp32;
+            ky = 2 * (tap >> 1) + (pp >> 1);
+            kx = 2 * (tap & 1) + (pp & 1);
+        } else {
+            ci = civ;
+            ky = tap / a.kw;
+            kx = tap - ky * a.kw;
+        }
+        if (co < a.Cout && ci < a.Cin) {
+            float sum = 0.f;
+            for (int s = 0; s < a.splits; ++s) sum += a.ws[(size_t)s * total + e];
+            const size_t o = (((size_t)co * a.cin_total + a.cin_begin + ci) * a.kh + ky) * a.kw + kx;
+            const float prev = (a.beta != 0.f) ? a.beta * a.dw[o] : 0.f;
+            a.dw[o] = prev + a.alpha * sum;
+        }
+    }
+    if (a.db != nullptr && e < a.Cout) {
+        float sum = 0.f;
+        for (int s = 0; s < a.splits; ++s) sum += a.dbp[(size_t)s * a.KoutP + e];
+        const float prev = (a.beta != 0.f) ? a.beta * a.db[e] : 0.f;
+        a.db[e] = prev + a.alpha * sum;
+    }
+}
+
+struct WgPlan {
+    int a_t, b_t, thg;
+    int ncib, ncob;
+    int KoutP, KinVP, cinp32;
+    int tiles_x, tiles_y, tiles_total, splits, tiles_per_split;
+    int ntaps;
+    int64_t ws_floats, db_floats;
+};
+
+int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
+    const bool s2d = d->mode == TNR_CONV_4x4_S2;
+    p.a_t = d->Cout > 32 ? 2 : 1;
+    const int vch = s2d ? 4 * tnr_round_up(d->Cin, 32) : tnr_round_up(d->Cin, 32);
+    const int vblocks = vch / 32;
+    if (p.a_t == 2) {
+        p.b_t = vblocks >= 2 ? 2 : 1;
+    } else {
+        p.b_t = vblocks >= 4 ? 4 : vblocks;
+        if (vblocks == 5) p.b_t = 3;  // caller normally splits 160 = 96 + 64 itself
+    }
+    // LDS budget (<= 80 KiB so two workgroups share a CU): (2,*) and (1,2) use 8x16 tiles
+    p.thg = (p.a_t == 2 || p.b_t <= 2) ? 8 : 4;
+    p.cinp32 = tnr_round_up(d->Cin, 32);
+    p.KinVP = vch;
+    p.KoutP = tnr_round_up(d->Cout, 32);
+    p.ncib = tnr_cdiv(vblocks, p.b_t);
+    p.ncob = tnr_cdiv(p.KoutP, 32 * p.a_t);
+    p.ntaps = s2d ? 4 : 9;
+    p.tiles_x = tnr_cdiv(d->Wo, 16);
+    p.tiles_y = tnr_cdiv(d->Ho, p.thg);
+    p.tiles_total = p.tiles_x * p.tiles_y * d->N;
+    // enough workgroups for ~2 per CU, but never fewer than 4 tiles of work per split
+    int want = tnr_cdiv(512, p.ncib * p.ncob);
+    int max_splits = tnr_cdiv(p.tiles_total, 4);
+    if (max_splits < 1) max_splits = 1;
+    p.splits = want < max_splits ? want : max_splits;
+    if (p.splits < 1) p.splits = 1;
+    p.tiles_per_split = tnr_cdiv(p.tiles_total, p.splits);
+    p.splits = tnr_cdiv(p.tiles_total, p.tiles_per_split);
+    p.ws_floats = (int64_t)p.splits * p.ntaps * p.KoutP * p.KinVP;
+    p.db_floats = (int64_t)p.splits * p.KoutP;
+    return 0;
+}
+
+template <int MODE, int A_T, int B_T, int THG>
+int launch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
+    constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
+    constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH - 1) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
+    static_assert(lds <= 80 * 1024, "wgrad tile exceeds the 2-workgroups-per-CU LDS budget");
+    static bool attr_done = false;
+    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            tnr_set_error("wgrad_tile: cannot raise dynamic LDS to %zu bytes", lds);
+            return TNR_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(p.splits, p.ncib, p.ncob), dim3(256), lds, s, k);
+    return tnr_check_launch("wgrad_tile");
+}
+
+template <int MODE>
+int dispatch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
+    if (p.a_t == 2) {
+        if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, p, s);
+        return launch_wgrad<MODE, 2, 1, 8>(k, p, s);
+    }
+    switch (p.b_t) {
+        case 1: return launch_wgrad<MODE, 1, 1, 8>(k, p, s);
+        case 2: return launch_wgrad<MODE, 1, 2, 8>(k, p, s);
+        case 3: return launch_wgrad<MODE, 1, 3, 4>(k, p, s);
+        default: return launch_wgrad<MODE, 1, 4, 4>(k, p, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d) {
+    if (d == nullptr) return 0;
+    WgPlan p;
+    plan_wgrad(d, p);
+    return (p.ws_floats + p.db_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
+    TNR_REQUIRE(d != nullptr && d->x.ptr && d->g.ptr && d->dw && d->ws, "wgrad: null pointer");
+    TNR_REQUIRE(d->mode == TNR_CONV_3x3 || d->mode == TNR_CONV_3x3_UP2 || d->mode == TNR_CONV_4x4_S2,
+                "wgrad: bad mode %d", d->mode);
+    TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->g.ctot % 4) == 0 && (d->g.coff % 4) == 0,
+                "wgrad: views must be 4-channel aligned");
+    TNR_REQUIRE(d->db == nullptr || d->cin_begin == 0, "wgrad: bias gradient only with cin_begin == 0");
+    if (d->mode == TNR_CONV_3x3) TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "wgrad3x3: size mismatch");
+    if (d->mode == TNR_CONV_3x3_UP2) TNR_REQUIRE(d->Ho == 2 * d->H && d->Wo == 2 * d->W, "wgrad3x3_up2: size mismatch");
+    if (d->mode == TNR_CONV_4x4_S2) TNR_REQUIRE(2 * d->Ho == d->H && 2 * d->Wo == d->W, "wgrad4x4s2: size mismatch");
+    WgPlan p;
+    plan_wgrad(d, p);
+    TNR_REQUIRE((p.ws_floats + p.db_floats) * (int64_t)sizeof(float) <= d->ws_bytes, "wgrad: workspace too small (%lld < %lld)",
+                (long long)d->ws_bytes, (long long)((p.ws_floats + p.db_floats) * sizeof(float)));
+    WgK k;
+    k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff; k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+    k.g = d->g.ptr; k.g_ct = d->g.ctot; k.g_co = d->g.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.ws = d->ws; k.KoutP = p.KoutP; k.KinVP = p.KinVP; k.cinp32 = p.cinp32;
+    k.dbp = d->db ? d->ws + p.ws_floats : nullptr;
+    k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.tiles_total = p.tiles_total; k.tiles_per_split = p.tiles_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (d->mode) {
+        case TNR_CONV_3x3: rc = dispatch_wgrad<TNR_CONV_3x3>(k, p, s); break;
+        case TNR_CONV_3x3_UP2: rc = dispatch_wgrad<TNR_CONV_3x3_UP2>(k, p, s); break;
+        default: rc = dispatch_wgrad<TNR_CONV_4x4_S2>(k, p, s); break;
+    }
+    if (rc != TNR_OK) return rc;
+    RedK r;
+    r.ws = d->ws; r.dbp = k.dbp; r.splits = p.splits; r.ntaps = p.ntaps; r.KoutP = p.KoutP; r.KinVP = p.KinVP;
+    r.cinp32 = p.cinp32; r.dw = d->dw; r.db = d->db; r.Cout = d->Cout; r.Cin = d->Cin; r.cin_total = d->cin_total;
+    r.cin_begin = d->cin_begin; r.s2d = d->mode == TNR_CONV_4x4_S2;
+    r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.alpha = d->alpha; r.beta = d->beta;
+    int64_t total = (int64_t)p.ntaps * p.KoutP * p.KinVP;
+    if (total < d->Cout) total = d->Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tnr_cdiv64(total, 256)), dim3(256), 0, s, r);
+    return tnr_check_launch("wgrad_reduce");
+}

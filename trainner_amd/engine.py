@@ -1,0 +1,95 @@
+"""Glue shared by the network executors: one convolution layer bound to its packed weights, and
+the autograd bridge that lets the reference-shaped training code (`loss.backward()`) drive the
+hand-written forward / backward kernel schedules of a whole network as ONE autograd node.
+"""
+import torch
+
+from . import hip, ops
+from .flat import FlatParams
+
+
+class ConvOp:
+    """Forward, data-gradient and weight-gradient launches of one Conv2dHIP layer."""
+
+    def __init__(self, mod, packer, need_dgrad=True, ups=False):
+        self.mod, self.packer = mod, packer
+        k, s = mod.kernel_size, mod.stride
+        if k == 3 and s == 1:
+            self.mode_f = ops.CONV_3x3_UP2 if ups else ops.CONV_3x3
+            self.mode_d = ops.CONV_3x3
+            pf, pd = ops.PACK_FWD, ops.PACK_DGRAD_3x3
+        elif k == 4 and s == 2 and not ups:
+            self.mode_f, self.mode_d = ops.CONV_4x4_S2, ops.DGRAD_4x4_S2
+            pf, pd = ops.PACK_FWD_S2D, ops.PACK_DGRAD_S2
+        else:
+            raise NotImplementedError("conv k=%d s=%d is not on the SR hot path" % (k, s))
+        self.i_f = packer.add(mod.weight, pf)
+        self.i_d = packer.add(mod.weight, pd) if need_dgrad else None
+
+    def fwd(self, x, y, **epi):
+        ops.conv(x, self.packer.get(self.i_f), y, mode=self.mode_f, bias=self.mod.bias, **epi)
+
+    def dgrad(self, g, gx, **epi):
+        """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
+        ops.conv(g, self.packer.get(self.i_d), gx, mode=self.mode_d, **epi)
+
+    def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+        w = self.mod.weight
+        db = self.mod.bias.grad if (with_bias and self.mod.bias is not None and cin_begin == 0) else None
+        ops.wgrad(x, g, w.grad, db, mode=self.mode_f, cin_begin=cin_begin, alpha=alpha, beta=1.0)
+
+
+class _NetFn(torch.autograd.Function):
+    """Whole-network autograd node.  Parameters are listed as inputs only so that autograd knows the
+    output depends on them; their gradients are accumulated by the engine straight into the flat
+    gradient buffer (param.grad views), so backward returns None for them."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        need_param_grad = any(p.requires_grad for p in params)
+        need_graph = torch.is_grad_enabled() and (x.requires_grad or need_param_grad)
+        out, saved = net.engine_forward(x, save=need_graph)
+        ctx.net, ctx.saved, ctx.need_param_grad = net, saved, need_param_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        saved = ctx.saved
+        if saved is None:
+            raise RuntimeError("HIP engine: backward through a forward that saved no activations")
+        ctx.saved = None
+        gx = ctx.net.engine_backward(saved, gout, need_input_grad=ctx.needs_input_grad[1],
+                                     need_param_grad=ctx.need_param_grad)
+        return (None, gx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class HipNet(torch.nn.Module):
+    """Base class of the engine's networks: flat parameters + the autograd bridge."""
+
+    def _init_engine(self):
+        self._flat = FlatParams(self)
+        self._packer = None
+        self._packer_owner = None
+        self._ops = None
+
+    def flat_params(self):
+        return self._flat.ensure()
+
+    def _prepare(self, x):
+        hip.require_device(x)
+        if x.dtype != torch.float32:
+            raise hip.HipEngineError("the HIP engine computes in fp32; got %s" % x.dtype)
+        fp = self.flat_params()
+        if fp.flat.device != x.device:
+            raise hip.HipEngineError("network is on %s but input on %s" % (fp.flat.device, x.device))
+        if self._packer is None or self._packer.device != x.device or self._packer_owner is not fp.flat:
+            self._packer = ops.WeightPacker(x.device)
+            self._packer_owner = fp.flat
+            self._build_ops(self._packer)
+        self._packer.run()
+
+    def forward(self, x, **kw):
+        x = x.contiguous()
+        self._prepare(x)
+        params = list(self.parameters())
+        return _NetFn.apply(self, x, *params)

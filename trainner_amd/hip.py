@@ -1,0 +1,146 @@
+"""ctypes binding of libtrainner_hip.so (the C ABI declared in include/trainner_hip.h).
+
+The product path has NO CPU or eager-PyTorch fallback: if the library is missing, or a call is
+made without a HIP device, this module raises.  torch is used only to own device memory and
+streams (`tensor.data_ptr()`, `torch.cuda.current_stream()`).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+c_f = C.c_float
+c_i = C.c_int32
+c_l = C.c_int64
+c_p = C.c_void_p
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2 = 0, 1, 2, 3
+PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2 = 0, 1, 2, 3
+
+
+class CView(C.Structure):
+    _fields_ = [("ptr", c_p), ("ctot", c_i), ("coff", c_i)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", CView), ("N", c_i), ("H", c_i), ("W", c_i), ("Cin", c_i),
+        ("wp", c_p), ("KinP", c_i), ("KoutP", c_i),
+        ("y", CView), ("Ho", c_i), ("Wo", c_i), ("Cout", c_i),
+        ("mode", c_i), ("bias", c_p), ("act", c_i), ("slope", c_f), ("alpha", c_f),
+        ("r1", CView), ("r1_ch", c_i), ("beta1", c_f),
+        ("r2", CView), ("alpha2", c_f),
+        ("m", CView), ("m_lo", c_i), ("m_hi", c_i), ("m_slope", c_f),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", CView), ("N", c_i), ("H", c_i), ("W", c_i), ("Cin", c_i),
+        ("g", CView), ("Ho", c_i), ("Wo", c_i), ("Cout", c_i),
+        ("mode", c_i),
+        ("dw", c_p), ("cin_total", c_i), ("cin_begin", c_i),
+        ("db", c_p), ("alpha", c_f), ("beta", c_f),
+        ("ws", c_p), ("ws_bytes", c_l),
+    ]
+
+
+class PackItem(C.Structure):
+    _fields_ = [("w", c_p), ("wp", c_p), ("Cout", c_i), ("Cin", c_i), ("kh", c_i), ("kw", c_i),
+                ("kind", c_i), ("KoutP", c_i), ("KinP", c_i), ("n_out", c_l)]
+
+
+_SIGS = {
+    "tnr_last_error": (C.c_char_p, []),
+    "tnr_version": (c_i, []),
+    "tnr_pack_dims": (c_i, [c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_l)]),
+    "tnr_pack_weights": (c_i, [c_p, c_i, c_l, c_p]),
+    "tnr_conv_forward": (c_i, [C.POINTER(ConvDesc), c_p]),
+    "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
+    "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
+    "tnr_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, CView, c_i, c_p, c_p, c_p]),
+    "tnr_nhwc_to_nchw": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "tnr_upsample2x_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
+    "tnr_depth_to_space": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_space_to_depth_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
+    "tnr_maxpool2_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_maxpool2_bwd": (c_i, [CView, CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_axpby": (c_i, [CView, CView, c_l, c_i, c_f, c_f, c_p]),
+    "tnr_mask_mul": (c_i, [CView, CView, c_l, c_i, c_f, c_p]),
+    "tnr_fill": (c_i, [c_p, c_l, c_f, c_p]),
+    "tnr_bn_workspace_bytes": (c_l, [c_i]),
+    "tnr_bn_train_fwd": (c_i, [CView, CView, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_i, c_f, c_p, c_p]),
+    "tnr_bn_train_bwd": (c_i, [CView, CView, CView, CView, c_l, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]),
+    "tnr_linear_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "tnr_linear_bwd": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    "tnr_reduce_workspace_bytes": (c_l, []),
+    "tnr_l1_mean_fwd": (c_i, [c_p, c_p, c_l, c_f, c_p, c_p, c_p]),
+    "tnr_l1_mean_bwd": (c_i, [c_p, c_p, c_l, c_f, c_p, c_p, c_i, c_p]),
+    "tnr_ragan_phase_a": (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    "tnr_ragan_phase_b": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "tnr_ragan_phase_c": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "tnr_scale_by": (c_i, [c_p, c_p, c_l, c_p, c_p]),
+    "tnr_sumsq": (c_i, [c_p, c_l, c_p, c_p, c_p]),
+    "tnr_clip_by_norm": (c_i, [c_p, c_l, c_p, c_f, c_p]),
+    "tnr_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _build.LIB
+
+
+def load(build_if_missing=False):
+    """dlopen the in-tree library and type every export.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        if build_if_missing:
+            _build.build()
+        else:
+            raise HipEngineError(
+                "libtrainner_hip.so not found at %s -- run `python -m trainner_amd.build` "
+                "(the engine has no CPU / eager fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def require_device(t=None):
+    if not torch.cuda.is_available():
+        raise HipEngineError("no HIP device visible: the trainner_amd engine only runs on MI355X (gfx950)")
+    if t is not None and not t.is_cuda:
+        raise HipEngineError("tensor is not on a HIP device")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().tnr_last_error()
+        raise HipEngineError("%s failed (%d): %s" % (what or "tnr call", rc, msg.decode() if msg else "?"))
+
+
+NULLVIEW = CView(None, 0, 0)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,332 @@
+"""BaseModel of the MI355X engine: the reference's model-object protocol (codes/models/base_model.py).
+
+Kept verbatim in behaviour: device pick (:76-81), save/load of networks as legacy-pickle CPU
+state_dicts with `latest_/previous_` rotation (:353-443), training-state save/resume (:454-500), LR /
+scheduler plumbing (:209-317), `requires_grad` (:325-351), the `setup_*` feature switches (:641-787) and
+`calc_gradients` / `optimizer_step` / `backward_D_Basic` / `apply_gradclip` (:805-922).
+Re-designed: gradient clipping and Adam act on the flat buffers (2 + 1 launches per network), the
+data-parallel gradient exchange happens inside `optimizer_step`, AMP/SWA/CEM/ATG/batch-aug switches
+raise if enabled (they are off in the ESRGAN recipe and outside the hot path, SURVEY.md 2 #18,#24).
+"""
+import logging
+import os
+from collections import Counter, OrderedDict
+from contextlib import nullcontext
+from shutil import copyfile
+
+import torch
+import torch.nn as nn
+
+from .. import dp as dpmod
+from .. import hip, ops
+from . import optimizers, schedulers
+from .losses import Adversarial
+from .networks import model_val
+
+logger = logging.getLogger("base")
+
+
+class LazyLog(OrderedDict):
+    """log_dict whose values may be 0-dim device tensors; they are fetched (one host sync per read
+    of the dict, not eight per step like the reference's `.item()` calls: losses.py:862,
+    sr_model.py:177, losses.py:515-520) when the training script asks for the log."""
+
+    def materialize(self):
+        out = OrderedDict()
+        for k, v in self.items():
+            out[k] = float(v) if torch.is_tensor(v) else v
+        return out
+
+
+class BaseModel:
+    def __init__(self, opt):
+        self.opt = opt
+        if opt["gpu_ids"]:
+            hip.require_device()
+            local = int(os.environ.get("LOCAL_RANK", "0")) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
+            self.device = torch.device("cuda", local)
+            torch.cuda.set_device(self.device)
+        else:
+            # the reference falls back to CPU here (base_model.py:80-81); this engine has no CPU path
+            raise hip.HipEngineError("gpu_ids is empty: the trainner_amd engine runs only on MI355X "
+                                     "(use the reference itself, or oracle/, for CPU)")
+        self.is_train = opt["is_train"]
+        self.model_names = []
+        self.schedulers = []
+        self.optimizers = []
+        self.swa = None
+        self.swa_start_iter = None
+        self.metric = 0
+        self.batchaugment = None
+        self.upsample = False
+        self.unshuffle = None
+        self.grad_clip = None
+        self.grad_history = []
+        self.dp = dpmod.init_from_env()
+
+    # ------------------------------------------------------------------ protocol stubs
+    def feed_data(self, data):
+        pass
+
+    def optimize_parameters(self, step):
+        pass
+
+    def get_current_visuals(self):
+        pass
+
+    def get_current_losses(self):
+        pass
+
+    def print_network(self, verbose=False):
+        for name in self.model_names:
+            net = getattr(self, "net" + name)
+            s, n = self.get_network_description(net)
+            logger.info("Network %s structure: %s, with parameters: %s", name, net.__class__.__name__, "{:,d}".format(n))
+            if verbose:
+                logger.info(s)
+
+    def get_network_description(self, network):
+        return str(network), sum(p.numel() for p in network.parameters())
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self, iter_step, latest=None, loader=None):
+        if self.dp.rank != 0:
+            return
+        for name in self.model_names:
+            self.save_network(getattr(self, "net" + name), name, iter_step, latest)
+
+    def load(self):
+        for name in self.model_names:
+            load_path = self.opt["path"]["pretrain_model_{}".format(name)]
+            if load_path is None:
+                continue
+            logger.info("Loading pretrained model for %s [%s]", name, load_path)
+            key = "network_{}".format(name)
+            strict = self.opt[key].get("strict", None) if self.opt[key] else True
+            self.load_network(load_path, getattr(self, "net" + name), strict, model_type=name)
+
+    def save_network(self, network, network_label, iter_step, latest=False):
+        fname = "latest_{}.pth".format(network_label) if latest else "{}_{}.pth".format(iter_step, network_label)
+        save_path = os.path.join(self.opt["path"]["models"], fname)
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        if os.path.exists(save_path):
+            copyfile(save_path, os.path.join(self.opt["path"]["models"], "previous_{}.pth".format(network_label)))
+        state = OrderedDict((k, v.detach().cpu().clone()) for k, v in network.state_dict().items())
+        torch.save(state, save_path, _use_new_zipfile_serialization=False)
+
+    def load_network(self, load_path, network, strict=True, submodule=None, model_type=None, param_key=None):
+        load_net = torch.load(load_path, map_location="cpu", weights_only=False)
+        if "state_dict" in load_net:
+            load_net = load_net["state_dict"]
+        if param_key is not None:
+            load_net = load_net[param_key]
+        own = network.state_dict()
+        if len(load_net) == len(own):      # same layout, mismatching shapes keep the initialised tensor
+            load_net = OrderedDict((k, v if v.size() == own[k].size() else own[k])
+                                   for k, v in zip(own.keys(), load_net.values()))
+        if model_type:
+            load_net = model_val(opt_net=self.opt, state_dict=load_net, model_type=model_type)
+        network.load_state_dict(load_net, strict=bool(strict))
+
+    def save_training_state(self, epoch, iter_step, latest=False):
+        if self.dp.rank != 0:
+            return
+        state = {"epoch": epoch, "iter": iter_step, "schedulers": [s.state_dict() for s in self.schedulers],
+                 "optimizers": [o.state_dict() for o in self.optimizers]}
+        fname = "latest.state" if latest else "{}.state".format(iter_step)
+        save_path = os.path.join(self.opt["path"]["training_state"], fname)
+        os.makedirs(os.path.dirname(save_path), exist_ok=True)
+        if os.path.exists(save_path):
+            copyfile(save_path, os.path.join(self.opt["path"]["training_state"], "previous.state"))
+        torch.save(state, save_path)
+
+    def resume_training(self, resume_state):
+        ro, rs = resume_state["optimizers"], resume_state["schedulers"]
+        assert len(ro) == len(self.optimizers), "Wrong length of optimizers"
+        assert len(rs) == len(self.schedulers), "Wrong length of schedulers"
+        for o, st in zip(self.optimizers, ro):
+            o.load_state_dict(st)
+        for s, st in zip(self.schedulers, rs):
+            if hasattr(s, "milestones") and isinstance(s.milestones, Counter) and isinstance(st.get("milestones"), list):
+                st["milestones"] = Counter(st["milestones"])
+            s.load_state_dict(st)
+
+    def update_schedulers(self, train_opt):
+        for s in self.schedulers:
+            if train_opt["lr_gamma"] is not None and getattr(s, "gamma", None) not in (None, train_opt["lr_gamma"]):
+                s.gamma = train_opt["lr_gamma"]
+            if train_opt["lr_scheme"] == "MultiStepLR" and train_opt["lr_steps"] is not None:
+                steps = Counter(train_opt["lr_steps"])
+                if s.milestones != steps:
+                    s.milestones = steps
+
+    # ------------------------------------------------------------------ learning rate
+    def _set_lr(self, lr_groups_l):
+        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
+            for group, lr in zip(optimizer.param_groups, lr_groups):
+                group["lr"] = lr
+
+    def _get_init_lr(self):
+        return [[g["initial_lr"] for g in o.param_groups] for o in self.optimizers]
+
+    def update_learning_rate(self, current_step=None, warmup_iter=-1):
+        for s in self.schedulers:
+            s.step()
+        if current_step is not None and current_step < warmup_iter:
+            self._set_lr([[v / warmup_iter * current_step for v in grp] for grp in self._get_init_lr()])
+        self.optGstep = False
+        if self.cri_gan:
+            self.optDstep = False
+
+    def get_current_learning_rate(self, current_step=None):
+        return self.schedulers[0].get_last_lr()[0]
+
+    def requires_grad(self, model, flag=True, target_layer=None, net_type=None):
+        for name, param in model.named_parameters():
+            if target_layer is None:
+                param.requires_grad = flag
+            elif net_type == "D" and "features.{}.".format(target_layer) in name:
+                param.requires_grad = flag
+
+    # ------------------------------------------------------------------ feature switches
+    def _reject(self, enabled, what):
+        if enabled:
+            raise NotImplementedError("{} is off in the ESRGAN recipe and not implemented by the HIP engine".format(what))
+
+    def setup_atg(self):
+        self.atg = False
+        self._reject(self.opt.get("use_atg"), "AdaTarget (use_atg)")
+
+    def setup_batchaug(self):
+        self.mixup = None
+        self._reject(self.opt["train"].get("mixup"), "batch augmentation (mixup)")
+
+    def setup_fs(self):
+        self.f_low = self.f_high = None
+        self._reject(self.opt["train"].get("fs"), "frequency separation (fs)")
+
+    def setup_gan(self, conditional=False):
+        train_opt = self.opt["train"]
+        if train_opt["gan_type"] and train_opt["gan_weight"]:
+            self.cri_gan = True
+            self.adversarial = Adversarial(train_opt=train_opt, device=self.device, diffaug=train_opt.get("diffaug"),
+                                           conditional=conditional)
+            self.adversarial.dp_group = self.dp if self.dp.world_size > 1 else None
+            self.D_update_ratio = train_opt.get("D_update_ratio", 1) or 1
+            self.D_init_iters = train_opt.get("D_init_iters", 0) or 0
+            logger.info("GAN enabled")
+        else:
+            self.cri_gan = False
+
+    def setup_freezeD(self):
+        self.feature_loc = None
+        loc = self.opt["train"].get("freeze_loc")
+        if loc and "discriminator_vgg" in self.opt["network_D"].get("type", ""):
+            self.feature_loc = (loc * 3) - 2
+            logger.info("FreezeD enabled")
+
+    def setup_optimizers(self, opt_G_nets, opt_D_nets, init_setup=False):
+        if init_setup:
+            self.optGstep, self.optDstep = False, True
+        train_opt = self.opt["train"]
+        self.optimizer_G = optimizers.config_optimizer(train_opt, "G", opt_G_nets)
+        self.optimizers.append(self.optimizer_G)
+        self._opt_nets = {"G": list(opt_G_nets)}
+        if self.cri_gan:
+            self.optimizer_D = optimizers.config_optimizer(train_opt, "D", opt_D_nets)
+            self.optimizers.append(self.optimizer_D)
+            self._opt_nets["D"] = list(opt_D_nets)
+            self.optDstep = False
+
+    def setup_schedulers(self):
+        self.schedulers = schedulers.get_schedulers(optimizers=self.optimizers, train_opt=self.opt["train"])
+
+    def setup_swa(self):
+        self.swa = None
+        self._reject(self.opt.get("use_swa"), "SWA (use_swa)")
+
+    def setup_virtual_batch(self):
+        ds = self.opt["datasets"]["train"]
+        batch_size = ds["batch_size"]
+        vb = ds.get("virtual_batch_size", None)
+        self.virtual_batch = vb if (vb and vb > batch_size) else batch_size
+        self.accumulations = self.virtual_batch // batch_size
+
+    def setup_amp(self):
+        self.amp = False
+        self.cast = nullcontext
+        self._reject(self.opt.get("use_amp"), "AMP (use_amp; the engine computes in fp32 on the matrix cores)")
+
+    def setup_cem(self):
+        self.CEM = None
+        self._reject(self.opt.get("use_cem"), "CEM (use_cem)")
+
+    def setup_unshuffle(self):
+        self._reject(self.opt.get("use_unshuffle"), "pixel unshuffle wrapper")
+
+    def setup_gradclip(self, clip_nets):
+        train_opt = self.opt["train"]
+        grad_clip = train_opt.get("grad_clip")
+        if grad_clip:
+            if grad_clip.lower() != "norm":
+                raise NotImplementedError("grad_clip [{}] is not implemented by the HIP engine".format(grad_clip))
+            self.grad_clip = "norm"
+            self.grad_clip_value = train_opt.get("grad_clip_value", 0.1)
+            if self.grad_clip_value == "auto":
+                raise NotImplementedError("grad_clip_value 'auto' is not implemented by the HIP engine")
+            self.clip_nets = clip_nets
+            logger.info("norm gradient clip enabled. Clip value: %s.", self.grad_clip_value)
+
+    # ------------------------------------------------------------------ step pieces
+    def calc_gradients(self, loss):
+        loss.backward()
+
+    def _sync_gradients(self, opt_flag):
+        """Data-parallel exchange of the gradients the backward pass just produced."""
+        if self.dp.world_size == 1:
+            return
+        for net in self._opt_nets[opt_flag]:
+            holder = net.flat_params()
+            sched = getattr(net, "_bucket_schedule", None)
+            if sched is not None:
+                sched.flush()
+                net._bucket_schedule = None
+            else:
+                self.dp.reduce_flat(holder.grad)
+        self.dp.wait(self.device)
+
+    def optimizer_step(self, step, optimizer, opt_flag):
+        """base_model.py:815-850: step only when the virtual batch is complete; G gets the clip."""
+        if step % self.accumulations != 0:
+            return
+        self._sync_gradients(opt_flag)
+        if opt_flag == "G":
+            self.apply_gradclip()
+        optimizer.step()
+        optimizer.zero_grad()
+        if opt_flag == "G":
+            self.optGstep = True
+        elif opt_flag == "D":
+            self.optDstep = True
+
+    def backward_D_Basic(self, netD, real=None, fake=None, log_dict=None, condition=None):
+        if log_dict is None:
+            log_dict = LazyLog()
+        l_d_total, gan_logs = self.adversarial(fake, real, condition, netD=netD, stage="discriminator", fsfilter=self.f_high)
+        for k, v in gan_logs.items():
+            log_dict[k] = v
+        if self.accumulations != 1:
+            l_d_total = l_d_total / self.accumulations
+        self.calc_gradients(l_d_total)
+        return log_dict
+
+    def apply_gradclip(self):
+        """clip_grad_norm_ over each clip net (base_model.py:911-922) = sum-of-squares reduction + one
+        scaling launch over the flat gradient buffer."""
+        if self.grad_clip is None:
+            return
+        for net in self.clip_nets:
+            holder = net.flat_params()
+            ss = torch.empty(1, dtype=torch.float64, device=holder.grad.device)
+            ops.sumsq(holder.grad, ss)
+            ops.clip_by_norm(holder.grad, ss, float(self.grad_clip_value))

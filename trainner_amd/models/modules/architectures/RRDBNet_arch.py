@@ -1,0 +1,252 @@
+"""RRDBNet (ESRGAN generator) on the MI355X engine.
+
+Same constructor, same state_dict keys and the same arithmetic as the reference's
+codes/models/modules/architectures/RRDBNet_arch.py (RRDBNet :14-60, RRDB :62-96,
+ResidualDenseBlock_5C :98-163), re-designed for CDNA4:
+
+  * every dense block lives in ONE 192-channel NHWC buffer [x | x1 | x2 | x3 | x4]; conv_k reads
+    channels [0, 64+32(k-1)) and writes its 32 channels in place, so the four torch.cat per block
+    (:152-160) never happen;
+  * bias, LeakyReLU(0.2), `x5*0.2 + x` and the RRDB-level `out*0.2 + x` are epilogues of the
+    implicit-GEMM kernel (conv5 of RDB3 carries both residuals);
+  * the nearest x2 of upconv_block is folded into the following conv's gather;
+  * backward is a hand-written schedule: per dense block five data-gradient launches that
+    accumulate in place into a 192-channel gradient buffer (LeakyReLU' fused as an epilogue mask)
+    and the matching deterministic split-K weight gradients, written straight into the flat
+    gradient buffer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....engine import ConvOp, HipNet
+from ....ops import View, new_act
+from . import block as B
+
+
+class ResidualDenseBlock_5C(nn.Module):
+    def __init__(self, nf=64, gc=32, act_type="leakyrelu"):
+        super().__init__()
+        self.conv1 = B.conv_block(nf, gc, 3, act_type=act_type)
+        self.conv2 = B.conv_block(nf + gc, gc, 3, act_type=act_type)
+        self.conv3 = B.conv_block(nf + 2 * gc, gc, 3, act_type=act_type)
+        self.conv4 = B.conv_block(nf + 3 * gc, gc, 3, act_type=act_type)
+        self.conv5 = B.conv_block(nf + 4 * gc, nf, 3, act_type=None)
+
+
+class RRDB(nn.Module):
+    def __init__(self, nf, gc=32, act_type="leakyrelu"):
+        super().__init__()
+        self.RDB1 = ResidualDenseBlock_5C(nf, gc, act_type)
+        self.RDB2 = ResidualDenseBlock_5C(nf, gc, act_type)
+        self.RDB3 = ResidualDenseBlock_5C(nf, gc, act_type)
+
+
+class RRDBNet(HipNet):
+    def __init__(self, in_nc, out_nc, nf, nb, nr=3, gc=32, upscale=4, norm_type=None, act_type="leakyrelu",
+                 mode="CNA", upsample_mode="upconv", convtype="Conv2D", finalact=None, gaussian_noise=False,
+                 plus=False):
+        super().__init__()
+        if nr != 3 or norm_type is not None or mode != "CNA" or convtype != "Conv2D" or finalact or plus:
+            raise NotImplementedError("RRDBNet option outside the ESRGAN recipe is not implemented by the HIP engine")
+        if gaussian_noise:
+            raise NotImplementedError("gaussian_noise (ESRGAN+) is stochastic and off the measured path; "
+                                      "set network_G.gaussian: false")
+        if upscale not in (2, 4, 8) or upsample_mode not in ("upconv", "pixelshuffle"):
+            raise NotImplementedError("upscale %s / upsample mode [%s] is not found" % (upscale, upsample_mode))
+        if nf % 32 or in_nc > 4 or out_nc > 4:
+            raise NotImplementedError("HIP RRDBNet needs nf %% 32 == 0 and <= 4 image channels")
+        self.in_nc, self.out_nc, self.nf, self.nb, self.gc = in_nc, out_nc, nf, nb, 32  # reference ignores gc (:24)
+        self.upsample_mode, self.n_up = upsample_mode, int(math.log(upscale, 2))
+        self.act, self.slope = B.act_code(act_type)
+
+        fea_conv = B.conv_block(in_nc, nf, 3, act_type=None)
+        trunk = [RRDB(nf, 32, act_type) for _ in range(nb)] + [B.conv_block(nf, nf, 3, act_type=None)]
+        ups = []
+        for _ in range(self.n_up):
+            if upsample_mode == "upconv":
+                ups.append(B.flat_sequential(B.Marker("nearest x2"), B.conv_block(nf, nf, 3, act_type=act_type)))
+            else:
+                ups.append(B.flat_sequential(B.conv_block(nf, nf * 4, 3, act_type=None), B.Marker("pixelshuffle x2"),
+                                             B.Marker("act:" + act_type)))
+        hr0 = B.conv_block(nf, nf, 3, act_type=act_type)
+        hr1 = B.conv_block(nf, out_nc, 3, act_type=None)
+        self.model = B.flat_sequential(fea_conv, B.ShortcutBlock(B.flat_sequential(*trunk)), *ups, hr0, hr1)
+        self._init_engine()
+
+    # ------------------------------------------------------------------------------ engine
+    def _build_ops(self, packer):
+        m = self.model
+        o = {"fea": ConvOp(m[0], packer, need_dgrad=False)}
+        sub = m[1].sub
+        o["rdb"] = []
+        for b in range(self.nb):
+            for r in (sub[b].RDB1, sub[b].RDB2, sub[b].RDB3):
+                o["rdb"].append([ConvOp(getattr(r, "conv%d" % k)[0], packer) for k in range(1, 6)])
+        o["lr"] = ConvOp(sub[self.nb], packer)
+        o["up"] = []
+        idx = 2
+        for _ in range(self.n_up):
+            if self.upsample_mode == "upconv":
+                o["up"].append(ConvOp(m[idx + 1], packer, ups=True))
+            else:
+                o["up"].append(ConvOp(m[idx], packer))
+            idx += 3
+        o["hr0"] = ConvOp(m[idx], packer)
+        o["hr1"] = ConvOp(m[idx + 2], packer)
+        self._ops = o
+
+    def engine_forward(self, x, save):
+        o, nf, gc = self._ops, self.nf, self.gc
+        N, _, h, w = x.shape
+        dev = x.device
+        act, sl = self.act, self.slope
+        cb = nf + 4 * gc
+        lr = new_act(N, h, w, 4, dev)
+        ops.nchw_to_nhwc(x, View(lr), Cpad=4)
+        nrdb = 3 * self.nb
+        nbuf = nrdb if save else min(nrdb, 4)
+        bufs = [new_act(N, h, w, cb, dev) for _ in range(nbuf)]
+        trunk = new_act(N, h, w, nf, dev)
+        first = View(bufs[0], 0, nf) if nrdb else View(trunk)
+        o["fea"].fwd(View(lr), first)
+        fea_keep = first
+        if not save and nrdb:
+            # the ring of 4 buffers is recycled: keep fea for the ShortcutBlock add
+            fea_keep = View(new_act(N, h, w, nf, dev))
+            ops.axpby(fea_keep, first, 1.0, 0.0)
+        for i in range(nrdb):
+            buf = bufs[i % nbuf]
+            convs = o["rdb"][i]
+            for k in range(4):
+                cin = nf + gc * k
+                convs[k].fwd(View(buf, 0, cin), View(buf, cin, gc), act=act, slope=sl)
+            dst = View(bufs[(i + 1) % nbuf], 0, nf) if i + 1 < nrdb else View(trunk)
+            if i % 3 == 2:   # RDB3 also closes the RRDB: (x5*0.2 + x)*0.2 + x_rrdb
+                convs[4].fwd(View(buf), dst, alpha=0.2, r1=View(buf, 0, nf), r2=View(bufs[(i - 2) % nbuf], 0, nf), alpha2=0.2)
+            else:
+                convs[4].fwd(View(buf), dst, alpha=0.2, r1=View(buf, 0, nf))
+        y0 = new_act(N, h, w, nf, dev)
+        o["lr"].fwd(View(trunk), View(y0), r1=fea_keep)          # ShortcutBlock: fea + trunk(fea)
+        cur, stages = View(y0), []
+        for u in o["up"]:
+            H2, W2 = cur.H * 2, cur.W * 2
+            if self.upsample_mode == "upconv":
+                nxt = View(new_act(N, H2, W2, nf, dev))
+                u.fwd(cur, nxt, act=act, slope=sl)
+                stages.append((cur, nxt, None))
+            else:
+                t = View(new_act(N, cur.H, cur.W, 4 * nf, dev))
+                u.fwd(cur, t, act=act, slope=sl)                  # activation commutes with the shuffle
+                nxt = View(new_act(N, H2, W2, nf, dev))
+                ops.depth_to_space(t, nxt)
+                stages.append((cur, nxt, t))
+            cur = nxt
+        h0 = View(new_act(N, cur.H, cur.W, nf, dev))
+        o["hr0"].fwd(cur, h0, act=act, slope=sl)
+        o4 = new_act(N, cur.H, cur.W, 4, dev)
+        o["hr1"].fwd(h0, View(o4, 0, self.out_nc))
+        out = torch.empty((N, self.out_nc, cur.H, cur.W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(o4, 0, self.out_nc), out)
+        saved = None
+        if save:
+            saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w))
+        return out, saved
+
+    def _rdb_backward(self, convs, buf, gin, s, G, extra, want_w):
+        """Backward of one dense block.  gin: incoming gradient (64-ch view), s: its scale, G: 192-ch
+        gradient buffer to fill ([0:64) ends as the gradient w.r.t. the block input), extra: optional
+        view added to that result (the RRDB skip)."""
+        nf, gc, sl = self.nf, self.gc, self.slope
+        cb = nf + 4 * gc
+        # conv5: G[0:192) = 0.2*s*dgrad5(gin); G[0:64) += s*gin; LeakyReLU' of x4 on channels [160,192)
+        convs[4].dgrad(gin, View(G, 0, cb), alpha=0.2 * s, r1=gin, r1_ch=nf, beta1=s,
+                       mask=View(buf), m_lo=cb - gc, m_hi=cb, m_slope=sl)
+        if want_w:
+            convs[4].wgrad(View(buf), gin, alpha=0.2 * s)
+        for k in (3, 2, 1, 0):                       # conv4 .. conv1
+            cin = nf + gc * k
+            gk = View(G, cin, gc)                     # final, already masked
+            acc = View(G, 0, cin)
+            kw = dict(alpha=1.0, r1=acc, beta1=1.0)
+            if k > 0:
+                kw.update(mask=View(buf), m_lo=cin - gc, m_hi=cin, m_slope=sl)
+            elif extra is not None:
+                kw.update(r2=extra, alpha2=1.0)
+            convs[k].dgrad(gk, acc, **kw)
+            if want_w:
+                if cin > 128:                        # 160 input channels: 96 + 64 (tile shapes of wgrad_tile.hip)
+                    convs[k].wgrad(View(buf, 0, 96), gk, cin_begin=0)
+                    convs[k].wgrad(View(buf, 96, cin - 96), gk, cin_begin=96)
+                else:
+                    convs[k].wgrad(View(buf, 0, cin), gk)
+
+    def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
+        o, nf, gc, sl = self._ops, self.nf, self.gc, self.slope
+        N, h, w = sv["shape"]
+        gout = gout.contiguous()
+        dev = gout.device
+        W = need_param_grad
+        cur, h0 = sv["hr_in"], sv["h0"]
+        g4 = new_act(N, cur.H, cur.W, 4, dev)
+        ops.nchw_to_nhwc(gout, View(g4), Cpad=4)
+        gh0 = View(new_act(N, cur.H, cur.W, nf, dev))
+        o["hr1"].dgrad(View(g4), gh0, mask=h0, m_slope=sl)
+        if W:
+            o["hr1"].wgrad(h0, View(g4, 0, self.out_nc))
+        gcur = View(new_act(N, cur.H, cur.W, nf, dev))
+        last_stage = sv["stages"][-1] if sv["stages"] else None
+        # gradient w.r.t. hr_in; it is an activation output only if an upsample stage produced it
+        o["hr0"].dgrad(gh0, gcur, **(dict(mask=cur, m_slope=sl) if (last_stage and self.upsample_mode == "upconv") else {}))
+        if W:
+            o["hr0"].wgrad(cur, gh0)
+        for si in range(len(sv["stages"]) - 1, -1, -1):
+            src, dst, t = sv["stages"][si]
+            u = o["up"][si]
+            prev_is_act = si > 0 and self.upsample_mode == "upconv"
+            if self.upsample_mode == "upconv":
+                # gcur = grad w.r.t. dst pre-activation (mask applied by the consumer's dgrad epilogue)
+                if W:
+                    u.wgrad(src, gcur)
+                gup = View(new_act(N, dst.H, dst.W, nf, dev))
+                u.dgrad(gcur, gup)
+                gsrc = View(new_act(N, src.H, src.W, nf, dev))
+                ops.upsample2x_bwd(gup, gsrc, mask=(src if prev_is_act else None), mslope=sl)
+            else:
+                gt = View(new_act(N, src.H, src.W, 4 * nf, dev))
+                ops.space_to_depth_bwd(gcur, gt, mask=dst, mslope=sl)
+                if W:
+                    u.wgrad(src, gt)
+                gsrc = View(new_act(N, src.H, src.W, nf, dev))
+                u.dgrad(gt, gsrc)
+            gcur = gsrc
+        gy0 = gcur                                     # grad w.r.t. fea + trunk
+        nrdb = 3 * self.nb
+        cb = nf + 4 * gc
+        G = [new_act(N, h, w, cb, dev) for _ in range(3 if nrdb else 1)]
+        if W:
+            o["lr"].wgrad(View(sv["trunk"]), gy0)
+        o["lr"].dgrad(gy0, View(G[0], 0, nf))
+        pin = 0                                        # index of the buffer holding the incoming gradient
+        for b in range(self.nb - 1, -1, -1):
+            q, r = [i for i in range(3) if i != pin]
+            bufs, convs = sv["bufs"], o["rdb"]
+            self._rdb_backward(convs[3 * b + 2], bufs[3 * b + 2], View(G[pin], 0, nf), 0.2, G[q], None, W)
+            self._rdb_backward(convs[3 * b + 1], bufs[3 * b + 1], View(G[q], 0, nf), 1.0, G[r], None, W)
+            self._rdb_backward(convs[3 * b], bufs[3 * b], View(G[r], 0, nf), 1.0, G[q], View(G[pin], 0, nf), W)
+            pin = q
+        gfea = View(G[pin], 0, nf)
+        ops.axpby(gfea, gy0, 1.0, 1.0)                 # ShortcutBlock: both branches reach fea
+        if W:
+            o["fea"].wgrad(View(sv["lr"], 0, self.in_nc), gfea)
+        gx = None
+        if need_input_grad:
+            raise NotImplementedError("gradient w.r.t. the LR input is not on the SR training path")
+        return gx
+
+    def forward(self, x, outm=None):
+        if outm:
+            raise NotImplementedError("finalcap/outm [%s] is not implemented by the HIP engine" % outm)
+        return super().forward(x)

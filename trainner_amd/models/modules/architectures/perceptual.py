@@ -1,0 +1,160 @@
+"""VGG feature extractor for the perceptual loss, on the MI355X engine.
+
+Follows codes/models/modules/architectures/perceptual.py FeatureExtractor (:73-214): ImageNet
+(x-mean)/std, torchvision cfg-E/D `features` truncated after the last listened layer, listened
+features taken BEFORE the ReLU when a 'convX_Y' name is listened (the `x.clone()` at :211-212
+happens before the in-place ReLU that follows).  Parameters are frozen (requires_grad False,
+:185-188): only the data-gradient schedule exists.
+
+torchvision is not a dependency: the layer table is the public VGG configuration.  Pretrained
+ImageNet weights, when available, are loaded with `load_path` (a torchvision `vgg19` state_dict,
+keys `features.N.*`); otherwise the caller fills the weights (the benchmarks use seeded weights,
+there is no network access).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....engine import ConvOp, HipNet
+from ....ops import View, new_act
+from . import block as B
+
+VGG_CFG = {
+    "vgg16": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
+    "vgg19": [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"],
+}
+
+
+def vgg_layer_names(net):
+    names, blk, idx = [], 1, 1
+    for v in VGG_CFG[net]:
+        if v == "M":
+            names.append("pool%d" % blk)
+            blk, idx = blk + 1, 1
+        else:
+            names += ["conv%d_%d" % (blk, idx), "relu%d_%d" % (blk, idx)]
+            idx += 1
+    return names
+
+
+class FeatureExtractor(HipNet):
+    def __init__(self, listen_list=None, net="vgg19", use_input_norm=True, z_norm=False, requires_grad=False,
+                 remove_pooling=False, pooling_stride=2, change_padding=False, load_path=None):
+        super().__init__()
+        if net not in VGG_CFG or remove_pooling or pooling_stride != 2 or change_padding or requires_grad or z_norm:
+            raise NotImplementedError("FeatureExtractor option outside the ESRGAN recipe is not implemented by the HIP engine")
+        listen_list = list(listen_list or ["conv5_4"])
+        if len(listen_list) != 1 or not listen_list[0].startswith("conv"):
+            raise NotImplementedError("the HIP FeatureExtractor listens to exactly one pre-ReLU conv layer")
+        self.listen = listen_list[0]
+        self.listen_list = set(listen_list)
+        self.use_input_norm = use_input_norm
+        names = vgg_layer_names(net)
+        last = names.index(self.listen)
+        self.names = names[:last + 1]
+        layers, c, chans = nn.ModuleDict(), 3, iter([v for v in VGG_CFG[net] if v != "M"])
+        for n in self.names:
+            if n.startswith("conv"):
+                v = next(chans)
+                layers[n] = B.Conv2dHIP(c, v, 3, 1)
+                c = v
+            else:
+                layers[n] = B.Marker(n)
+        self.feature_net = layers            # keys feature_net.convX_Y.{weight,bias} as in the reference
+        self.out_channels = c
+        if use_input_norm:
+            self.register_buffer("mean", torch.tensor([[[0.485]], [[0.456]], [[0.406]]]))
+            self.register_buffer("std", torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
+        if load_path and os.path.exists(load_path):
+            self.load_torchvision_state(torch.load(load_path, map_location="cpu"))
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+        self._init_engine()
+        self._norm = None
+
+    def load_torchvision_state(self, sd):
+        """Accept a torchvision vggNN state_dict (features.<i>.weight/bias): torchvision's `features`
+        indices run over the same conv / relu / pool sequence as self.names."""
+        own = self.state_dict()
+        for i, n in enumerate(self.names):
+            if n.startswith("conv"):
+                own["feature_net.%s.weight" % n].copy_(sd["features.%d.weight" % i])
+                own["feature_net.%s.bias" % n].copy_(sd["features.%d.bias" % i])
+
+    def _build_ops(self, packer):
+        self._ops = {n: ConvOp(self.feature_net[n], packer) for n in self.names if n.startswith("conv")}
+
+    def _norm_consts(self, dev):
+        """(x - mean)/std as x*scale + shift; six host-side constants uploaded once."""
+        if self._norm is None or self._norm[0].device != dev:
+            if self.use_input_norm:
+                mean = [float(v) for v in self.mean.reshape(3).cpu().tolist()]
+                std = [float(v) for v in self.std.reshape(3).cpu().tolist()]
+                scale = torch.tensor([1.0 / s for s in std], dtype=torch.float32).to(dev)
+                shift = torch.tensor([-m / s for m, s in zip(mean, std)], dtype=torch.float32).to(dev)
+            else:
+                scale = torch.ones(3).to(dev)
+                shift = torch.zeros(3).to(dev)
+            self._norm = (scale, shift)
+        return self._norm
+
+    def engine_forward(self, x, save):
+        N, Cc, H, W = x.shape
+        if Cc != 3:
+            raise ValueError("FeatureExtractor expects RGB input")
+        dev = x.device
+        scale, shift = self._norm_consts(dev)
+        x4 = View(new_act(N, H, W, 4, dev))
+        ops.nchw_to_nhwc(x, x4, Cpad=4, scale=scale, shift=shift)
+        cur, tape = x4, []
+        for n in self.names:
+            if n.startswith("conv"):
+                y = View(new_act(N, cur.H, cur.W, self.feature_net[n].out_channels, dev))
+                if n == self.listen:
+                    self._ops[n].fwd(cur, y)                              # listened pre-ReLU
+                else:
+                    self._ops[n].fwd(cur, y, act=ops.ACT_RELU)
+                tape.append((n, cur, y))
+                cur = y
+            elif n.startswith("pool"):
+                y = View(new_act(N, cur.H // 2, cur.W // 2, cur.C, dev))
+                ops.maxpool2_fwd(cur, y)
+                tape.append((n, cur, y))
+                cur = y
+        # logical NCHW tensor over the NHWC storage (channels_last strides); L1 is layout agnostic
+        out = cur.buf.permute(0, 3, 1, 2)
+        return out, (dict(tape=tape, in_shape=(N, H, W)) if save else None)
+
+    def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
+        if not need_input_grad:
+            return None
+        tape = sv["tape"]
+        N, H, W = sv["in_shape"]
+        dev = gout.device
+        g_nhwc = gout.permute(0, 2, 3, 1)
+        if not g_nhwc.is_contiguous():
+            g_nhwc = g_nhwc.contiguous()
+        g = View(g_nhwc)
+        for i in range(len(tape) - 1, -1, -1):
+            n, xin, y = tape[i]
+            gx = View(new_act(N, xin.H, xin.W, xin.C, dev))
+            if n.startswith("pool"):
+                ops.maxpool2_bwd(g, xin, gx)                              # routes + ReLU' of the pooled activation
+            else:
+                prev = tape[i - 1][0] if i > 0 else None
+                if prev is not None and prev.startswith("conv"):
+                    self._ops[n].dgrad(g, gx, mask=xin, m_slope=0.0)      # ReLU' of the producing conv
+                else:
+                    self._ops[n].dgrad(g, gx)                             # input image / pooled map: no activation
+            g = gx
+        scale, _ = self._norm_consts(dev)
+        out = torch.empty((N, 3, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(g.buf, 0, 3), out, scale=scale)
+        return out
+
+    def forward(self, x):
+        feat = super().forward(x)
+        return {self.listen: feat}

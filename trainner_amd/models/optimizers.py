@@ -1,0 +1,112 @@
+"""Optimiser factory of the SR path.
+
+`config_optimizer(train_opt, name, net)` keeps the reference's contract (codes/models/optimizers.py:
+74-134: lr_<G|D> default 1e-4, beta1 0.9, beta2 0.999, weight decay 0, Adam default eps 1e-8) but the
+'adam' branch (:130-132) returns FusedAdam: torch.optim.Adam's update rule as ONE HIP launch over the
+network's flat parameter buffer instead of ~700 per-tensor kernels.  state_dict()/load_state_dict()
+use torch.optim.Adam's layout ('step', 'exp_avg', 'exp_avg_sq' per parameter) so `.state` files
+written by either engine resume in the other (base_model.py:454-500).
+"""
+import logging
+import math
+
+import torch
+
+from .. import ops
+
+logger = logging.getLogger("base")
+
+
+def get_optim_params(networks, only_requires_grad=True, param_filter=None):
+    if isinstance(networks, torch.nn.Module):
+        networks = [networks]
+    if param_filter:
+        raise NotImplementedError("parameter filters are not implemented by the HIP engine")
+    params = []
+    for net in networks:
+        params += [p for p in net.parameters() if p.requires_grad or not only_requires_grad]
+    return params, []
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._moments = {}     # id(FlatParams) -> (exp_avg_flat, exp_avg_sq_flat)
+
+    def _holders(self, group):
+        """The distinct flat buffers the group's parameters live in (insertion ordered)."""
+        holders = {}
+        for p in group["params"]:
+            h = getattr(p, "_tnr_flat", None)
+            if h is None:
+                raise RuntimeError("FusedAdam: parameter is not part of a HIP-engine network (no flat storage)")
+            holders.setdefault(id(h[0]), h[0])
+        return list(holders.values())
+
+    def _ensure_state(self, group):
+        for holder in self._holders(group):
+            holder.ensure()
+            key = id(holder)
+            mv = self._moments.get(key)
+            if mv is None or mv[0].numel() != holder.total or mv[0].device != holder.flat.device:
+                mv = (torch.zeros_like(holder.flat), torch.zeros_like(holder.flat))
+                self._moments[key] = mv
+                for p in group["params"]:
+                    if p._tnr_flat[0] is not holder:
+                        continue
+                    st = self.state[p]
+                    o, n = p._tnr_flat[1], p.numel()
+                    old_m, old_v = st.get("exp_avg"), st.get("exp_avg_sq")
+                    st["exp_avg"] = mv[0][o:o + n].view(p.shape)
+                    st["exp_avg_sq"] = mv[1][o:o + n].view(p.shape)
+                    if old_m is not None:          # state arrived through load_state_dict
+                        st["exp_avg"].copy_(old_m)
+                        st["exp_avg_sq"].copy_(old_v)
+                    if "step" not in st:
+                        st["step"] = torch.tensor(0.0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        for group in self.param_groups:
+            self._ensure_state(group)
+            b1, b2 = group["betas"]
+            t = int(float(self.state[group["params"][0]]["step"])) + 1   # one counter per group
+            bc1 = 1.0 - b1 ** t
+            bc2 = 1.0 - b2 ** t
+            for holder in self._holders(group):
+                m, v = self._moments[id(holder)]
+                ops.adam_step(holder.flat, holder.grad, m, v, group["lr"] / bc1, b1, b2, math.sqrt(bc2), group["eps"],
+                              group["weight_decay"])
+            shared = torch.tensor(float(t))
+            for p in group["params"]:
+                self.state[p]["step"] = shared
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the flat gradient buffers in place (views stay attached to the parameters)."""
+        for group in self.param_groups:
+            for holder in self._holders(group):
+                holder.ensure()
+                ops.fill(holder.grad, 0.0)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._moments = {}       # re-home the loaded moments into flat buffers on next use
+        for group in self.param_groups:
+            self._ensure_state(group)
+
+
+def config_optimizer(train_opt, name, net=None, optim_params=None):
+    if name not in ("G", "D"):
+        raise NotImplementedError("Invalid optimizer name: {}".format(name))
+    if not optim_params:
+        optim_params, _ = get_optim_params(net, True)
+    optim = train_opt.get("optim_" + name, "adam") or "adam"
+    lr = train_opt.get("lr_" + name, 1e-4) or 1e-4
+    wd = train_opt.get("weight_decay_" + name, 0) or 0
+    beta1 = train_opt.get("beta1_" + name, 0.9) or 0.9
+    beta2 = train_opt.get("beta2_" + name, 0.999) or 0.999
+    if optim != "adam":
+        raise NotImplementedError("optimizer [{}] is outside the SR hot path of the HIP engine".format(optim))
+    return FusedAdam(optim_params, lr=lr, weight_decay=wd, betas=(beta1, beta2))

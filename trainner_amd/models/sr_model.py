@@ -1,0 +1,123 @@
+"""SRModel on the MI355X engine -- the drop-in for codes/models/sr_model.py.
+
+Same constructor sequence (:22-113), `feed_data` (:115-128), `forward` (:134-160), `backward_G`
+(:162-188), `backward_D` (:190-193), **`optimize_parameters`** (:195-267), `test` (:269-277) and
+visuals/log accessors (:352-372), so codes/train.py drives it unchanged.  netG / netD / netF are the
+HIP-engine networks (single autograd node each), the losses are HIP kernels, clip+Adam are fused over
+flat buffers and gradients are exchanged with RCCL when WORLD_SIZE > 1.
+"""
+import logging
+from collections import OrderedDict
+
+import torch
+
+from . import losses, networks
+from .base_model import BaseModel, LazyLog
+
+logger = logging.getLogger("base")
+
+
+class SRModel(BaseModel):
+    def __init__(self, opt, step=0):
+        super().__init__(opt)
+        train_opt = opt["train"]
+        self.model_names = ["G"]
+        self.netG = networks.define_G(opt, step=step).to(self.device)
+        if self.is_train:
+            self.netG.train()
+            opt_G_nets, opt_D_nets = [self.netG], []
+            if train_opt["gan_weight"]:
+                self.model_names.append("D")
+                self.netD = networks.define_D(opt).to(self.device)
+                self.netD.train()
+                opt_D_nets.append(self.netD)
+            self.setup_atg()
+        self.load()
+        self.outm = None
+        if self.is_train:
+            self.outm = train_opt.get("finalcap", None)
+            self.setup_batchaug()
+            self.setup_fs()
+            self.generatorlosses = losses.GeneratorLoss(opt, self.device)
+            self.setup_gan()
+            if self.cri_gan:
+                self.setup_freezeD()
+            self.setup_optimizers(opt_G_nets, opt_D_nets, init_setup=True)
+            self.setup_schedulers()
+            self.optimizer_G.zero_grad()
+            if self.cri_gan:
+                self.optimizer_D.zero_grad()
+            self.log_dict = LazyLog()
+            self.setup_swa()
+            self.setup_virtual_batch()
+            self.setup_amp()
+            self.setup_cem()
+            self.setup_unshuffle()
+            self.setup_gradclip(opt_G_nets)
+        self.print_network(verbose=False)
+
+    def feed_data(self, data, need_HR=True):
+        self.var_L = data["LR"].to(self.device, non_blocking=True)
+        if need_HR:
+            self.real_H = data["HR"].to(self.device, non_blocking=True)
+            self.var_ref = data.get("ref", data["HR"]).to(self.device, non_blocking=True)
+
+    def forward(self, data=None, CEM_net=None):
+        if isinstance(data, torch.Tensor):
+            return self.netG(data)
+        self.fake_H = self.netG(self.var_L, outm=self.outm) if self.outm else self.netG(self.var_L)
+
+    def backward_G(self):
+        loss_results, self.log_dict = self.generatorlosses(self.fake_H, self.real_H, self.log_dict, self.f_low)
+        l_g_total = sum(loss_results)
+        if self.accumulations != 1:
+            l_g_total = l_g_total / self.accumulations
+        if self.cri_gan:
+            l_g_gan = self.adversarial(self.fake_H, self.var_ref, netD=self.netD, stage="generator", fsfilter=self.f_high)
+            self.log_dict["l_g_gan"] = l_g_gan.detach()
+            l_g_total = l_g_total + (l_g_gan if self.accumulations == 1 else l_g_gan / self.accumulations)
+        self.calc_gradients(l_g_total)
+
+    def backward_D(self):
+        self.log_dict = self.backward_D_Basic(self.netD, self.var_ref, self.fake_H, self.log_dict)
+
+    def optimize_parameters(self, step):
+        eff_step = step / self.accumulations
+        if self.cri_gan:
+            self.requires_grad(self.netD, flag=False, net_type="D")
+        self.forward()
+        if (self.cri_gan is not True) or (eff_step % self.D_update_ratio == 0 and eff_step > self.D_init_iters):
+            self.backward_G()
+            self.optimizer_step(step, self.optimizer_G, "G")
+        if self.cri_gan:
+            self.requires_grad(self.netD, flag=True)
+            if isinstance(self.feature_loc, int):
+                for loc in range(self.feature_loc):
+                    self.requires_grad(self.netD, False, target_layer=loc, net_type="D")
+            self.backward_D()
+            self.optimizer_step(step, self.optimizer_D, "D")
+
+    def test(self, CEM_net=None):
+        self.netG.eval()
+        with torch.no_grad():
+            self.forward()
+        self.netG.train()
+
+    def get_current_log(self):
+        return self.log_dict.materialize()
+
+    def get_current_visuals(self, need_HR=True):
+        out = OrderedDict()
+        out["LR"] = self.var_L.detach()[0].float().cpu()
+        out["SR"] = self.fake_H.detach()[0].float().cpu()
+        if need_HR:
+            out["HR"] = self.real_H.detach()[0].float().cpu()
+        return out
+
+    def get_current_visuals_batch(self, need_HR=True):
+        out = OrderedDict()
+        out["LR"] = self.var_L.detach().float().cpu()
+        out["SR"] = self.fake_H.detach().float().cpu()
+        if need_HR:
+            out["HR"] = self.real_H.detach().float().cpu()
+        return out

@@ -1,0 +1,356 @@
+"""Thin Python wrappers over the C ABI: NHWC views, packed weights, per-device workspaces.
+
+Nothing here computes with torch; torch only allocates the buffers the kernels read and write.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
+                  PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView, ConvDesc, PackItem, WgradDesc)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class View:
+    """Channels [coff, coff+C) of an fp32 NHWC buffer [N,H,W,Ctot]."""
+    __slots__ = ("buf", "coff", "C")
+
+    def __init__(self, buf, coff=0, C=None):
+        assert buf.dim() == 4 and buf.dtype == torch.float32 and buf.is_contiguous()
+        self.buf, self.coff = buf, coff
+        self.C = buf.shape[3] - coff if C is None else C
+        assert 0 <= coff and coff + self.C <= buf.shape[3]
+
+    N = property(lambda s: s.buf.shape[0])
+    H = property(lambda s: s.buf.shape[1])
+    W = property(lambda s: s.buf.shape[2])
+    ctot = property(lambda s: s.buf.shape[3])
+    pixels = property(lambda s: s.buf.shape[0] * s.buf.shape[1] * s.buf.shape[2])
+
+    def sub(self, off, C):
+        return View(self.buf, self.coff + off, C)
+
+    def c(self):
+        return CView(self.buf.data_ptr(), self.buf.shape[3], self.coff)
+
+    def dense(self):
+        """torch view [N,H,W,C] of this window (debug / tests only)."""
+        return self.buf[..., self.coff:self.coff + self.C]
+
+
+def new_act(N, H, W, C, device):
+    """Uninitialised NHWC activation buffer."""
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=device)
+
+
+def cv(v):
+    return hip.NULLVIEW if v is None else v.c()
+
+
+# ----------------------------------------------------------------------------------------------
+# workspaces (per device, grown on demand; all kernels of one engine run on one stream)
+# ----------------------------------------------------------------------------------------------
+class _Workspaces:
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, nbytes, device):
+        key = (name, str(device))
+        t = self.bufs.get(key)
+        if t is None or t.numel() * 8 < nbytes:
+            n = max(int(nbytes * 1.25) // 8 + 1, 1024)
+            t = torch.empty(n, dtype=torch.float64, device=device)
+            self.bufs[key] = t
+        return t
+
+
+WS = _Workspaces()
+
+
+# ----------------------------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------------------------
+class Packed:
+    __slots__ = ("t", "KoutP", "KinP", "kind")
+
+    def __init__(self, t, KoutP, KinP, kind):
+        self.t, self.KoutP, self.KinP, self.kind = t, KoutP, KinP, kind
+
+
+def pack_dims(Cout, Cin, kh, kw, kind):
+    lib = hip.load()
+    ko, ki, n = hip.c_i(), hip.c_i(), hip.c_l()
+    hip.check(lib.tnr_pack_dims(Cout, Cin, kh, kw, kind, C.byref(ko), C.byref(ki), C.byref(n)), "pack_dims")
+    return ko.value, ki.value, n.value
+
+
+class WeightPacker:
+    """One device table of pack jobs for a whole network; `run()` re-lays out every weight with a
+    single launch (weights change every optimiser step)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []          # (weight tensor, kind)
+        self.packed = []
+        self.table = None
+        self.max_out = 0
+        self.flat = None
+
+    def add(self, w, kind):
+        Cout, Cin, kh, kw = w.shape
+        ko, ki, n = pack_dims(Cout, Cin, kh, kw, kind)
+        self.jobs.append((w, kind, ko, ki, n))
+        self.packed.append(None)
+        self.table = None
+        return len(self.jobs) - 1
+
+    def _finalize(self):
+        total = sum(round_up(j[4], 64) for j in self.jobs)
+        self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        items = (PackItem * len(self.jobs))()
+        off = 0
+        for i, (w, kind, ko, ki, n) in enumerate(self.jobs):
+            seg = self.flat[off:off + n]
+            off += round_up(n, 64)
+            Cout, Cin, kh, kw = w.shape
+            items[i] = PackItem(w.data_ptr(), seg.data_ptr(), Cout, Cin, kh, kw, kind, ko, ki, n)
+            self.packed[i] = Packed(seg, ko, ki, kind)
+            self.max_out = max(self.max_out, n)
+        raw = bytes(items)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._ptrs = [j[0].data_ptr() for j in self.jobs]
+
+    def get(self, idx):
+        if self.table is None:
+            self._finalize()
+        return self.packed[idx]
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self.table is None or any(j[0].data_ptr() != p for j, p in zip(self.jobs, self._ptrs)):
+            self._finalize()
+        hip.check(hip.load().tnr_pack_weights(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
+                  "pack_weights")
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+class ConvProfile:
+    """Optional per-launch HIP-event timing of the implicit-GEMM kernels (bench.py's roofline leg).
+    Events are recorded on the launch stream around every launch; nothing is synchronised until
+    `summary()`."""
+
+    def __init__(self):
+        self.records = []      # (family, flops, start_event, end_event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, family, flops, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.append((family, flops, start, ev))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, a, b in self.records:
+            d = out.setdefault(fam, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += a.elapsed_time(b)
+        return out
+
+
+PROFILE = None      # set to a ConvProfile() to time launches
+
+
+def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
+         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
+    d = ConvDesc()
+    d.x = x.c()
+    d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
+    d.wp, d.KinP, d.KoutP = wp.t.data_ptr(), wp.KinP, wp.KoutP
+    d.y = y.c()
+    d.Ho, d.Wo, d.Cout = y.H, y.W, y.C
+    d.mode = mode
+    d.bias = hip.ptr(bias)
+    d.act, d.slope, d.alpha = act, slope, alpha
+    d.r1 = cv(r1)
+    d.r1_ch = (r1.C if r1_ch is None else r1_ch) if r1 is not None else 0
+    d.beta1 = beta1
+    d.r2 = cv(r2)
+    d.alpha2 = alpha2
+    d.m = cv(mask)
+    d.m_lo = m_lo
+    d.m_hi = (y.C if m_hi is None else m_hi)
+    d.m_slope = m_slope
+    if PROFILE is None:
+        hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
+        return
+    t0 = PROFILE.begin()
+    hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
+    taps = 9 if mode in (CONV_3x3, CONV_3x3_UP2) else 16
+    opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
+    fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
+           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2"}[mode]
+    PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0)
+
+
+def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
+    """dw (OIHW, full tensor) += alpha * sum g (x) x over input channels [cin_begin, cin_begin+x.C)."""
+    lib = hip.load()
+    d = WgradDesc()
+    d.x = x.c()
+    d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
+    d.g = g.c()
+    d.Ho, d.Wo, d.Cout = g.H, g.W, g.C
+    d.mode = mode
+    d.dw, d.cin_total, d.cin_begin = dw.data_ptr(), dw.shape[1], cin_begin
+    d.db = hip.ptr(db)
+    d.alpha, d.beta = alpha, beta
+    need = lib.tnr_wgrad_workspace_bytes(C.byref(d))
+    ws = WS.get("wgrad", need, x.buf.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
+    if PROFILE is None:
+        hip.check(lib.tnr_conv_wgrad(C.byref(d), hip.stream()), "conv_wgrad")
+        return
+    t0 = PROFILE.begin()
+    hip.check(lib.tnr_conv_wgrad(C.byref(d), hip.stream()), "conv_wgrad")
+    taps = 16 if mode == CONV_4x4_S2 else 9
+    PROFILE.end("wgrad_tile", 2.0 * g.pixels * taps * x.C * g.C, t0)
+
+
+# ----------------------------------------------------------------------------------------------
+# layout / resampling / elementwise
+# ----------------------------------------------------------------------------------------------
+def nchw_to_nhwc(src, dst, Cpad=None, scale=None, shift=None):
+    N, Cc, H, W = src.shape
+    assert src.is_contiguous() and src.dtype == torch.float32
+    hip.check(hip.load().tnr_nchw_to_nhwc(src.data_ptr(), N, Cc, H, W, dst.c(), dst.C if Cpad is None else Cpad,
+                                          hip.ptr(scale), hip.ptr(shift), hip.stream()), "nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, dst, scale=None, accumulate=False):
+    N, Cc, H, W = dst.shape
+    assert dst.is_contiguous() and dst.dtype == torch.float32
+    hip.check(hip.load().tnr_nhwc_to_nchw(src.c(), N, Cc, H, W, dst.data_ptr(), hip.ptr(scale), int(accumulate),
+                                          hip.stream()), "nhwc_to_nchw")
+
+
+def upsample2x_bwd(gup, gx, mask=None, mslope=0.2):
+    hip.check(hip.load().tnr_upsample2x_bwd(gup.c(), gx.c(), gx.N, gx.H, gx.W, gx.C, cv(mask), mslope, hip.stream()),
+              "upsample2x_bwd")
+
+
+def depth_to_space(x, y):
+    hip.check(hip.load().tnr_depth_to_space(x.c(), y.c(), x.N, x.H, x.W, y.C, hip.stream()), "depth_to_space")
+
+
+def space_to_depth_bwd(gy, gx, mask=None, mslope=0.2):
+    hip.check(hip.load().tnr_space_to_depth_bwd(gy.c(), gx.c(), gx.N, gx.H, gx.W, gy.C, cv(mask), mslope, hip.stream()),
+              "space_to_depth_bwd")
+
+
+def maxpool2_fwd(x, y):
+    hip.check(hip.load().tnr_maxpool2_fwd(x.c(), y.c(), x.N, x.H, x.W, x.C, hip.stream()), "maxpool2_fwd")
+
+
+def maxpool2_bwd(gy, x, gx):
+    hip.check(hip.load().tnr_maxpool2_bwd(gy.c(), x.c(), gx.c(), x.N, x.H, x.W, x.C, hip.stream()), "maxpool2_bwd")
+
+
+def axpby(dst, src, a=1.0, b=1.0):
+    """dst = a*src + b*dst"""
+    hip.check(hip.load().tnr_axpby(dst.c(), src.c(), dst.pixels, dst.C, a, b, hip.stream()), "axpby")
+
+
+def mask_mul(g, y, mslope=0.2):
+    hip.check(hip.load().tnr_mask_mul(g.c(), y.c(), g.pixels, g.C, mslope, hip.stream()), "mask_mul")
+
+
+def fill(t, value=0.0):
+    hip.check(hip.load().tnr_fill(t.data_ptr(), t.numel(), value, hip.stream()), "fill")
+
+
+# ----------------------------------------------------------------------------------------------
+# batch norm / linear
+# ----------------------------------------------------------------------------------------------
+def bn_train_fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save_mean, save_invstd,
+                 momentum=0.1, eps=1e-5, act=ACT_LRELU, slope=0.2):
+    lib = hip.load()
+    ws = WS.get("bn", lib.tnr_bn_workspace_bytes(z.C), z.buf.device)
+    hip.check(lib.tnr_bn_train_fwd(z.c(), y.c(), z.pixels, z.C, gamma.data_ptr(), beta.data_ptr(),
+                                   hip.ptr(running_mean), hip.ptr(running_var), hip.ptr(num_batches), momentum, eps,
+                                   save_mean.data_ptr(), save_invstd.data_ptr(), act, slope, ws.data_ptr(),
+                                   hip.stream()), "bn_train_fwd")
+
+
+def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2):
+    lib = hip.load()
+    ws = WS.get("bn", lib.tnr_bn_workspace_bytes(z.C), z.buf.device)
+    hip.check(lib.tnr_bn_train_bwd(gy.c(), y.c(), z.c(), gz.c(), z.pixels, z.C, gamma.data_ptr(),
+                                   save_mean.data_ptr(), save_invstd.data_ptr(), mslope, hip.ptr(dgamma),
+                                   hip.ptr(dbeta), acc_beta, ws.data_ptr(), hip.stream()), "bn_train_bwd")
+
+
+def linear_fwd(x, w, b, y, act=ACT_NONE, slope=0.2):
+    N, In = x.shape
+    Out = w.shape[0]
+    hip.check(hip.load().tnr_linear_fwd(x.data_ptr(), w.data_ptr(), hip.ptr(b), y.data_ptr(), N, In, Out, act, slope,
+                                        hip.stream()), "linear_fwd")
+
+
+def linear_bwd(x, w, gy, yact=None, gx=None, dw=None, db=None, acc_beta=1.0, mslope=0.2):
+    N, In = x.shape
+    Out = w.shape[0]
+    gpre = WS.get("lin", N * Out * 4, x.device)
+    hip.check(hip.load().tnr_linear_bwd(x.data_ptr(), w.data_ptr(), gy.data_ptr(), hip.ptr(yact), mslope, hip.ptr(gx),
+                                        hip.ptr(dw), hip.ptr(db), N, In, Out, acc_beta, gpre.data_ptr(), hip.stream()),
+              "linear_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# losses / optimiser
+# ----------------------------------------------------------------------------------------------
+def _red_ws(device):
+    lib = hip.load()
+    return WS.get("red", lib.tnr_reduce_workspace_bytes(), device)
+
+
+def l1_mean_fwd(a, b, scale, out):
+    hip.check(hip.load().tnr_l1_mean_fwd(a.data_ptr(), b.data_ptr(), a.numel(), scale, out.data_ptr(),
+                                         _red_ws(a.device).data_ptr(), hip.stream()), "l1_mean_fwd")
+
+
+def l1_mean_bwd(a, b, scale, gscale, ga, accumulate=False):
+    hip.check(hip.load().tnr_l1_mean_bwd(a.data_ptr(), b.data_ptr(), a.numel(), scale, hip.ptr(gscale), ga.data_ptr(),
+                                         int(accumulate), hip.stream()), "l1_mean_bwd")
+
+
+def scale_by(dst, src, gscale):
+    hip.check(hip.load().tnr_scale_by(dst.data_ptr(), src.data_ptr(), src.numel(), gscale.data_ptr(), hip.stream()),
+              "scale_by")
+
+
+def sumsq(g, out):
+    hip.check(hip.load().tnr_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _red_ws(g.device).data_ptr(), hip.stream()),
+              "sumsq")
+
+
+def clip_by_norm(g, sumsq_t, max_norm):
+    hip.check(hip.load().tnr_clip_by_norm(g.data_ptr(), g.numel(), sumsq_t.data_ptr(), max_norm, hip.stream()),
+              "clip_by_norm")
+
+
+def adam_step(p, g, m, v, step_size, b1, b2, bc2_sqrt, eps, wd=0.0):
+    hip.check(hip.load().tnr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), step_size, b1,
+                                       b2, bc2_sqrt, eps, wd, hip.stream()), "adam_step")
