@@ -89,8 +89,8 @@ def state_error(sd, probes, skip=(), lr_steps=1e-4):
     mean tightly and the worst loosely."""
     worst, worst_k, tot, cnt = 0.0, None, 0.0, 0
     for k, pr in probes.items():
-        if k in skip or k.endswith("num_batches_tracked"):
-            continue
+        if k in skip or k.endswith("num_batches_tracked") or ".running_" in k:
+            continue      # buffers are not Adam-driven: see buffers_error
         f = sd[k].detach().flatten().to(torch.float64).cpu()
         s_ = f[::pr["stride"]][:pr["samples"].numel()]
         d = (s_ - pr["samples"]).abs() / lr_steps

@@ -1,0 +1,288 @@
+"""TEST INFRASTRUCTURE ONLY: a torch-CPU stand-in for `trainner_amd.ops`, installed by monkeypatch.
+
+It re-states the *contract* of every C-ABI op (views, epilogues, accumulation semantics) with stock
+torch functions so that the HOST logic -- the hand-written forward/backward kernel schedules of the
+networks, the autograd bridge, flat parameters, fused clip/Adam plumbing, the SRModel step -- can be
+exercised and checked against the reference-generated goldens on a machine without a GPU
+(`-m "not gpu"`).  The product never imports this module; on a GPU box the `-m gpu` tests run the
+same schedules through libtrainner_hip.so.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from trainner_amd import hip, ops
+
+
+class _Packed:
+    def __init__(self, w, kind):
+        self.w, self.kind = w, kind
+        self.KinP = self.KoutP = 0
+        self.t = w
+
+
+class EmulPacker:
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+
+    def add(self, w, kind):
+        self.jobs.append(_Packed(w, kind))
+        return len(self.jobs) - 1
+
+    def get(self, idx):
+        return self.jobs[idx]
+
+    def run(self):
+        pass
+
+
+def _nchw(v):
+    return v.dense().permute(0, 3, 1, 2)
+
+
+def _fit(t, C):
+    """slice / zero-pad channel dim of an NCHW tensor to C channels."""
+    if t.shape[1] >= C:
+        return t[:, :C]
+    return F.pad(t, (0, 0, 0, 0, 0, C - t.shape[1]))
+
+
+def _mask(m, slope):
+    return torch.where(m > 0, torch.ones_like(m), torch.full_like(m, slope))
+
+
+def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
+         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
+    w = wp.w.detach()
+    xin = _nchw(x)
+    if wp.kind == ops.PACK_FWD:
+        xi = _fit(xin, w.shape[1])
+        if mode == ops.CONV_3x3_UP2:
+            xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+        out = F.conv2d(xi, w, None, padding=1)
+    elif wp.kind == ops.PACK_FWD_S2D:
+        out = F.conv2d(_fit(xin, w.shape[1]), w, None, stride=2, padding=1)
+    elif wp.kind == ops.PACK_DGRAD_3x3:
+        out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, padding=1)
+    else:
+        out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, stride=2, padding=1)
+    out = _fit(out, y.C)
+    if bias is not None:
+        out = out + _fit(bias.detach().view(1, -1, 1, 1), y.C)
+    if act == ops.ACT_LRELU:
+        out = F.leaky_relu(out, slope)
+    elif act == ops.ACT_RELU:
+        out = F.relu(out)
+    out = out * alpha
+    if r1 is not None:
+        ch = r1.C if r1_ch is None else r1_ch
+        out = torch.cat([out[:, :ch] + beta1 * _nchw(r1)[:, :ch], out[:, ch:]], 1)
+    if r2 is not None:
+        out = out * alpha2 + _nchw(r2)[:, :y.C]
+    if mask is not None:
+        hi = y.C if m_hi is None else m_hi
+        mm = _mask(_nchw(mask)[:, m_lo:hi], m_slope)
+        out = torch.cat([out[:, :m_lo], out[:, m_lo:hi] * mm, out[:, hi:]], 1)
+    y.dense().copy_(out.permute(0, 2, 3, 1))
+
+
+def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
+    k = 4 if mode == ops.CONV_4x4_S2 else 3
+    xin, gin = _nchw(x), _nchw(g)
+    with torch.enable_grad():
+        w0 = torch.zeros(g.C, x.C, k, k, requires_grad=True)
+        if mode == ops.CONV_3x3_UP2:
+            out = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), w0, None, padding=1)
+        elif mode == ops.CONV_4x4_S2:
+            out = F.conv2d(xin, w0, None, stride=2, padding=1)
+        else:
+            out = F.conv2d(xin, w0, None, padding=1)
+        (gw,) = torch.autograd.grad(out, w0, gin)
+    tgt = dw[:, cin_begin:cin_begin + x.C]
+    tgt.copy_(beta * tgt + alpha * gw)
+    if db is not None:
+        db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
+
+
+def nchw_to_nhwc(src, dst, Cpad=None, scale=None, shift=None):
+    t = src
+    if scale is not None:
+        t = t * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    Cpad = dst.C if Cpad is None else Cpad
+    View = ops.View
+    View(dst.buf, dst.coff, Cpad).dense().copy_(_fit(t, Cpad).permute(0, 2, 3, 1))
+
+
+def nhwc_to_nchw(src, dst, scale=None, accumulate=False):
+    t = _nchw(src)[:, :dst.shape[1]]
+    if scale is not None:
+        t = t * scale.view(1, -1, 1, 1)
+    if accumulate:
+        dst.add_(t)
+    else:
+        dst.copy_(t)
+
+
+def upsample2x_bwd(gup, gx, mask=None, mslope=0.2):
+    t = F.avg_pool2d(_nchw(gup), 2) * 4
+    if mask is not None:
+        t = t * _mask(_nchw(mask), mslope)
+    gx.dense().copy_(t.permute(0, 2, 3, 1))
+
+
+def depth_to_space(x, y):
+    y.dense().copy_(F.pixel_shuffle(_nchw(x), 2).permute(0, 2, 3, 1))
+
+
+def space_to_depth_bwd(gy, gx, mask=None, mslope=0.2):
+    t = _nchw(gy)
+    if mask is not None:
+        t = t * _mask(_nchw(mask), mslope)
+    gx.dense().copy_(F.pixel_unshuffle(t, 2).permute(0, 2, 3, 1))
+
+
+def maxpool2_fwd(x, y):
+    y.dense().copy_(F.max_pool2d(_nchw(x), 2, 2).permute(0, 2, 3, 1))
+
+
+def maxpool2_bwd(gy, x, gx):
+    with torch.enable_grad():
+        xin = _nchw(x).clone().requires_grad_(True)
+        (g,) = torch.autograd.grad(F.max_pool2d(xin, 2, 2), xin, _nchw(gy))
+    gx.dense().copy_((g * (xin.detach() > 0)).permute(0, 2, 3, 1))
+
+
+def axpby(dst, src, a=1.0, b=1.0):
+    d = dst.dense()
+    d.copy_(a * src.dense() + (b * d if b != 0 else 0))
+
+
+def mask_mul(g, y, mslope=0.2):
+    g.dense().mul_(_mask(y.dense(), mslope))
+
+
+def fill(t, value=0.0):
+    t.fill_(value)
+
+
+def bn_train_fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save_mean, save_invstd, momentum=0.1,
+                 eps=1e-5, act=ops.ACT_LRELU, slope=0.2):
+    zin = _nchw(z)
+    mean = zin.mean(dim=(0, 2, 3))
+    var = zin.var(dim=(0, 2, 3), unbiased=False)
+    save_mean.copy_(mean)
+    save_invstd.copy_(1.0 / torch.sqrt(var + eps))
+    out = F.batch_norm(zin, running_mean, running_var, gamma.detach(), beta.detach(), True, momentum, eps)
+    if num_batches is not None:
+        num_batches += 1
+    out = F.leaky_relu(out, slope) if act == ops.ACT_LRELU else (F.relu(out) if act == ops.ACT_RELU else out)
+    y.dense().copy_(out.permute(0, 2, 3, 1))
+
+
+def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2):
+    g = _nchw(gy) * _mask(_nchw(y), mslope)
+    zin = _nchw(z)
+    n = zin.numel() / zin.shape[1]
+    xm = zin - save_mean.view(1, -1, 1, 1)
+    s, dot = g.sum(dim=(0, 2, 3)), (g * xm).sum(dim=(0, 2, 3))
+    inv = save_invstd
+    k = (dot * inv * inv / n).view(1, -1, 1, 1)
+    dz = (g - (s / n).view(1, -1, 1, 1) - xm * k) * (inv * gamma.detach()).view(1, -1, 1, 1)
+    gz.dense().copy_(dz.permute(0, 2, 3, 1))
+    if dgamma is not None:
+        dgamma.copy_(acc_beta * dgamma + dot * inv)
+        dbeta.copy_(acc_beta * dbeta + s)
+
+
+def linear_fwd(x, w, b, y, act=ops.ACT_NONE, slope=0.2):
+    o = F.linear(x, w.detach(), None if b is None else b.detach())
+    y.copy_(F.leaky_relu(o, slope) if act == ops.ACT_LRELU else o)
+
+
+def linear_bwd(x, w, gy, yact=None, gx=None, dw=None, db=None, acc_beta=1.0, mslope=0.2):
+    gpre = gy if yact is None else gy * _mask(yact, mslope)
+    if dw is not None:
+        dw.copy_(acc_beta * dw + gpre.t() @ x)
+    if db is not None:
+        db.copy_(acc_beta * db + gpre.sum(0))
+    if gx is not None:
+        gx.copy_(gpre @ w.detach())
+
+
+def l1_mean_fwd(a, b, scale, out):
+    out.copy_(scale * (a.detach() - b).abs().mean())
+
+
+def l1_mean_bwd(a, b, scale, gscale, ga, accumulate=False):
+    g = torch.sign(a.detach() - b) * (scale * (1.0 if gscale is None else float(gscale.reshape(-1)[0])) / a.numel())
+    if accumulate:
+        ga.add_(g)
+    else:
+        ga.copy_(g)
+
+
+def ragan_phase_a(pf, pr, sums):
+    sums.zero_()
+    sums[0], sums[1], sums[2] = pf.sum(), pr.sum(), float(pf.numel())
+
+
+def ragan_phase_b(pf, pr, stage, sums):
+    mf, mr = sums[0] / sums[2], sums[1] / sums[2]
+    dr, df = pr - mf, pf - mr
+    if stage == 0:
+        sums[3], sums[4], sums[5], sums[6] = F.softplus(dr).sum(), F.softplus(-df).sum(), torch.sigmoid(dr).sum(), 0.0
+    else:
+        sums[3], sums[4] = F.softplus(-dr).sum(), F.softplus(df).sum()
+        sums[5], sums[6] = torch.sigmoid(-dr).sum(), torch.sigmoid(df).sum()
+
+
+def ragan_phase_c(pf, pr, stage, weight, sums, out, gf, gr):
+    NN = sums[2]
+    mf, mr = sums[0] / NN, sums[1] / NN
+    l1, l2 = sums[3] / NN, sums[4] / NN
+    out[0], out[1], out[2], out[3], out[4] = weight * (l1 + l2) * 0.5, l1, l2, mr, mf
+    k = weight * 0.5 / NN
+    dr, df = pr - mf, pf - mr
+    if stage == 0:
+        gf.copy_(k * (-(sums[5] / NN) - torch.sigmoid(-df)))
+        gr.zero_()
+    else:
+        gf.copy_(k * (torch.sigmoid(df) + sums[5] / NN))
+        gr.copy_(k * (-torch.sigmoid(-dr) - sums[6] / NN))
+
+
+def scale_by(dst, src, gscale):
+    dst.copy_(src * gscale.reshape(-1)[0])
+
+
+def sumsq(g, out):
+    out.copy_((g.double() ** 2).sum().reshape(1))
+
+
+def clip_by_norm(g, sumsq_t, max_norm):
+    coef = min(1.0, max_norm / (math.sqrt(float(sumsq_t[0])) + 1e-6))
+    g.mul_(coef)
+
+
+def adam_step(p, g, m, v, step_size, b1, b2, bc2_sqrt, eps, wd=0.0):
+    gr = g + wd * p if wd else g
+    m.lerp_(gr, 1 - b1)
+    v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+    p.addcdiv_(m, v.sqrt() / bc2_sqrt + eps, value=-step_size)
+
+
+_NAMES = ["conv", "wgrad", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+          "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
+          "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
+          "sumsq", "clip_by_norm", "adam_step"]
+
+
+def install(monkeypatch):
+    g = globals()
+    for n in _NAMES:
+        monkeypatch.setattr(ops, n, g[n])
+    monkeypatch.setattr(ops, "WeightPacker", EmulPacker)
+    monkeypatch.setattr(hip, "require_device", lambda t=None: None)
+    monkeypatch.setattr(hip, "engine_device", lambda index=0: torch.device("cpu"))

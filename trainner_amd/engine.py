@@ -46,8 +46,9 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, *params):
-        need_param_grad = any(p.requires_grad for p in params)
-        need_graph = torch.is_grad_enabled() and (x.requires_grad or need_param_grad)
+        # (grad mode is always off inside Function.forward; needs_input_grad already accounts for it)
+        need_param_grad = any(ctx.needs_input_grad[2:])
+        need_graph = ctx.needs_input_grad[1] or need_param_grad
         out, saved = net.engine_forward(x, save=need_graph)
         ctx.net, ctx.saved, ctx.need_param_grad = net, saved, need_param_grad
         return out

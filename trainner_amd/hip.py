@@ -129,6 +129,11 @@ def require_device(t=None):
         raise HipEngineError("tensor is not on a HIP device")
 
 
+def engine_device(index=0):
+    require_device()
+    return torch.device("cuda", index)
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -43,9 +43,10 @@ class BaseModel:
         self.opt = opt
         if opt["gpu_ids"]:
             hip.require_device()
-            local = int(os.environ.get("LOCAL_RANK", "0")) if "LOCAL_RANK" in os.environ else torch.cuda.current_device()
-            self.device = torch.device("cuda", local)
-            torch.cuda.set_device(self.device)
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            self.device = hip.engine_device(local)
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
         else:
             # the reference falls back to CPU here (base_model.py:80-81); this engine has no CPU path
             raise hip.HipEngineError("gpu_ids is empty: the trainner_amd engine runs only on MI355X "

@@ -64,22 +64,18 @@ class _RaGANFn(torch.autograd.Function):
     def forward(ctx, pred_fake, pred_real, stage, weight, group):
         hip.require_device(pred_fake)
         pf, pr = pred_fake.contiguous().view(-1), pred_real.contiguous().view(-1)
-        n = pf.numel()
-        lib = hip.load()
         dev = pf.device
         sums = torch.empty(8, dtype=torch.float32, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         gf = torch.empty_like(pf)
         gr = torch.empty_like(pr)
-        s = hip.stream()
-        hip.check(lib.tnr_ragan_phase_a(pf.data_ptr(), pr.data_ptr(), n, sums.data_ptr(), s), "ragan_a")
+        ops.ragan_phase_a(pf, pr, sums)
         if group is not None:
             group.all_reduce_sum(sums[0:3])
-        hip.check(lib.tnr_ragan_phase_b(pf.data_ptr(), pr.data_ptr(), n, stage, sums.data_ptr(), s), "ragan_b")
+        ops.ragan_phase_b(pf, pr, stage, sums)
         if group is not None:
             group.all_reduce_sum(sums[3:7])
-        hip.check(lib.tnr_ragan_phase_c(pf.data_ptr(), pr.data_ptr(), n, stage, float(weight), sums.data_ptr(),
-                                        out.data_ptr(), gf.data_ptr(), gr.data_ptr(), s), "ragan_c")
+        ops.ragan_phase_c(pf, pr, stage, weight, sums, out, gf, gr)
         ctx.save_for_backward(gf, gr)
         ctx.shapes = (pred_fake.shape, pred_real.shape)
         ctx.world = 1 if group is None else group.world_size

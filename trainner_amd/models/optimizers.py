@@ -100,6 +100,9 @@ class FusedAdam(torch.optim.Optimizer):
 def config_optimizer(train_opt, name, net=None, optim_params=None):
     if name not in ("G", "D"):
         raise NotImplementedError("Invalid optimizer name: {}".format(name))
+    for n in ([net] if isinstance(net, torch.nn.Module) else (net or [])):
+        if hasattr(n, "flat_params"):
+            n.flat_params()              # parameters become views of the network's flat buffer
     if not optim_params:
         optim_params, _ = get_optim_params(net, True)
     optim = train_opt.get("optim_" + name, "adam") or "adam"

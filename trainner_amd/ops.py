@@ -336,6 +336,20 @@ def l1_mean_bwd(a, b, scale, gscale, ga, accumulate=False):
                                          int(accumulate), hip.stream()), "l1_mean_bwd")
 
 
+def ragan_phase_a(pf, pr, sums):
+    hip.check(hip.load().tnr_ragan_phase_a(pf.data_ptr(), pr.data_ptr(), pf.numel(), sums.data_ptr(), hip.stream()), "ragan_a")
+
+
+def ragan_phase_b(pf, pr, stage, sums):
+    hip.check(hip.load().tnr_ragan_phase_b(pf.data_ptr(), pr.data_ptr(), pf.numel(), stage, sums.data_ptr(), hip.stream()),
+              "ragan_b")
+
+
+def ragan_phase_c(pf, pr, stage, weight, sums, out, gf, gr):
+    hip.check(hip.load().tnr_ragan_phase_c(pf.data_ptr(), pr.data_ptr(), pf.numel(), stage, float(weight), sums.data_ptr(),
+                                           out.data_ptr(), hip.ptr(gf), hip.ptr(gr), hip.stream()), "ragan_c")
+
+
 def scale_by(dst, src, gscale):
     hip.check(hip.load().tnr_scale_by(dst.data_ptr(), src.data_ptr(), src.numel(), gscale.data_ptr(), hip.stream()),
               "scale_by")
