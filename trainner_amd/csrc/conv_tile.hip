@@ -88,7 +88,44 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nn][r] = 0.f;
 
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // ---- staging plan.  Every item is one float4 (4 channels); the per-item global offsets do not
+    // depend on the chunk (except the parity of the space-to-depth view), so they are computed once.
+    // Loads of chunk k+1 are issued into registers BEFORE the MFMA phase of chunk k and written to
+    // LDS after it (issue-early / write-late): HBM/L2 latency hides under ~10-20k cycles of MFMA.
+    constexpr int IN_ITEMS = HT * WT * 4, IN_IT = (IN_ITEMS + 255) / 256;
+    constexpr int W_ITEMS = NTAPS * NC * 4, W_IT = (W_ITEMS + 255) / 256;
+    int in_off[IN_IT];   // element offset into x (without the chunk's channel offset), -1 = zero fill
+    int w_off[W_IT];     // element offset into the packed weights (without chunk offset), -1 = zero fill
+    if (!S2D) {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            const int pix = i >> 2, q = i & 3;
+            const int hr = pix / WT, hc = pix - hr * WT;
+            int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            bool ok = i < IN_ITEMS;
+            if (UP) {
+                ok = ok & (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                Y >>= 1;
+                X >>= 1;
+            } else {
+                ok = ok & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            }
+            in_off[it] = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int i = tid + it * 256;
+        const int row = i >> 2, q = i & 3;
+        const int t = row / NC, co = row - t * NC;
+        const int cog = cb * NC + co;
+        const bool ok = (i < W_ITEMS) & (cog < a.KoutP);
+        w_off[it] = ok ? ((t * a.KoutP + cog) * (S2D ? 4 * a.KinP : a.KinP) + q * 4) : -1;
+    }
+    f32x4 rin[IN_IT], rw[W_IT];
+
+    auto load_chunk = [&](int chunk) {
         int c0, pp = 0;
         if (S2D) {
             pp = chunk / nck;
@@ -96,48 +133,50 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         } else {
             c0 = chunk * CK;
         }
-        __syncthreads();  // previous chunk's fragments are consumed
-        // ---- stage the halo tile of this chunk: one float4 (4 channels) per item
-        for (int i = tid; i < HT * WT * 4; i += 256) {
-            const int pix = i >> 2, q = i & 3;
-            const int hr = pix / WT, hc = pix - hr * WT;
-            int Y, X;
-            bool ok;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            const int q = i & 3;
+            int off;
             if (S2D) {
-                Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
-                X = 2 * (tx0 + hc) - 1 + (pp & 1);
-                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-            } else if (UP) {
-                Y = ty0 + hr - 1;
-                X = tx0 + hc - 1;
-                ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
-                Y >>= 1;
-                X >>= 1;
+                const int pix = i >> 2;
+                const int hr = pix / WT, hc = pix - hr * WT;
+                const int Y = 2 * (ty0 + hr) - 1 + (pp >> 1), X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                const bool ok = (i < IN_ITEMS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
             } else {
-                Y = ty0 + hr - 1;
-                X = tx0 + hc - 1;
-                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                off = in_off[it];
             }
-            const int c = c0 + q * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && c < a.Cin)
-                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)(n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c);
-            *reinterpret_cast<f32x4 *>(s_in + pix * PST + q * 4) = v;
+            if (off >= 0 && c0 + q * 4 < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
+            rin[it] = v;
         }
-        // ---- stage the weight slab [tap][cout][16]
-        for (int i = tid; i < NTAPS * NC * 4; i += 256) {
-            const int row = i >> 2, q = i & 3;
-            const int t = row / NC, co = row - t * NC;
-            const int cog = cb * NC + co;
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cog < a.KoutP) {
-                const size_t off = S2D ? ((size_t)(t * a.KoutP + cog) * (4 * a.KinP) + (size_t)pp * a.KinP + c0 + q * 4)
-                                       : ((size_t)(t * a.KoutP + cog) * a.KinP + c0 + q * 4);
-                v = *reinterpret_cast<const f32x4 *>(wbase + off);
-            }
-            *reinterpret_cast<f32x4 *>(s_w + row * PST + q * 4) = v;
+            if (w_off[it] >= 0) v = *reinterpret_cast<const f32x4 *>(wbase + (size_t)w_off[it] + (S2D ? pp * a.KinP : 0) + c0);
+            rw[it] = v;
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < IN_ITEMS) *reinterpret_cast<f32x4 *>(s_in + (i >> 2) * PST + (i & 3) * 4) = rin[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < W_ITEMS) *reinterpret_cast<f32x4 *>(s_w + (i >> 2) * PST + (i & 3) * 4) = rw[it];
+        }
+    };
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // previous chunk's fragments are consumed
+        store_chunk();
         __syncthreads();
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase below
         // ---- MFMA over taps x 16 channels
 #pragma unroll 1
         for (int t = 0; t < NTAPS; ++t) {
@@ -245,6 +284,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
                 "conv: input view must be 4-channel aligned (ctot %d coff %d Cin %d)", d->x.ctot, d->x.coff, d->Cin);
     TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
     TNR_REQUIRE(d->Cin <= d->KinP && d->Cout <= d->KoutP, "conv: Cin/Cout exceed the packing");
+    TNR_REQUIRE((int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 31), "conv: input buffer above 2^31 elements needs 64-bit offsets");
     ConvK k;
     k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
     k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;

@@ -77,49 +77,86 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
         const int ty = q % a.tiles_y;
         const int n = q / a.tiles_y;
         const int ty0 = ty * THG, tx0 = tx * TWG;
-        __syncthreads();
-        // ---- stage g tile [PX][COB]
-        for (int i = tid; i < PX * (COB / 4); i += 256) {
-            const int p = i / (COB / 4), c4 = i - p * (COB / 4);
-            const int r = p / TWG, c = p - r * TWG;
-            const int oy = ty0 + r, ox = tx0 + c;
-            const int co = cob * COB + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (oy < a.Ho && ox < a.Wo && co < a.Cout)
-                v = *reinterpret_cast<const f32x4 *>(a.g + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.g_ct + a.g_co + co);
-            *reinterpret_cast<f32x4 *>(s_g + p * COB + c4 * 4) = v;
-        }
-        // ---- stage x halo tile [HT*WT][CIB]; each 32-channel sub-block may be its own parity (S2D)
-        for (int i = tid; i < HT * WT * (CIB / 4); i += 256) {
-            const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
-            const int hr = pix / WT, hc = pix - hr * WT;
-            const int vb = cib * B_T + (c4 >> 3);  // global 32-wide virtual block index
-            int Y, X, c;
-            bool ok;
-            if (S2D) {
-                const int nb32 = a.cinp32 >> 5;
-                const int pp = vb / nb32;
-                c = (vb - pp * nb32) * 32 + (c4 & 7) * 4;
-                Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
-                X = 2 * (tx0 + hc) - 1 + (pp & 1);
-                ok = (pp < 4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-            } else if (UP) {
-                c = vb * 32 + (c4 & 7) * 4;
-                Y = ty0 + hr - 1;
-                X = tx0 + hc - 1;
-                ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
-                Y >>= 1;
-                X >>= 1;
-            } else {
-                c = vb * 32 + (c4 & 7) * 4;
-                Y = ty0 + hr - 1;
-                X = tx0 + hc - 1;
-                ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+        // ---- stage g tile [PX][COB] and x halo tile [HT*WT][CIB]: all global loads are issued back to
+        // back into registers (one latency, not one per item), then written to LDS
+        constexpr int G_ITEMS = PX * (COB / 4), G_IT = (G_ITEMS + 255) / 256;
+        constexpr int X_ITEMS = HT * WT * (CIB / 4), X_IT = (X_ITEMS + 255) / 256;
+        // Items (G first, then X) are processed in batches of BATCH float4 per thread: enough loads in
+        // flight to cover latency, few enough that staging registers + the accumulators stay < 256 VGPRs.
+        constexpr int N_IT = G_IT + X_IT;
+        constexpr int BATCH = (J >= 9) ? 5 : 8;
+        constexpr int NBATCH = (N_IT + BATCH - 1) / BATCH;
+        f32x4 rr[BATCH];
+        auto load_batch = [&](int batch) {
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int it = batch * BATCH + k;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (it < G_IT) {
+                    const int i = tid + it * 256;
+                    const int p = i / (COB / 4), c4 = i - p * (COB / 4);
+                    const int r = p / TWG, c = p - r * TWG;
+                    const int oy = ty0 + r, ox = tx0 + c;
+                    const int co = cob * COB + c4 * 4;
+                    if (i < G_ITEMS && oy < a.Ho && ox < a.Wo && co < a.Cout) {
+                        const int off = ((n * a.Ho + oy) * a.Wo + ox) * a.g_ct + a.g_co + co;
+                        v = *reinterpret_cast<const f32x4 *>(a.g + off);
+                    }
+                } else if (it < N_IT) {
+                    const int i = tid + (it - G_IT) * 256;
+                    const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
+                    const int hr = pix / WT, hc = pix - hr * WT;
+                    const int vb = cib * B_T + (c4 >> 3);  // global 32-wide virtual block index
+                    int Y, X, c;
+                    bool ok;
+                    if (S2D) {
+                        const int nb32 = a.cinp32 >> 5;
+                        const int pp = vb / nb32;
+                        c = (vb - pp * nb32) * 32 + (c4 & 7) * 4;
+                        Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
+                        X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                        ok = (pp < 4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                    } else if (UP) {
+                        c = vb * 32 + (c4 & 7) * 4;
+                        Y = ty0 + hr - 1;
+                        X = tx0 + hc - 1;
+                        ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                        Y >>= 1;
+                        X >>= 1;
+                    } else {
+                        c = vb * 32 + (c4 & 7) * 4;
+                        Y = ty0 + hr - 1;
+                        X = tx0 + hc - 1;
+                        ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                    }
+                    if (i < X_ITEMS && ok && c < a.Cin) {
+                        const int off = ((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c;
+                        v = *reinterpret_cast<const f32x4 *>(a.x + off);
+                    }
+                }
+                rr[k] = v;
             }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok && c < a.Cin)
-                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)(n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c);
-            *reinterpret_cast<f32x4 *>(s_x + pix * CIB + c4 * 4) = v;
+        };
+        auto store_batch = [&](int batch) {
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int it = batch * BATCH + k;
+                if (it < G_IT) {
+                    const int i = tid + it * 256;
+                    if (i < G_ITEMS) *reinterpret_cast<f32x4 *>(s_g + i * 4) = rr[k];
+                } else if (it < N_IT) {
+                    const int i = tid + (it - G_IT) * 256;
+                    if (i < X_ITEMS) *reinterpret_cast<f32x4 *>(s_x + i * 4) = rr[k];
+                }
+            }
+        };
+        load_batch(0);
+        __syncthreads();  // previous tile's fragments are consumed
+        store_batch(0);
+#pragma unroll
+        for (int bt = 1; bt < NBATCH; ++bt) {
+            load_batch(bt);
+            store_batch(bt);
         }
         __syncthreads();
         if (want_bias && tid < COB) {
@@ -178,10 +215,33 @@ struct RedK {
     float alpha, beta;
 };
 
-__global__ void wgrad_reduce_kernel(const RedK a) {
+// 256 threads = 32 consecutive slab elements x 8 split lanes: lane l sums splits l, l+8, ... (eight
+// independent 128-B-coalesced load streams per element group), then the 8 lane sums are combined in a
+// fixed order through LDS -- deterministic, and ~8x32 loads in flight per block instead of one.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
+    __shared__ float sh[8][33];
     const int64_t total = (int64_t)a.ntaps * a.KoutP * a.KinVP;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
+    float part = 0.f;
     if (e < total) {
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        int s = sl;
+        for (; s + 24 < a.splits; s += 32) {       // four independent loads in flight per lane
+            p0 += a.ws[(size_t)s * total + e];
+            p1 += a.ws[(size_t)(s + 8) * total + e];
+            p2 += a.ws[(size_t)(s + 16) * total + e];
+            p3 += a.ws[(size_t)(s + 24) * total + e];
+        }
+        for (; s < a.splits; s += 8) p0 += a.ws[(size_t)s * total + e];
+        part = (p0 + p1) + (p2 + p3);
+    }
+    sh[sl][el] = part;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        float sum = 0.f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) sum += sh[l][el];
         const int civ = (int)(e % a.KinVP);
         const int64_t q = e / a.KinVP;
         const int co = (int)(q % a.KoutP);
@@ -198,18 +258,20 @@ __global__ void wgrad_reduce_kernel(const RedK a) {
             kx = tap - ky * a.kw;
         }
         if (co < a.Cout && ci < a.Cin) {
-            float sum = 0.f;
-            for (int s = 0; s < a.splits; ++s) sum += a.ws[(size_t)s * total + e];
             const size_t o = (((size_t)co * a.cin_total + a.cin_begin + ci) * a.kh + ky) * a.kw + kx;
             const float prev = (a.beta != 0.f) ? a.beta * a.dw[o] : 0.f;
             a.dw[o] = prev + a.alpha * sum;
         }
     }
-    if (a.db != nullptr && e < a.Cout) {
-        float sum = 0.f;
-        for (int s = 0; s < a.splits; ++s) sum += a.dbp[(size_t)s * a.KoutP + e];
-        const float prev = (a.beta != 0.f) ? a.beta * a.db[e] : 0.f;
-        a.db[e] = prev + a.alpha * sum;
+    // bias: the first blocks also own one output channel each (32 per block)
+    if (a.db != nullptr && sl == 1) {
+        const int64_t c = (int64_t)blockIdx.x * 32 + el;
+        if (c < a.Cout) {
+            float sum = 0.f;
+            for (int s = 0; s < a.splits; ++s) sum += a.dbp[(size_t)s * a.KoutP + c];
+            const float prev = (a.beta != 0.f) ? a.beta * a.db[c] : 0.f;
+            a.db[c] = prev + a.alpha * sum;
+        }
     }
 }
 
@@ -245,7 +307,8 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
     p.tiles_y = tnr_cdiv(d->Ho, p.thg);
     p.tiles_total = p.tiles_x * p.tiles_y * d->N;
     // enough workgroups for ~2 per CU, but never fewer than 4 tiles of work per split
-    int want = tnr_cdiv(512, p.ncib * p.ncob);
+    int want = 512 / (p.ncib * p.ncob);   // <= 2 resident workgroups per CU, never a 513th straggler
+    if (want < 1) want = 1;
     int max_splits = tnr_cdiv(p.tiles_total, 4);
     if (max_splits < 1) max_splits = 1;
     p.splits = want < max_splits ? want : max_splits;
@@ -309,6 +372,8 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     if (d->mode == TNR_CONV_3x3) TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "wgrad3x3: size mismatch");
     if (d->mode == TNR_CONV_3x3_UP2) TNR_REQUIRE(d->Ho == 2 * d->H && d->Wo == 2 * d->W, "wgrad3x3_up2: size mismatch");
     if (d->mode == TNR_CONV_4x4_S2) TNR_REQUIRE(2 * d->Ho == d->H && 2 * d->Wo == d->W, "wgrad4x4s2: size mismatch");
+    TNR_REQUIRE((int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 31) && (int64_t)d->N * d->Ho * d->Wo * d->g.ctot < (1LL << 31),
+                "wgrad: buffers above 2^31 elements need 64-bit offsets");
     WgPlan p;
     plan_wgrad(d, p);
     TNR_REQUIRE((p.ws_floats + p.db_floats) * (int64_t)sizeof(float) <= d->ws_bytes, "wgrad: workspace too small (%lld < %lld)",
@@ -334,6 +399,6 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.alpha = d->alpha; r.beta = d->beta;
     int64_t total = (int64_t)p.ntaps * p.KoutP * p.KinVP;
     if (total < d->Cout) total = d->Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tnr_cdiv64(total, 256)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tnr_cdiv64(total, 32)), dim3(256), 0, s, r);
     return tnr_check_launch("wgrad_reduce");
 }

@@ -154,16 +154,17 @@ class ConvProfile:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, family, flops, start):
+    def end(self, family, flops, start, shape=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self.records.append((family, flops, start, ev))
+        self.records.append((family, flops, start, ev, shape))
 
-    def summary(self):
+    def summary(self, by_shape=False):
         torch.cuda.synchronize()
         out = {}
-        for fam, flops, a, b in self.records:
-            d = out.setdefault(fam, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for fam, flops, a, b, shape in self.records:
+            key = (fam,) + tuple(shape or ()) if by_shape else fam
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
             d["ms"] += a.elapsed_time(b)
@@ -202,7 +203,7 @@ def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0,
     opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
            DGRAD_4x4_S2: "conv_tile_dgrad4x4s2"}[mode]
-    PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0)
+    PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
 
 
 def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
@@ -226,7 +227,7 @@ def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
     t0 = PROFILE.begin()
     hip.check(lib.tnr_conv_wgrad(C.byref(d), hip.stream()), "conv_wgrad")
     taps = 16 if mode == CONV_4x4_S2 else 9
-    PROFILE.end("wgrad_tile", 2.0 * g.pixels * taps * x.C * g.C, t0)
+    PROFILE.end("wgrad_tile", 2.0 * g.pixels * taps * x.C * g.C, t0, (x.C, g.C, g.H, mode))
 
 
 # ----------------------------------------------------------------------------------------------
