@@ -104,6 +104,22 @@ typedef struct tnr_pack_item {
     int64_t n_out;   /* number of packed floats */
 } tnr_pack_item;
 
+/* "Gradient dense block": the data-gradient of a ResidualDenseBlock_5C (RRDBNet_arch.py:150-163) run as
+ * the mirror image of its forward.  With the gradient buffer laid out [g5(nf) | g4 | g3 | g2 | g1]
+ * (g_k = gradient w.r.t. conv_k's pre-activation output), the gradient w.r.t. the block's t-th feature
+ * group (t = 0..4 -> x4, x3, x2, x1, x) is ONE convolution over the first nf + t*gc channels of that
+ * buffer, with this packing of the transposed / flipped slices of W5..W(5-t) (conv5's slice pre-scaled by
+ * scale5 = 0.2 * s).  No read-modify-write accumulation, K grows like in the forward pass.             */
+typedef struct tnr_dense_pack_item {
+    const float *w[5]; /* conv1..conv5 weights, OIHW */
+    float *wp;
+    int32_t nf, gc;
+    int32_t t;         /* 0..4 */
+    int32_t KoutP, KinP;
+    float scale5;
+    int64_t n_out;
+} tnr_dense_pack_item;
+
 const char *tnr_last_error(void);
 int tnr_version(void);
 
@@ -112,6 +128,8 @@ int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t kin
                   int32_t *KoutP, int32_t *KinP, int64_t *n_out);
 /* items: DEVICE array of n descriptors; max_out = max n_out over the items */
 int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
+int tnr_pack_dense_dims(int32_t nf, int32_t gc, int32_t t, int32_t *KoutP, int32_t *KinP, int64_t *n_out);
+int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
 int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);

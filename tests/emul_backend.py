@@ -38,6 +38,39 @@ class EmulPacker:
         pass
 
 
+class EmulDensePacker:
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+
+    def add_block(self, weights, nf, gc, scale5):
+        idx = []
+        for t in range(5):
+            p = _Packed(None, ops.PACK_DENSE_DGRAD)
+            p.srcs, p.tt, p.nf, p.gc, p.scale5 = list(weights), t, nf, gc, scale5
+            self.jobs.append(p)
+            idx.append(len(self.jobs) - 1)
+        return idx
+
+    def get(self, idx):
+        return self.jobs[idx]
+
+    def run(self):
+        pass
+
+
+def _dense_dgrad(xin, wp, yC):
+    """sum over the consumers of the target group of conv_transpose(g_k, W_k[:, target])."""
+    nf, gc, t = wp.nf, wp.gc, wp.tt
+    tlo, ntar = (0, nf) if t == 4 else (nf + (3 - t) * gc, gc)
+    w5 = wp.srcs[4].detach()[:, tlo:tlo + ntar]
+    out = wp.scale5 * F.conv_transpose2d(xin[:, :nf], w5, None, padding=1)
+    for m in range(t):
+        wk = wp.srcs[3 - m].detach()[:, tlo:tlo + ntar]
+        out = out + F.conv_transpose2d(xin[:, nf + m * gc: nf + (m + 1) * gc], wk, None, padding=1)
+    return out
+
+
 def _nchw(v):
     return v.dense().permute(0, 3, 1, 2)
 
@@ -55,9 +88,11 @@ def _mask(m, slope):
 
 def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
          beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
-    w = wp.w.detach()
     xin = _nchw(x)
-    if wp.kind == ops.PACK_FWD:
+    w = None if wp.kind == ops.PACK_DENSE_DGRAD else wp.w.detach()
+    if wp.kind == ops.PACK_DENSE_DGRAD:
+        out = _dense_dgrad(xin, wp, y.C)
+    elif wp.kind == ops.PACK_FWD:
         xi = _fit(xin, w.shape[1])
         if mode == ops.CONV_3x3_UP2:
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
@@ -284,5 +319,6 @@ def install(monkeypatch):
     for n in _NAMES:
         monkeypatch.setattr(ops, n, g[n])
     monkeypatch.setattr(ops, "WeightPacker", EmulPacker)
+    monkeypatch.setattr(ops, "DensePacker", EmulDensePacker)
     monkeypatch.setattr(hip, "require_device", lambda t=None: None)
     monkeypatch.setattr(hip, "engine_device", lambda index=0: torch.device("cpu"))

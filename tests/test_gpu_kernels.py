@@ -385,3 +385,25 @@ def test_linear_and_losses_and_optim():
         close(gcur.cpu(), pt.grad, tol=1e-6, what="clip")
         ops.adam_step(pd, gcur, md, vd, 1e-4 / (1 - 0.9 ** t), 0.9, 0.999, math.sqrt(1 - 0.999 ** t), 1e-8)
     assert (pd.cpu() - pt.detach()).abs().max().item() < 2e-7, "adam"
+
+
+@pytest.mark.parametrize("t", [0, 1, 2, 3, 4])
+def test_dense_block_gradient_pack(t):
+    """tnr_pack_dense_dgrad + conv_tile == sum over consumers of conv_transpose(g_k, W_k[:, target])."""
+    ops = _ops()
+    nf, gc, N, H, W = 64, 32, 1, 20, 36
+    ws = [rnd(gc if k < 4 else nf, nf + k * gc, 3, 3, seed=60 + k, lo=-0.1, hi=0.1) for k in range(5)]
+    gp = rnd(N, nf + 4 * gc, H, W, seed=70)                      # [g5 | g4 | g3 | g2 | g1]
+    scale5 = 0.04
+    tlo, ntar = (0, nf) if t == 4 else (nf + (3 - t) * gc, gc)
+    ref = scale5 * F.conv_transpose2d(gp[:, :nf], ws[4][:, tlo:tlo + ntar], None, padding=1)
+    for m in range(t):
+        ref = ref + F.conv_transpose2d(gp[:, nf + m * gc: nf + (m + 1) * gc], ws[3 - m][:, tlo:tlo + ntar], None, padding=1)
+    dp = ops.DensePacker(torch.device(DEV))
+    wd = [w.to(DEV) for w in ws]
+    idx = dp.add_block(wd, nf, gc, scale5)
+    dp.run()
+    gb = nhwc_buf(gp)
+    yb = torch.zeros((N, H, W, ntar), device=DEV)
+    ops.conv(ops.View(gb, 0, nf + t * gc), dp.get(idx[t]), ops.View(yb))
+    close(to_nchw(yb, 0, ntar), ref, what="dense-block gradient step %d" % t)

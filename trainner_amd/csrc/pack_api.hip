@@ -101,6 +101,56 @@ __global__ void pack_weights_kernel(const tnr_pack_item *items) {
 }
 }  // namespace
 
+namespace {
+__global__ void pack_dense_kernel(const tnr_dense_pack_item *items) {
+    const tnr_dense_pack_item it = items[blockIdx.y];
+    const int nf = it.nf, gc = it.gc, t = it.t, ko = it.KoutP, ki = it.KinP;
+    const int ntarget = (t == 4) ? nf : gc;
+    const int tlo = (t == 4) ? 0 : nf + (3 - t) * gc;   // first forward-input channel of the target group
+    const int K = nf + t * gc;                          // valid reduction channels
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < it.n_out; e += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(e % ki);
+        int64_t q = e / ki;
+        const int cl = (int)(q % ko);
+        const int tap = (int)(q / ko);
+        float v = 0.f;
+        if (cl < ntarget && r < K) {
+            const int ky = 2 - tap / 3, kx = 2 - tap % 3;
+            const int c = tlo + cl;                      // channel of the forward conv's input
+            if (r < nf) {                                // conv5 (nf outputs, nf + 4 gc inputs)
+                const int cin = nf + 4 * gc;
+                v = it.scale5 * it.w[4][(((size_t)r * cin + c) * 3 + ky) * 3 + kx];
+            } else {
+                const int m = (r - nf) / gc;             // 0 -> conv4, 1 -> conv3, ...
+                const int ro = (r - nf) - m * gc;
+                const int k = 3 - m;                     // index into w[] (conv_{k+1})
+                const int cin = nf + k * gc;
+                v = it.w[k][(((size_t)ro * cin + c) * 3 + ky) * 3 + kx];
+            }
+        }
+        it.wp[e] = v;
+    }
+}
+}  // namespace
+
+extern "C" int tnr_pack_dense_dims(int32_t nf, int32_t gc, int32_t t, int32_t *KoutP, int32_t *KinP, int64_t *n_out) {
+    TNR_REQUIRE(nf > 0 && gc > 0 && t >= 0 && t <= 4 && (nf % 4) == 0 && (gc % 4) == 0, "pack_dense: bad arguments");
+    const int ko = tnr_round_up(t == 4 ? nf : gc, 32), ki = tnr_round_up(nf + t * gc, TNR_CK);
+    if (KoutP) *KoutP = ko;
+    if (KinP) *KinP = ki;
+    if (n_out) *n_out = (int64_t)9 * ko * ki;
+    return TNR_OK;
+}
+
+extern "C" int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_t max_out, void *stream) {
+    TNR_REQUIRE(items_dev != nullptr && n > 0 && max_out > 0, "pack_dense: bad arguments");
+    int64_t bx = tnr_cdiv64(max_out, 256 * 4);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(pack_dense_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return tnr_check_launch("pack_dense_dgrad");
+}
+
 extern "C" int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out, void *stream) {
     TNR_REQUIRE(items_dev != nullptr && n > 0 && max_out > 0, "pack: bad arguments");
     int64_t bx = tnr_cdiv64(max_out, 256 * 4);

@@ -19,7 +19,7 @@ struct WgK {
     float *ws; int KoutP, KinVP;  // slab dims
     int cinp32;                   // per-parity padded channel count (S2D); == KinVP otherwise
     float *dbp;                   // partial bias sums [split][KoutP] or null
-    int tiles_x, tiles_y, tiles_total, tiles_per_split;
+    int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits;
 };
 
 template <int MODE, int A_T, int B_T, int THG>
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
         const int ty = tap / KH, tx = tap - ty * KH;
         t_tap[j] = tap * 1024 + aa * 32 + bb;  // packed for the store phase
         t_aa[j] = aa;
-        t_boff[j] = (ty * WT + tx) * CIB + bb * 32;
+        t_boff[j] = (ty * WT + tx) * CIB + bb * 32;  // slots beyond T alias tile 0: computed, never stored
     }
 
     f32x16 acc[J];
@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float bacc = 0.f;
+    float bsum[A_T];   // per-lane partial bias gradient: sum over pixels of g[p][aa*32 + li] (both pixel parities)
+#pragma unroll
+    for (int aa = 0; aa < A_T; ++aa) bsum[aa] = 0.f;
     const bool want_bias = (a.dbp != nullptr) && (cib == 0);
 
     const int t_begin = split * a.tiles_per_split;
@@ -159,30 +161,47 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
             store_batch(bt);
         }
         __syncthreads();
-        if (want_bias && tid < COB) {
-            float sacc = 0.f;
-            for (int p = 0; p < PX; ++p) sacc += s_g[p * COB + tid];
-            bacc += sacc;
+        // ---- K loop: two pixels per MFMA.  Operands of k-step s+1 are fetched from LDS before the
+        // MFMAs of k-step s are issued (explicit software pipeline), and there is no control flow in the
+        // loop body: J straight-line MFMAs per k-step.
+        auto frag_addr = [&](int s_, int &gbase, int &xbase) {
+            const int p = 2 * s_ + half;
+            const int r = p / TWG, c = p - r * TWG;
+            gbase = p * COB + li;
+            xbase = (r * WT + c) * CIB + li;
+        };
+        float a_cur[A_T], b_cur[J];
+        {
+            int gb, xb;
+            frag_addr(0, gb, xb);
+#pragma unroll
+            for (int aa = 0; aa < A_T; ++aa) a_cur[aa] = s_g[gb + aa * 32];
+#pragma unroll
+            for (int j = 0; j < J; ++j) b_cur[j] = s_x[xb + t_boff[j]];
         }
-        // ---- K loop: two pixels per MFMA
 #pragma unroll 2
         for (int s = 0; s < PX / 2; ++s) {
-            const int p = 2 * s + half;
-            const int r = p / TWG, c = p - r * TWG;
-            const int gbase = p * COB;
-            const int xbase = (r * WT + c) * CIB;
-            float av[A_T];
+            float a_nxt[A_T], b_nxt[J];
+            {
+                int gb, xb;
+                frag_addr(s + 1 < PX / 2 ? s + 1 : s, gb, xb);
 #pragma unroll
-            for (int aa = 0; aa < A_T; ++aa) av[aa] = s_g[gbase + aa * 32 + li];
+                for (int aa = 0; aa < A_T; ++aa) a_nxt[aa] = s_g[gb + aa * 32];
+#pragma unroll
+                for (int j = 0; j < J; ++j) b_nxt[j] = s_x[xb + t_boff[j]];
+            }
+#pragma unroll
+            for (int aa = 0; aa < A_T; ++aa) bsum[aa] += a_cur[aa];
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                if (t_ok[j]) {
-                    float aval = av[0];
-                    if (A_T > 1) aval = t_aa[j] ? av[A_T - 1] : av[0];
-                    const float bval = s_x[xbase + t_boff[j] + li];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bval, acc[j], 0, 0, 0);
-                }
+                float aval = a_cur[0];
+                if (A_T > 1) aval = t_aa[j] ? a_cur[A_T - 1] : a_cur[0];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, b_cur[j], acc[j], 0, 0, 0);
             }
+#pragma unroll
+            for (int aa = 0; aa < A_T; ++aa) a_cur[aa] = a_nxt[aa];
+#pragma unroll
+            for (int j = 0; j < J; ++j) b_cur[j] = b_nxt[j];
         }
     }
 
@@ -191,19 +210,26 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
     for (int j = 0; j < J; ++j) {
         if (!t_ok[j]) continue;
         const int tap = t_tap[j] >> 10, aa = (t_tap[j] >> 5) & 31, bb = t_tap[j] & 31;
-        const int civ = (cib * B_T + bb) * 32 + li;
-        if (civ >= a.KinVP) continue;
-        float *slab = a.ws + ((size_t)split * NTAPS + tap) * a.KoutP * a.KinVP;
+        const int blk = cib * B_T + bb;                // 32-wide virtual input-channel block
+        const int nblk = a.KinVP >> 5;
+        if (blk >= nblk) continue;
+        // slab layout [tap][co][blk][split][32]: the split axis is contiguous (128-B granules), so the
+        // reducer streams each (tap, co, blk) row; a wave store still writes 128 B per half-wave
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int co = cob * COB + aa * 32 + i;
-            if (co < a.KoutP) slab[(size_t)co * a.KinVP + civ] = acc[j][r];
+            if (co < a.KoutP)
+                a.ws[((((size_t)tap * a.KoutP + co) * nblk + blk) * a.nsplits + split) * 32 + li] = acc[j][r];
         }
     }
-    if (want_bias && tid < COB) {
-        const int co = cob * COB + tid;
-        if (co < a.KoutP) a.dbp[(size_t)split * a.KoutP + co] = bacc;
+    if (want_bias && wave == 0) {   // every wave accumulated the same sums; wave 0 publishes them
+#pragma unroll
+        for (int aa = 0; aa < A_T; ++aa) {
+            const float tot = bsum[aa] + __shfl_xor(bsum[aa], 32);
+            const int co = cob * COB + aa * 32 + li;
+            if (half == 0 && co < a.KoutP) a.dbp[(size_t)split * a.KoutP + co] = tot;
+        }
     }
 }
 
@@ -215,37 +241,34 @@ struct RedK {
     float alpha, beta;
 };
 
-// 256 threads = 32 consecutive slab elements x 8 split lanes: lane l sums splits l, l+8, ... (eight
-// independent 128-B-coalesced load streams per element group), then the 8 lane sums are combined in a
-// fixed order through LDS -- deterministic, and ~8x32 loads in flight per block instead of one.
+// One block per slab row (tap, co, 32-channel block): 256 threads = 32 channels x 8 split lanes.  The
+// row's partials [split][32] are contiguous, so the 8 lanes stream 1 KiB per step; lane sums are combined
+// in a fixed order through LDS (deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
     __shared__ float sh[8][33];
-    const int64_t total = (int64_t)a.ntaps * a.KoutP * a.KinVP;
+    const int nblk = a.KinVP >> 5;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int64_t e = (int64_t)blockIdx.x * 32 + el;
-    float part = 0.f;
-    if (e < total) {
-        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-        int s = sl;
-        for (; s + 24 < a.splits; s += 32) {       // four independent loads in flight per lane
-            p0 += a.ws[(size_t)s * total + e];
-            p1 += a.ws[(size_t)(s + 8) * total + e];
-            p2 += a.ws[(size_t)(s + 16) * total + e];
-            p3 += a.ws[(size_t)(s + 24) * total + e];
-        }
-        for (; s < a.splits; s += 8) p0 += a.ws[(size_t)s * total + e];
-        part = (p0 + p1) + (p2 + p3);
+    const int row = blockIdx.x;                         // ((tap * KoutP) + co) * nblk + blk
+    const int blk = row % nblk;
+    const int co = (row / nblk) % a.KoutP;
+    const int tap = row / (nblk * a.KoutP);
+    const float *src = a.ws + (size_t)row * a.splits * 32 + el;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    int s = sl;
+    for (; s + 24 < a.splits; s += 32) {                // four independent loads in flight per lane
+        p0 += src[(size_t)s * 32];
+        p1 += src[(size_t)(s + 8) * 32];
+        p2 += src[(size_t)(s + 16) * 32];
+        p3 += src[(size_t)(s + 24) * 32];
     }
-    sh[sl][el] = part;
+    for (; s < a.splits; s += 8) p0 += src[(size_t)s * 32];
+    sh[sl][el] = (p0 + p1) + (p2 + p3);
     __syncthreads();
-    if (sl == 0 && e < total) {
+    if (sl == 0) {
         float sum = 0.f;
 #pragma unroll
         for (int l = 0; l < 8; ++l) sum += sh[l][el];
-        const int civ = (int)(e % a.KinVP);
-        const int64_t q = e / a.KinVP;
-        const int co = (int)(q % a.KoutP);
-        const int tap = (int)(q / a.KoutP);
+        const int civ = blk * 32 + el;
         int ci, ky, kx;
         if (a.s2d) {
             const int pp = civ / a.cinp32;
@@ -263,12 +286,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
             a.dw[o] = prev + a.alpha * sum;
         }
     }
-    // bias: the first blocks also own one output channel each (32 per block)
+    // bias: the first ceil(Cout/32) blocks also own 32 output channels each
     if (a.db != nullptr && sl == 1) {
         const int64_t c = (int64_t)blockIdx.x * 32 + el;
         if (c < a.Cout) {
             float sum = 0.f;
-            for (int s = 0; s < a.splits; ++s) sum += a.dbp[(size_t)s * a.KoutP + c];
+            for (int q = 0; q < a.splits; ++q) sum += a.dbp[(size_t)q * a.KoutP + c];
             const float prev = (a.beta != 0.f) ? a.beta * a.db[c] : 0.f;
             a.db[c] = prev + a.alpha * sum;
         }
@@ -384,6 +407,7 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     k.ws = d->ws; k.KoutP = p.KoutP; k.KinVP = p.KinVP; k.cinp32 = p.cinp32;
     k.dbp = d->db ? d->ws + p.ws_floats : nullptr;
     k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.tiles_total = p.tiles_total; k.tiles_per_split = p.tiles_per_split;
+    k.nsplits = p.splits;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (d->mode) {
@@ -397,8 +421,7 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     r.cinp32 = p.cinp32; r.dw = d->dw; r.db = d->db; r.Cout = d->Cout; r.Cin = d->Cin; r.cin_total = d->cin_total;
     r.cin_begin = d->cin_begin; r.s2d = d->mode == TNR_CONV_4x4_S2;
     r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.alpha = d->alpha; r.beta = d->beta;
-    int64_t total = (int64_t)p.ntaps * p.KoutP * p.KinVP;
-    if (total < d->Cout) total = d->Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)tnr_cdiv64(total, 32)), dim3(256), 0, s, r);
+    const int64_t rows = (int64_t)p.ntaps * p.KoutP * (p.KinVP / 32);    // >= Cout/32 blocks for the bias part
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, s, r);
     return tnr_check_launch("wgrad_reduce");
 }

@@ -70,6 +70,7 @@ class HipNet(torch.nn.Module):
     def _init_engine(self):
         self._flat = FlatParams(self)
         self._packer = None
+        self._dense_packer = None
         self._packer_owner = None
         self._ops = None
 
@@ -85,9 +86,11 @@ class HipNet(torch.nn.Module):
             raise hip.HipEngineError("network is on %s but input on %s" % (fp.flat.device, x.device))
         if self._packer is None or self._packer.device != x.device or self._packer_owner is not fp.flat:
             self._packer = ops.WeightPacker(x.device)
+            self._dense_packer = ops.DensePacker(x.device)
             self._packer_owner = fp.flat
             self._build_ops(self._packer)
         self._packer.run()
+        self._dense_packer.run()
 
     def forward(self, x, **kw):
         x = x.contiguous()

@@ -19,6 +19,7 @@ c_p = C.c_void_p
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2 = 0, 1, 2, 3
 PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2 = 0, 1, 2, 3
+PACK_DENSE_DGRAD = 16      # host-side tag of tnr_pack_dense_dgrad slabs (consumed like PACK_FWD by conv_tile)
 
 
 class CView(C.Structure):
@@ -53,11 +54,18 @@ class PackItem(C.Structure):
                 ("kind", c_i), ("KoutP", c_i), ("KinP", c_i), ("n_out", c_l)]
 
 
+class DensePackItem(C.Structure):
+    _fields_ = [("w", c_p * 5), ("wp", c_p), ("nf", c_i), ("gc", c_i), ("t", c_i), ("KoutP", c_i), ("KinP", c_i),
+                ("scale5", c_f), ("n_out", c_l)]
+
+
 _SIGS = {
     "tnr_last_error": (C.c_char_p, []),
     "tnr_version": (c_i, []),
     "tnr_pack_dims": (c_i, [c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_l)]),
     "tnr_pack_weights": (c_i, [c_p, c_i, c_l, c_p]),
+    "tnr_pack_dense_dims": (c_i, [c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_l)]),
+    "tnr_pack_dense_dgrad": (c_i, [c_p, c_i, c_l, c_p]),
     "tnr_conv_forward": (c_i, [C.POINTER(ConvDesc), c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
     "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),

@@ -10,10 +10,13 @@ ResidualDenseBlock_5C :98-163), re-designed for CDNA4:
   * bias, LeakyReLU(0.2), `x5*0.2 + x` and the RRDB-level `out*0.2 + x` are epilogues of the
     implicit-GEMM kernel (conv5 of RDB3 carries both residuals);
   * the nearest x2 of upconv_block is folded into the following conv's gather;
-  * backward is a hand-written schedule: per dense block five data-gradient launches that
-    accumulate in place into a 192-channel gradient buffer (LeakyReLU' fused as an epilogue mask)
-    and the matching deterministic split-K weight gradients, written straight into the flat
-    gradient buffer.
+  * backward is a hand-written schedule.  The data-gradient of a dense block runs as a "gradient
+    dense block", the mirror image of the forward: with the gradient buffer laid out
+    [g5 | g4 | g3 | g2 | g1] the gradient of each feature group is ONE convolution over a growing
+    channel prefix (K = 64..192, exactly the forward's shapes; LeakyReLU' fused as an epilogue mask)
+    instead of a chain of read-modify-write accumulations; the transposed/flipped weight slices are
+    packed by tnr_pack_dense_dgrad.  Weight gradients are deterministic split-K launches that write
+    straight into the flat gradient buffer.
 """
 import math
 
@@ -81,10 +84,13 @@ class RRDBNet(HipNet):
         m = self.model
         o = {"fea": ConvOp(m[0], packer, need_dgrad=False)}
         sub = m[1].sub
-        o["rdb"] = []
+        o["rdb"], o["rdb_dense"] = [], []
         for b in range(self.nb):
-            for r in (sub[b].RDB1, sub[b].RDB2, sub[b].RDB3):
-                o["rdb"].append([ConvOp(getattr(r, "conv%d" % k)[0], packer) for k in range(1, 6)])
+            for ri, r in enumerate((sub[b].RDB1, sub[b].RDB2, sub[b].RDB3)):
+                convs = [getattr(r, "conv%d" % k)[0] for k in range(1, 6)]
+                o["rdb"].append([ConvOp(c, packer, need_dgrad=False) for c in convs])
+                s = 0.2 if ri == 2 else 1.0      # RDB3's output is scaled by the RRDB residual (x0.2)
+                o["rdb_dense"].append(self._dense_packer.add_block([c.weight for c in convs], self.nf, self.gc, 0.2 * s))
         o["lr"] = ConvOp(sub[self.nb], packer)
         o["up"] = []
         idx = 2
@@ -155,29 +161,27 @@ class RRDBNet(HipNet):
             saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w))
         return out, saved
 
-    def _rdb_backward(self, convs, buf, gin, s, G, extra, want_w):
-        """Backward of one dense block.  gin: incoming gradient (64-ch view), s: its scale, G: 192-ch
-        gradient buffer to fill ([0:64) ends as the gradient w.r.t. the block input), extra: optional
-        view added to that result (the RRDB skip)."""
+    def _rdb_backward(self, convs, dense, buf, GP, s, gnext, extra, want_w):
+        """Backward of one dense block as a 'gradient dense block' (mirror of the forward).
+        GP: 192-ch gradient buffer whose [0:nf) holds the incoming gradient g (unscaled; the block's
+        residual scale s and conv5's 0.2 are folded into the packed weights).  Fills GP[nf:] with the
+        pre-activation gradients [g4 | g3 | g2 | g1] and writes the gradient w.r.t. the block input,
+        + s*g (+ extra, the RRDB skip), into `gnext` (64-ch view)."""
         nf, gc, sl = self.nf, self.gc, self.slope
-        cb = nf + 4 * gc
-        # conv5: G[0:192) = 0.2*s*dgrad5(gin); G[0:64) += s*gin; LeakyReLU' of x4 on channels [160,192)
-        convs[4].dgrad(gin, View(G, 0, cb), alpha=0.2 * s, r1=gin, r1_ch=nf, beta1=s,
-                       mask=View(buf), m_lo=cb - gc, m_hi=cb, m_slope=sl)
+        dp = self._dense_packer
+        for t in range(4):                       # targets x4, x3, x2, x1: LeakyReLU' fused as mask
+            cin = nf + t * gc
+            xk = View(buf, nf + (3 - t) * gc, gc)
+            ops.conv(View(GP, 0, cin), dp.get(dense[t]), View(GP, cin, gc), mask=xk, m_lo=0, m_hi=gc, m_slope=sl)
+        g = View(GP, 0, nf)
+        kw = dict(r2=extra, alpha2=1.0) if extra is not None else {}
+        ops.conv(View(GP), dp.get(dense[4]), gnext, r1=g, beta1=s, **kw)
         if want_w:
-            convs[4].wgrad(View(buf), gin, alpha=0.2 * s)
-        for k in (3, 2, 1, 0):                       # conv4 .. conv1
-            cin = nf + gc * k
-            gk = View(G, cin, gc)                     # final, already masked
-            acc = View(G, 0, cin)
-            kw = dict(alpha=1.0, r1=acc, beta1=1.0)
-            if k > 0:
-                kw.update(mask=View(buf), m_lo=cin - gc, m_hi=cin, m_slope=sl)
-            elif extra is not None:
-                kw.update(r2=extra, alpha2=1.0)
-            convs[k].dgrad(gk, acc, **kw)
-            if want_w:
-                if cin > 128:                        # 160 input channels: 96 + 64 (tile shapes of wgrad_tile.hip)
+            convs[4].wgrad(View(buf), g, alpha=0.2 * s)
+            for k in (3, 2, 1, 0):               # conv4 .. conv1: g_k lives at GP[nf + (3-k)*gc : +gc)
+                cin = nf + gc * k
+                gk = View(GP, nf + (3 - k) * gc, gc)
+                if cin > 128:                    # 160 input channels: 96 + 64 (tile shapes of wgrad_tile.hip)
                     convs[k].wgrad(View(buf, 0, 96), gk, cin_begin=0)
                     convs[k].wgrad(View(buf, 96, cin - 96), gk, cin_begin=96)
                 else:
@@ -229,13 +233,13 @@ class RRDBNet(HipNet):
         if W:
             o["lr"].wgrad(View(sv["trunk"]), gy0)
         o["lr"].dgrad(gy0, View(G[0], 0, nf))
-        pin = 0                                        # index of the buffer holding the incoming gradient
+        pin = 0                                        # buffer whose [0:nf) holds the incoming gradient
         for b in range(self.nb - 1, -1, -1):
             q, r = [i for i in range(3) if i != pin]
-            bufs, convs = sv["bufs"], o["rdb"]
-            self._rdb_backward(convs[3 * b + 2], bufs[3 * b + 2], View(G[pin], 0, nf), 0.2, G[q], None, W)
-            self._rdb_backward(convs[3 * b + 1], bufs[3 * b + 1], View(G[q], 0, nf), 1.0, G[r], None, W)
-            self._rdb_backward(convs[3 * b], bufs[3 * b], View(G[r], 0, nf), 1.0, G[q], View(G[pin], 0, nf), W)
+            bufs, convs, dense = sv["bufs"], o["rdb"], o["rdb_dense"]
+            self._rdb_backward(convs[3 * b + 2], dense[3 * b + 2], bufs[3 * b + 2], G[pin], 0.2, View(G[q], 0, nf), None, W)
+            self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W)
+            self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, View(G[q], 0, nf), View(G[pin], 0, nf), W)
             pin = q
         gfea = View(G[pin], 0, nf)
         ops.axpby(gfea, gy0, 1.0, 1.0)                 # ShortcutBlock: both branches reach fea

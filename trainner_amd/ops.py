@@ -8,7 +8,8 @@ import torch
 
 from . import hip
 from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
-                  PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView, ConvDesc, PackItem, WgradDesc)
+                  PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView, ConvDesc,
+                  DensePackItem, PackItem, WgradDesc)
 
 
 def round_up(a, b):
@@ -136,6 +137,62 @@ class WeightPacker:
             self._finalize()
         hip.check(hip.load().tnr_pack_weights(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
                   "pack_weights")
+
+
+class DensePacker:
+    """Packs the 'gradient dense block' slabs (tnr_pack_dense_dgrad) of every dense block of a network
+    with one launch.  add() takes the five conv weights of a block and the block's residual scale."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []          # (weights[5], t, nf, gc, scale5, ko, ki, n)
+        self.packed = []
+        self.table = None
+        self.max_out = 0
+
+    def add_block(self, weights, nf, gc, scale5):
+        """-> list of 5 job indices (t = 0..4)."""
+        lib = hip.load()
+        idx = []
+        for t in range(5):
+            ko, ki, n = hip.c_i(), hip.c_i(), hip.c_l()
+            hip.check(lib.tnr_pack_dense_dims(nf, gc, t, C.byref(ko), C.byref(ki), C.byref(n)), "pack_dense_dims")
+            self.jobs.append((list(weights), t, nf, gc, float(scale5), ko.value, ki.value, n.value))
+            self.packed.append(None)
+            idx.append(len(self.jobs) - 1)
+        self.table = None
+        return idx
+
+    def _finalize(self):
+        total = sum(round_up(j[7], 64) for j in self.jobs)
+        self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
+        items = (DensePackItem * len(self.jobs))()
+        off = 0
+        for i, (ws, t, nf, gc, sc, ko, ki, n) in enumerate(self.jobs):
+            seg = self.flat[off:off + n]
+            off += round_up(n, 64)
+            it = DensePackItem()
+            for k in range(5):
+                it.w[k] = ws[k].data_ptr()
+            it.wp, it.nf, it.gc, it.t, it.KoutP, it.KinP, it.scale5, it.n_out = seg.data_ptr(), nf, gc, t, ko, ki, sc, n
+            items[i] = it
+            self.packed[i] = Packed(seg, ko, ki, PACK_DENSE_DGRAD)
+            self.max_out = max(self.max_out, n)
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+        self._ptrs = [w.data_ptr() for j in self.jobs for w in j[0]]
+
+    def get(self, idx):
+        if self.table is None:
+            self._finalize()
+        return self.packed[idx]
+
+    def run(self):
+        if not self.jobs:
+            return
+        if self.table is None or [w.data_ptr() for j in self.jobs for w in j[0]] != self._ptrs:
+            self._finalize()
+        hip.check(hip.load().tnr_pack_dense_dgrad(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
+                  "pack_dense_dgrad")
 
 
 # ----------------------------------------------------------------------------------------------
