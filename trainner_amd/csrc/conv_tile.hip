@@ -177,9 +177,10 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         store_chunk();
         __syncthreads();
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase below
-        // ---- MFMA over taps x 16 channels
-#pragma unroll 1
-        for (int t = 0; t < NTAPS; ++t) {
+        // ---- MFMA over taps x 16 channels.  Explicit two-deep software pipeline over taps: the
+        // ds_read_b128 fragment fetches of tap t+1 are issued before the 8*NT*2 MFMAs of tap t (two
+        // register sets, statically indexed), so LDS latency never stalls the matrix pipe.
+        auto tap_offsets = [&](int t, int &tapoff, int &woff) {
             int pos_y, pos_x;
             if (DG2) {
                 pos_y = 1 + py - (t >> 1);
@@ -191,26 +192,49 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
                 pos_y = t / 3;
                 pos_x = t - pos_y * 3;
             }
-            const int tapoff = (pos_y * WT + pos_x) * PST;
-            const float *wt = s_w + t * NC * PST + boff;
+            tapoff = (pos_y * WT + pos_x) * PST;
+            woff = t * NC * PST + boff;
+        };
+        auto fetch = [&](int t, f32x4 (&fa)[2][CK / 8], f32x4 (&fb)[NT][CK / 8]) {
+            int tapoff, woff;
+            tap_offsets(t, tapoff, woff);
 #pragma unroll
             for (int kk = 0; kk < CK / 8; ++kk) {
-                f32x4 av[2], bv[NT];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    av[mi] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + kk * 8);
+                    fa[mi][kk] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + kk * 8);
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
-                    bv[nn] = *reinterpret_cast<const f32x4 *>(wt + nn * 32 * PST + kk * 8);
+                    fb[nn][kk] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + kk * 8);
+            }
+        };
+        auto mma = [&](const f32x4 (&fa)[2][CK / 8], const f32x4 (&fb)[NT][CK / 8]) {
+#pragma unroll
+            for (int kk = 0; kk < CK / 8; ++kk)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[nn][j], acc[mi][nn], 0, 0, 0);
-            }
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][kk][j], fb[nn][kk][j], acc[mi][nn], 0, 0, 0);
+        };
+        f32x4 fa0[2][CK / 8], fb0[NT][CK / 8], fa1[2][CK / 8], fb1[NT][CK / 8];
+        // sched_barrier(0) pins the fetches ABOVE the MFMA block they overlap with (the scheduler would
+        // otherwise sink them next to their first use to save registers)
+        fetch(0, fa0, fb0);
+#pragma unroll 1
+        for (int t = 0; t + 1 < NTAPS; t += 2) {
+            fetch(t + 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < NTAPS) fetch(t + 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (NTAPS & 1) mma(fa0, fb0);
     }
 
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)

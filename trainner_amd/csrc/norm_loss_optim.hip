@@ -80,16 +80,38 @@ __global__ void bn_partial_kernel(const float *z, int z_ct, int z_co, const floa
     }
 }
 
-__global__ void bn_fwd_finalize_kernel(const double *partial, int nblocks, int C, int64_t pixels, float *running_mean,
-                                       float *running_var, int64_t *num_batches, float momentum, float eps, float *save_mean,
-                                       float *save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        double s = 0, ss = 0;
-        for (int b = 0; b < nblocks; ++b) {
-            s += partial[((size_t)b * C + c) * 2 + 0];
-            ss += partial[((size_t)b * C + c) * 2 + 1];
+// Finalize kernels: 256 threads = 32 channels x 8 lanes; lane l sums partial blocks l, l+8, ... (the
+// loads of the 8 lanes are independent, so the ~500 partials cost ~60 dependent steps, not ~500), then
+// the lane sums are combined in a fixed order through LDS.
+__device__ __forceinline__ void bn_sum_partials(const double *partial, int nblocks, int C, int c, int sl, int el,
+                                                double (*sh)[2][33], double &s0, double &s1) {
+    double a = 0, b = 0;
+    if (c < C)
+        for (int q = sl; q < nblocks; q += 8) {
+            a += partial[((size_t)q * C + c) * 2 + 0];
+            b += partial[((size_t)q * C + c) * 2 + 1];
         }
+    sh[sl][0][el] = a;
+    sh[sl][1][el] = b;
+    __syncthreads();
+    s0 = 0;
+    s1 = 0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        s0 += sh[l][0][el];
+        s1 += sh[l][1][el];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_fwd_finalize_kernel(const double *partial, int nblocks, int C, int64_t pixels, float *running_mean, float *running_var,
+                       int64_t *num_batches, float momentum, float eps, float *save_mean, float *save_invstd) {
+    __shared__ double sh[8][2][33];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + el;
+    double s, ss;
+    bn_sum_partials(partial, nblocks, C, c, sl, el, sh, s, ss);
+    if (sl == 0 && c < C) {
         const double n = (double)pixels;
         const double mean = s / n;
         double var = ss / n - mean * mean;
@@ -102,7 +124,7 @@ __global__ void bn_fwd_finalize_kernel(const double *partial, int nblocks, int C
             running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
         }
     }
-    if (c == 0 && num_batches) *num_batches += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
 }
 
 __global__ void bn_fwd_apply_kernel(const float *z, int z_ct, int z_co, float *y, int y_ct, int y_co, int64_t pixels, int C,
@@ -125,15 +147,15 @@ __global__ void bn_fwd_apply_kernel(const float *z, int z_ct, int z_co, float *y
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double *partial, int nblocks, int C, const float *invstd, double *sums,
-                                       float *dgamma, float *dbeta, float acc_beta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        double s = 0, dot = 0;
-        for (int b = 0; b < nblocks; ++b) {
-            s += partial[((size_t)b * C + c) * 2 + 0];
-            dot += partial[((size_t)b * C + c) * 2 + 1];
-        }
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(const double *partial, int nblocks, int C, const float *invstd, double *sums, float *dgamma,
+                       float *dbeta, float acc_beta) {
+    __shared__ double sh[8][2][33];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + el;
+    double s, dot;
+    bn_sum_partials(partial, nblocks, C, c, sl, el, sh, s, dot);
+    if (sl == 0 && c < C) {
         sums[2 * c + 0] = s;
         sums[2 * c + 1] = dot;
         if (dgamma) {
@@ -404,7 +426,7 @@ extern "C" int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t 
     double *partial = (double *)ws;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblocks), dim3(256), lds, s, z.ptr, z.ctot, z.coff, nullptr, 0, 0, nullptr, 0,
                        0, nullptr, 0.f, pixels, C, ppb, partial);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(tnr_cdiv(C, 256)), dim3(256), 0, s, partial, nblocks, C, pixels,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(tnr_cdiv(C, 32)), dim3(256), 0, s, partial, nblocks, C, pixels,
                        running_mean, running_var, num_batches, momentum, eps, save_mean, save_invstd);
     hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, z.ptr, z.ctot, z.coff, y.ptr,
                        y.ctot, y.coff, pixels, C, gamma, beta, save_mean, save_invstd, act, slope);
@@ -424,7 +446,7 @@ extern "C" int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz
     double *sums = partial + (size_t)RED_BLOCKS * C * 2;
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblocks), dim3(256), lds, s, z.ptr, z.ctot, z.coff, gy.ptr, gy.ctot, gy.coff,
                        y.ptr, y.ctot, y.coff, save_mean, mslope, pixels, C, ppb, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tnr_cdiv(C, 256)), dim3(256), 0, s, partial, nblocks, C, save_invstd, sums,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tnr_cdiv(C, 32)), dim3(256), 0, s, partial, nblocks, C, save_invstd, sums,
                        dgamma, dbeta, acc_beta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
                        y.ctot, y.coff, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, gamma, save_mean,

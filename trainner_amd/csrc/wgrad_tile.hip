@@ -22,8 +22,22 @@ struct WgK {
     int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits;
 };
 
+// Two occupancy regimes (chosen by the accumulator count J = ceil(A_T*B_T*taps/4) per wave):
+//   J < 9  : <= 200 VGPRs, TWO workgroups per CU; staging loads are issued in batches of 8 float4 per
+//            thread and the other workgroup's MFMA phase hides their latency;
+//   J >= 9 : 144 accumulator VGPRs, ONE workgroup per CU with the whole 512-entry register file: the
+//            global loads of tile i+1 are all issued before the MFMA phase of tile i and written to LDS
+//            after it (issue-early / write-late), and the k-loop is unrolled 4 k-steps deep.
+template <int A_T, int B_T, int NTAPS_>
+struct WgCfg {
+    static constexpr int J = (A_T * B_T * NTAPS_ + 3) / 4;
+    static constexpr bool PIPE = J >= 9;
+    static constexpr int WAVES_PER_SIMD = PIPE ? 1 : 2;
+};
+
 template <int MODE, int A_T, int B_T, int THG>
-__global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
+__global__ void __launch_bounds__(256, (WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD))
+wgrad_tile_kernel(const WgK a) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
     constexpr int TWG = 16, PX = THG * TWG;
@@ -33,6 +47,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
     constexpr int COB = 32 * A_T, CIB = 32 * B_T;
     constexpr int AB = A_T * B_T;
     constexpr int T = AB * NTAPS, J = (T + 3) / 4;
+    constexpr bool PIPE = WgCfg<A_T, B_T, NTAPS>::PIPE;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_g = smem;             // PX * COB
@@ -72,136 +87,132 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
     int t_end = t_begin + a.tiles_per_split;
     if (t_end > a.tiles_total) t_end = a.tiles_total;
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // ---- staging: g tile [PX][COB] then x halo tile [HT*WT][CIB], one float4 per item
+    constexpr int G_ITEMS = PX * (COB / 4), G_IT = (G_ITEMS + 255) / 256;
+    constexpr int X_ITEMS = HT * WT * (CIB / 4), X_IT = (X_ITEMS + 255) / 256;
+    constexpr int N_IT = G_IT + X_IT;
+    constexpr int BATCH = PIPE ? N_IT : 8;
+    constexpr int NBATCH = (N_IT + BATCH - 1) / BATCH;
+    f32x4 rr[BATCH];
+    auto load_batch = [&](int tile, int batch) {
         int q = tile;
         const int tx = q % a.tiles_x;
         q /= a.tiles_x;
         const int ty = q % a.tiles_y;
         const int n = q / a.tiles_y;
         const int ty0 = ty * THG, tx0 = tx * TWG;
-        // ---- stage g tile [PX][COB] and x halo tile [HT*WT][CIB]: all global loads are issued back to
-        // back into registers (one latency, not one per item), then written to LDS
-        constexpr int G_ITEMS = PX * (COB / 4), G_IT = (G_ITEMS + 255) / 256;
-        constexpr int X_ITEMS = HT * WT * (CIB / 4), X_IT = (X_ITEMS + 255) / 256;
-        // Items (G first, then X) are processed in batches of BATCH float4 per thread: enough loads in
-        // flight to cover latency, few enough that staging registers + the accumulators stay < 256 VGPRs.
-        constexpr int N_IT = G_IT + X_IT;
-        constexpr int BATCH = (J >= 9) ? 5 : 8;
-        constexpr int NBATCH = (N_IT + BATCH - 1) / BATCH;
-        f32x4 rr[BATCH];
-        auto load_batch = [&](int batch) {
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int it = batch * BATCH + k;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (it < G_IT) {
-                    const int i = tid + it * 256;
-                    const int p = i / (COB / 4), c4 = i - p * (COB / 4);
-                    const int r = p / TWG, c = p - r * TWG;
-                    const int oy = ty0 + r, ox = tx0 + c;
-                    const int co = cob * COB + c4 * 4;
-                    if (i < G_ITEMS && oy < a.Ho && ox < a.Wo && co < a.Cout) {
-                        const int off = ((n * a.Ho + oy) * a.Wo + ox) * a.g_ct + a.g_co + co;
-                        v = *reinterpret_cast<const f32x4 *>(a.g + off);
-                    }
-                } else if (it < N_IT) {
-                    const int i = tid + (it - G_IT) * 256;
-                    const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
-                    const int hr = pix / WT, hc = pix - hr * WT;
-                    const int vb = cib * B_T + (c4 >> 3);  // global 32-wide virtual block index
-                    int Y, X, c;
-                    bool ok;
-                    if (S2D) {
-                        const int nb32 = a.cinp32 >> 5;
-                        const int pp = vb / nb32;
-                        c = (vb - pp * nb32) * 32 + (c4 & 7) * 4;
-                        Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
-                        X = 2 * (tx0 + hc) - 1 + (pp & 1);
-                        ok = (pp < 4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-                    } else if (UP) {
-                        c = vb * 32 + (c4 & 7) * 4;
-                        Y = ty0 + hr - 1;
-                        X = tx0 + hc - 1;
-                        ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
-                        Y >>= 1;
-                        X >>= 1;
-                    } else {
-                        c = vb * 32 + (c4 & 7) * 4;
-                        Y = ty0 + hr - 1;
-                        X = tx0 + hc - 1;
-                        ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
-                    }
-                    if (i < X_ITEMS && ok && c < a.Cin) {
-                        const int off = ((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c;
-                        v = *reinterpret_cast<const f32x4 *>(a.x + off);
-                    }
+        for (int k = 0; k < BATCH; ++k) {
+            const int it = batch * BATCH + k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (it < G_IT) {
+                const int i = tid + it * 256;
+                const int p = i / (COB / 4), c4 = i - p * (COB / 4);
+                const int r = p / TWG, c = p - r * TWG;
+                const int oy = ty0 + r, ox = tx0 + c;
+                const int co = cob * COB + c4 * 4;
+                if (i < G_ITEMS && oy < a.Ho && ox < a.Wo && co < a.Cout) {
+                    const int off = ((n * a.Ho + oy) * a.Wo + ox) * a.g_ct + a.g_co + co;
+                    v = *reinterpret_cast<const f32x4 *>(a.g + off);
                 }
-                rr[k] = v;
-            }
-        };
-        auto store_batch = [&](int batch) {
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int it = batch * BATCH + k;
-                if (it < G_IT) {
-                    const int i = tid + it * 256;
-                    if (i < G_ITEMS) *reinterpret_cast<f32x4 *>(s_g + i * 4) = rr[k];
-                } else if (it < N_IT) {
-                    const int i = tid + (it - G_IT) * 256;
-                    if (i < X_ITEMS) *reinterpret_cast<f32x4 *>(s_x + i * 4) = rr[k];
+            } else if (it < N_IT) {
+                const int i = tid + (it - G_IT) * 256;
+                const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
+                const int hr = pix / WT, hc = pix - hr * WT;
+                const int vb = cib * B_T + (c4 >> 3);  // global 32-wide virtual block index
+                int Y, X, c;
+                bool ok;
+                if (S2D) {
+                    const int nb32 = a.cinp32 >> 5;
+                    const int pp = vb / nb32;
+                    c = (vb - pp * nb32) * 32 + (c4 & 7) * 4;
+                    Y = 2 * (ty0 + hr) - 1 + (pp >> 1);
+                    X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                    ok = (pp < 4) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                } else if (UP) {
+                    c = vb * 32 + (c4 & 7) * 4;
+                    Y = ty0 + hr - 1;
+                    X = tx0 + hc - 1;
+                    ok = (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                    Y >>= 1;
+                    X >>= 1;
+                } else {
+                    c = vb * 32 + (c4 & 7) * 4;
+                    Y = ty0 + hr - 1;
+                    X = tx0 + hc - 1;
+                    ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                }
+                if (i < X_ITEMS && ok && c < a.Cin) {
+                    const int off = ((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + c;
+                    v = *reinterpret_cast<const f32x4 *>(a.x + off);
                 }
             }
-        };
-        load_batch(0);
-        __syncthreads();  // previous tile's fragments are consumed
-        store_batch(0);
-#pragma unroll
-        for (int bt = 1; bt < NBATCH; ++bt) {
-            load_batch(bt);
-            store_batch(bt);
+            rr[k] = v;
         }
-        __syncthreads();
-        // ---- K loop: two pixels per MFMA.  Operands of k-step s+1 are fetched from LDS before the
-        // MFMAs of k-step s are issued (explicit software pipeline), and there is no control flow in the
-        // loop body: J straight-line MFMAs per k-step.
-        auto frag_addr = [&](int s_, int &gbase, int &xbase) {
-            const int p = 2 * s_ + half;
-            const int r = p / TWG, c = p - r * TWG;
-            gbase = p * COB + li;
-            xbase = (r * WT + c) * CIB + li;
-        };
-        float a_cur[A_T], b_cur[J];
-        {
-            int gb, xb;
-            frag_addr(0, gb, xb);
+    };
+    auto store_batch = [&](int batch) {
 #pragma unroll
-            for (int aa = 0; aa < A_T; ++aa) a_cur[aa] = s_g[gb + aa * 32];
-#pragma unroll
-            for (int j = 0; j < J; ++j) b_cur[j] = s_x[xb + t_boff[j]];
+        for (int k = 0; k < BATCH; ++k) {
+            const int it = batch * BATCH + k;
+            if (it < G_IT) {
+                const int i = tid + it * 256;
+                if (i < G_ITEMS) *reinterpret_cast<f32x4 *>(s_g + i * 4) = rr[k];
+            } else if (it < N_IT) {
+                const int i = tid + (it - G_IT) * 256;
+                if (i < X_ITEMS) *reinterpret_cast<f32x4 *>(s_x + i * 4) = rr[k];
+            }
         }
-#pragma unroll 2
-        for (int s = 0; s < PX / 2; ++s) {
-            float a_nxt[A_T], b_nxt[J];
-            {
-                int gb, xb;
-                frag_addr(s + 1 < PX / 2 ? s + 1 : s, gb, xb);
+    };
+
+    if (PIPE && t_begin < t_end) load_batch(t_begin, 0);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (PIPE) {
+            __syncthreads();  // previous tile's fragments are consumed
+            store_batch(0);
+            __syncthreads();
+            if (tile + 1 < t_end) load_batch(tile + 1, 0);  // in flight during the MFMA phase below
+        } else {
+            load_batch(tile, 0);
+            __syncthreads();
+            store_batch(0);
 #pragma unroll
-                for (int aa = 0; aa < A_T; ++aa) a_nxt[aa] = s_g[gb + aa * 32];
-#pragma unroll
-                for (int j = 0; j < J; ++j) b_nxt[j] = s_x[xb + t_boff[j]];
+            for (int bt = 1; bt < NBATCH; ++bt) {
+                load_batch(tile, bt);
+                store_batch(bt);
             }
+            __syncthreads();
+        }
+        // ---- K loop: two pixels per MFMA, one tile row (16 pixels = 8 k-steps) per outer iteration.
+        // Inside a row every LDS address is row base + compile-time offset, so the unrolled body is
+        // ds_read (immediate offsets) + MFMA only; the scheduler hoists the reads of later k-steps above
+        // the MFMAs of earlier ones.
+#pragma unroll 1
+        for (int r = 0; r < THG; ++r) {
+            const float *gr = s_g + (r * TWG + half) * COB + li;
+            const float *xr = s_x + (r * WT + half) * CIB + li;
+            const float *xj[J];
 #pragma unroll
-            for (int aa = 0; aa < A_T; ++aa) bsum[aa] += a_cur[aa];
+            for (int j = 0; j < J; ++j) xj[j] = xr + t_boff[j];
+            constexpr int KU = PIPE ? 4 : 8;   // k-steps unrolled together
+#pragma unroll 1
+            for (int k0 = 0; k0 < TWG / 2; k0 += KU) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                float aval = a_cur[0];
-                if (A_T > 1) aval = t_aa[j] ? a_cur[A_T - 1] : a_cur[0];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, b_cur[j], acc[j], 0, 0, 0);
+                for (int kk = 0; kk < KU; ++kk) {
+                    const int k = k0 + kk;
+                    float av[A_T];
+#pragma unroll
+                    for (int aa = 0; aa < A_T; ++aa) {
+                        av[aa] = gr[2 * k * COB + aa * 32];
+                        bsum[aa] += av[aa];
+                    }
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        float aval = av[0];
+                        if (A_T > 1) aval = t_aa[j] ? av[A_T - 1] : av[0];
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, xj[j][2 * k * CIB], acc[j], 0, 0, 0);
+                    }
+                }
             }
-#pragma unroll
-            for (int aa = 0; aa < A_T; ++aa) a_cur[aa] = a_nxt[aa];
-#pragma unroll
-            for (int j = 0; j < J; ++j) b_cur[j] = b_nxt[j];
         }
     }
 
@@ -228,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_tile_kernel(const WgK a) {
         for (int aa = 0; aa < A_T; ++aa) {
             const float tot = bsum[aa] + __shfl_xor(bsum[aa], 32);
             const int co = cob * COB + aa * 32 + li;
-            if (half == 0 && co < a.KoutP) a.dbp[(size_t)split * a.KoutP + co] = tot;
+            if (half == 0 && co < a.KoutP) a.dbp[(size_t)co * a.nsplits + split] = tot;   // [co][split]
         }
     }
 }
@@ -248,6 +259,24 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
     __shared__ float sh[8][33];
     const int nblk = a.KinVP >> 5;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int nrows = a.ntaps * a.KoutP * nblk;
+    if ((int)blockIdx.x >= nrows) {
+        // bias blocks: 32 output channels each, the 8 split lanes stream dbp[co][split]
+        const int c = ((int)blockIdx.x - nrows) * 32 + el;
+        float part = 0.f;
+        if (c < a.Cout)
+            for (int q = sl; q < a.splits; q += 8) part += a.dbp[(size_t)c * a.splits + q];
+        sh[sl][el] = part;
+        __syncthreads();
+        if (sl == 0 && c < a.Cout) {
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) sum += sh[l][el];
+            const float prev = (a.beta != 0.f) ? a.beta * a.db[c] : 0.f;
+            a.db[c] = prev + a.alpha * sum;
+        }
+        return;
+    }
     const int row = blockIdx.x;                         // ((tap * KoutP) + co) * nblk + blk
     const int blk = row % nblk;
     const int co = (row / nblk) % a.KoutP;
@@ -286,16 +315,6 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
             a.dw[o] = prev + a.alpha * sum;
         }
     }
-    // bias: the first ceil(Cout/32) blocks also own 32 output channels each
-    if (a.db != nullptr && sl == 1) {
-        const int64_t c = (int64_t)blockIdx.x * 32 + el;
-        if (c < a.Cout) {
-            float sum = 0.f;
-            for (int q = 0; q < a.splits; ++q) sum += a.dbp[(size_t)q * a.KoutP + c];
-            const float prev = (a.beta != 0.f) ? a.beta * a.db[c] : 0.f;
-            a.db[c] = prev + a.alpha * sum;
-        }
-    }
 }
 
 struct WgPlan {
@@ -330,7 +349,9 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
     p.tiles_y = tnr_cdiv(d->Ho, p.thg);
     p.tiles_total = p.tiles_x * p.tiles_y * d->N;
     // enough workgroups for ~2 per CU, but never fewer than 4 tiles of work per split
-    int want = 512 / (p.ncib * p.ncob);   // <= 2 resident workgroups per CU, never a 513th straggler
+    const int J = (p.a_t * p.b_t * p.ntaps + 3) / 4;
+    const int resident = (J >= 9) ? 256 : 512;   // workgroups that fit the chip at once in this regime
+    int want = resident / (p.ncib * p.ncob);     // one full wave of workgroups, never a straggler
     if (want < 1) want = 1;
     int max_splits = tnr_cdiv(p.tiles_total, 4);
     if (max_splits < 1) max_splits = 1;
@@ -347,7 +368,7 @@ template <int MODE, int A_T, int B_T, int THG>
 int launch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH - 1) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
-    static_assert(lds <= 80 * 1024, "wgrad tile exceeds the 2-workgroups-per-CU LDS budget");
+    static_assert(lds <= 80 * 1024, "wgrad tile exceeds the LDS budget");
     static bool attr_done = false;
     auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG>;
     if (!attr_done) {
@@ -421,7 +442,8 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     r.cinp32 = p.cinp32; r.dw = d->dw; r.db = d->db; r.Cout = d->Cout; r.Cin = d->Cin; r.cin_total = d->cin_total;
     r.cin_begin = d->cin_begin; r.s2d = d->mode == TNR_CONV_4x4_S2;
     r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.alpha = d->alpha; r.beta = d->beta;
-    const int64_t rows = (int64_t)p.ntaps * p.KoutP * (p.KinVP / 32);    // >= Cout/32 blocks for the bias part
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, s, r);
+    const int64_t rows = (int64_t)p.ntaps * p.KoutP * (p.KinVP / 32);
+    const int bias_blocks = d->db ? tnr_cdiv(d->Cout, 32) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(rows + bias_blocks)), dim3(256), 0, s, r);
     return tnr_check_launch("wgrad_reduce");
 }
