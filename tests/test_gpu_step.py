@@ -128,3 +128,30 @@ def test_full_config_properties(tmp_path):
     assert torch.equal(fakes[0], fakes[1])
     assert torch.equal(fakes[0][:8], fakes[0][8:]), "identical images must map to identical outputs"
     assert torch.isfinite(gw).all()
+
+
+def test_dp_collectives_single_rank():
+    """The data-parallel code path (RCCL all-reduce of gradient buckets on a side stream overlapped with
+    backward, relativistic-sum exchange) executed for real in a 1-rank process group must reproduce the
+    plain single-process run bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "dp_selftest_worker.py")
+
+    def run(cmd, env):
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("DPSELF ")]
+        assert lines, out.stdout[-2000:] + out.stderr[-2000:]
+        return json.loads(lines[-1][7:])
+
+    env = dict(os.environ)
+    env.pop("TNR_DP_SELFTEST", None)
+    plain = run([sys.executable, worker], env)
+    env2 = dict(env, TNR_DP_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dp = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", str(29500 + os.getpid() % 400), worker], env2)
+    assert plain["active"] is False and dp["active"] is True
+    assert plain["logs"] == dp["logs"], (plain["logs"], dp["logs"])
+    assert plain["w"] == dp["w"]

@@ -31,9 +31,9 @@ struct ConvK {
     int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
 };
 
-template <int MODE, int TW, int NT>
+template <int MODE, int TW, int NT, int MT>
 __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
-    constexpr int TH = 256 / TW;
+    constexpr int TH = 128 * MT / TW;   // 4 waves x MT M-tiles of 32 pixels
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
@@ -70,19 +70,19 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     const int nck = a.KinP / CK;
     const int nchunks = S2D ? 4 * nck : nck;
 
-    // per-lane A offsets (dwords) of the two M-tiles this wave owns
-    int aoff[2];
+    // per-lane A offsets (dwords) of the MT M-tiles this wave owns
+    int aoff[MT];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int p = (wave * 2 + mi) * 32 + li;
+    for (int mi = 0; mi < MT; ++mi) {
+        const int p = (wave * MT + mi) * 32 + li;
         const int r = p / TW, c = p - r * TW;
         aoff[mi] = (r * WT + c) * PST + half * 4;
     }
     const int boff = li * PST + half * 4;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
@@ -195,33 +195,42 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
             tapoff = (pos_y * WT + pos_x) * PST;
             woff = t * NC * PST + boff;
         };
-        auto fetch = [&](int t, f32x4 (&fa)[2][CK / 8], f32x4 (&fb)[NT][CK / 8]) {
+        auto fetch = [&](int t, f32x4 (&fa)[MT][CK / 8], f32x4 (&fb)[NT][CK / 8]) {
             int tapoff, woff;
             tap_offsets(t, tapoff, woff);
 #pragma unroll
             for (int kk = 0; kk < CK / 8; ++kk) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
                     fa[mi][kk] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + kk * 8);
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
                     fb[nn][kk] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + kk * 8);
             }
         };
-        auto mma = [&](const f32x4 (&fa)[2][CK / 8], const f32x4 (&fb)[NT][CK / 8]) {
+        auto mma = [&](const f32x4 (&fa)[MT][CK / 8], const f32x4 (&fb)[NT][CK / 8]) {
 #pragma unroll
             for (int kk = 0; kk < CK / 8; ++kk)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
                             acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][kk][j], fb[nn][kk][j], acc[mi][nn], 0, 0, 0);
         };
-        f32x4 fa0[2][CK / 8], fb0[NT][CK / 8], fa1[2][CK / 8], fb1[NT][CK / 8];
+        f32x4 fa0[MT][CK / 8], fb0[NT][CK / 8], fa1[MT][CK / 8], fb1[NT][CK / 8];
         // sched_barrier(0) pins the fetches ABOVE the MFMA block they overlap with (the scheduler would
         // otherwise sink them next to their first use to save registers)
+        if (MT > 2) {
+            // 4 M-tiles per wave: one fragment set (register budget); 2 workgroups per CU cover the LDS latency
+#pragma unroll 1
+            for (int t = 0; t < NTAPS; ++t) {
+                fetch(t, fa0, fb0);
+                mma(fa0, fb0);
+            }
+            continue;
+        }
         fetch(0, fa0, fb0);
 #pragma unroll 1
         for (int t = 0; t + 1 < NTAPS; t += 2) {
@@ -246,11 +255,11 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         const bool use_r1 = (a.r1 != nullptr) && (co < a.r1_ch);
         const bool use_m = (a.m != nullptr) && (co >= a.m_lo) && (co < a.m_hi);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int p = (wave * 2 + mi) * 32 + i;
+                const int p = (wave * MT + mi) * 32 + i;
                 const int rr = p / TW, cc = p - rr * TW;
                 const int sy = ty0 + rr, sx = tx0 + cc;
                 if (!cok || sy >= a.th_space || sx >= a.tw_space) continue;
@@ -272,14 +281,14 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     }
 }
 
-template <int MODE, int TW, int NT>
+template <int MODE, int TW, int NT, int MT = 2>
 int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
-    constexpr int TH = 256 / TW;
+    constexpr int TH = 128 * MT / TW;
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
     constexpr size_t lds = (size_t)((TH + KH - 1) * (TW + KH - 1) + NTAPS * NT * 32) * TNR_PST * sizeof(float);
     static bool attr_done = false;
-    auto fn = conv_tile_kernel<MODE, TW, NT>;
+    auto fn = conv_tile_kernel<MODE, TW, NT, MT>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -340,14 +349,18 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     }
     k.th_space = sh; k.tw_space = sw;
     const int tw = sw >= 32 ? 32 : (sw >= 16 ? 16 : 8);
-    const int th = 256 / tw;
     const int nt = d->Cout > 32 ? 2 : 1;
+    // 32-cout 3x3 layers (the dense-block convs and their gradients): 4 M-tiles per wave (16x32 pixel
+    // tile) so the weight slab and the fixed per-workgroup costs are amortised like in the 64-cout kernel
+    const bool big_m = (d->mode == TNR_CONV_3x3) && nt == 1 && tw == 32 && sh >= 16;
+    const int th = (big_m ? 512 : 256) / tw;
     k.tiles_x = tnr_cdiv(sw, tw);
     k.tiles_y = tnr_cdiv(sh, th);
     k.ncb = tnr_cdiv(d->Cout, nt * 32);
     const int64_t tiles = (int64_t)k.tiles_x * k.tiles_y * k.ncb * d->N * (d->mode == TNR_DGRAD_4x4_S2 ? 4 : 1);
     TNR_REQUIRE(tiles > 0 && tiles < (1LL << 31), "conv: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (big_m) return launch_conv<TNR_CONV_3x3, 32, 1, 4>(k, (int)tiles, s);
     switch (d->mode) {
         case TNR_CONV_3x3: return dispatch_conv<TNR_CONV_3x3>(k, tw, nt, (int)tiles, s);
         case TNR_CONV_3x3_UP2: return dispatch_conv<TNR_CONV_3x3_UP2>(k, tw, nt, (int)tiles, s);

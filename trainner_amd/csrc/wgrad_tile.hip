@@ -337,8 +337,8 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
         p.b_t = vblocks >= 4 ? 4 : vblocks;
         if (vblocks == 5) p.b_t = 3;  // caller normally splits 160 = 96 + 64 itself
     }
-    // LDS budget (<= 80 KiB so two workgroups share a CU): (2,*) and (1,2) use 8x16 tiles
-    p.thg = (p.a_t == 2 || p.b_t <= 2) ? 8 : 4;
+    // LDS budget: two workgroups per CU (<= 80 KiB each) except the 1-workgroup regime (J >= 9, <= 160 KiB)
+    p.thg = (p.a_t == 2 || p.b_t <= 2 || (p.b_t == 4 && d->mode != TNR_CONV_4x4_S2)) ? 8 : 4;
     p.cinp32 = tnr_round_up(d->Cin, 32);
     p.KinVP = vch;
     p.KoutP = tnr_round_up(d->Cout, 32);
@@ -368,7 +368,8 @@ template <int MODE, int A_T, int B_T, int THG>
 int launch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH - 1) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
-    static_assert(lds <= 80 * 1024, "wgrad tile exceeds the LDS budget");
+    constexpr bool pipe = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::PIPE;
+    static_assert(lds <= (pipe ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
     auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG>;
     if (!attr_done) {
@@ -393,7 +394,11 @@ int dispatch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
         case 1: return launch_wgrad<MODE, 1, 1, 8>(k, p, s);
         case 2: return launch_wgrad<MODE, 1, 2, 8>(k, p, s);
         case 3: return launch_wgrad<MODE, 1, 3, 4>(k, p, s);
-        default: return launch_wgrad<MODE, 1, 4, 4>(k, p, s);
+        default:
+            if constexpr (MODE != TNR_CONV_4x4_S2) {
+                if (p.thg == 8) return launch_wgrad<MODE, 1, 4, 8>(k, p, s);
+            }
+            return launch_wgrad<MODE, 1, 4, 4>(k, p, s);
     }
 }
 

@@ -25,12 +25,15 @@ class DPGroup:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # TNR_DP_SELFTEST=1: run every collective even in a 1-rank group (exercises the RCCL / side-stream
+        # path on a single GPU; results must equal the plain run)
+        self.active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("TNR_DP_SELFTEST") == "1")
         self._side = None
         self._pending = []
 
     # ---------------------------------------------------------------- small forward exchanges
     def all_reduce_sum(self, t):
-        if self.world_size > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     # ---------------------------------------------------------------- gradient buckets
@@ -44,7 +47,7 @@ class DPGroup:
     def reduce_range_async(self, flat_grad, lo, hi):
         """All-reduce flat_grad[lo:hi] on the side stream, ordered after everything already enqueued
         on the compute stream (an event wait -- the host never blocks)."""
-        if self.world_size == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         seg = flat_grad[lo:hi]
         side = self._stream(flat_grad.device)
@@ -109,7 +112,8 @@ class BucketSchedule:
 def init_from_env():
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    selftest = os.environ.get("TNR_DP_SELFTEST") == "1" and "RANK" in os.environ
+    if (world > 1 or selftest) and not dist.is_initialized():
         use_cuda = torch.cuda.is_available()
         if use_cuda:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))

@@ -212,7 +212,7 @@ class BaseModel:
             self.cri_gan = True
             self.adversarial = Adversarial(train_opt=train_opt, device=self.device, diffaug=train_opt.get("diffaug"),
                                            conditional=conditional)
-            self.adversarial.dp_group = self.dp if self.dp.world_size > 1 else None
+            self.adversarial.dp_group = self.dp if self.dp.active else None
             self.D_update_ratio = train_opt.get("D_update_ratio", 1) or 1
             self.D_init_iters = train_opt.get("D_init_iters", 0) or 0
             logger.info("GAN enabled")
@@ -282,9 +282,16 @@ class BaseModel:
     def calc_gradients(self, loss):
         loss.backward()
 
+    def _arm_bucket_schedule(self, nets):
+        """Let the next backward pass of `nets` hand finished gradient buckets to RCCL while it is still
+        running (only when this backward completes the virtual batch: partial sums must not be reduced)."""
+        if self.dp.active and self.accumulations == 1:
+            for net in nets:
+                net._bucket_schedule = dpmod.BucketSchedule(self.dp, net.flat_params())
+
     def _sync_gradients(self, opt_flag):
         """Data-parallel exchange of the gradients the backward pass just produced."""
-        if self.dp.world_size == 1:
+        if not self.dp.active:
             return
         for net in self._opt_nets[opt_flag]:
             holder = net.flat_params()

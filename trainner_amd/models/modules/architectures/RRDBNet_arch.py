@@ -181,9 +181,12 @@ class RRDBNet(HipNet):
             for k in (3, 2, 1, 0):               # conv4 .. conv1: g_k lives at GP[nf + (3-k)*gc : +gc)
                 cin = nf + gc * k
                 gk = View(GP, nf + (3 - k) * gc, gc)
-                if cin > 128:                    # 160 input channels: 96 + 64 (tile shapes of wgrad_tile.hip)
-                    convs[k].wgrad(View(buf, 0, 96), gk, cin_begin=0)
-                    convs[k].wgrad(View(buf, 96, cin - 96), gk, cin_begin=96)
+                # 32-cout weight gradients run best as (32 x 64|96)-channel workgroup tiles (wgrad_tile.hip):
+                # 160 inputs = 96 + 64, 128 inputs = 64 + 64
+                if cin > 96:
+                    first = 96 if cin > 128 else 64
+                    convs[k].wgrad(View(buf, 0, first), gk, cin_begin=0)
+                    convs[k].wgrad(View(buf, first, cin - first), gk, cin_begin=first)
                 else:
                     convs[k].wgrad(View(buf, 0, cin), gk)
 
@@ -198,14 +201,22 @@ class RRDBNet(HipNet):
         ops.nchw_to_nhwc(gout, View(g4), Cpad=4)
         gh0 = View(new_act(N, cur.H, cur.W, nf, dev))
         o["hr1"].dgrad(View(g4), gh0, mask=h0, m_slope=sl)
+        sched = getattr(self, "_bucket_schedule", None) if W else None   # data-parallel gradient buckets (dp.py)
+
+        def done(op):
+            if sched is not None:
+                sched.mark_done(op.mod.weight)
+
         if W:
             o["hr1"].wgrad(h0, View(g4, 0, self.out_nc))
+            done(o["hr1"])
         gcur = View(new_act(N, cur.H, cur.W, nf, dev))
         last_stage = sv["stages"][-1] if sv["stages"] else None
         # gradient w.r.t. hr_in; it is an activation output only if an upsample stage produced it
         o["hr0"].dgrad(gh0, gcur, **(dict(mask=cur, m_slope=sl) if (last_stage and self.upsample_mode == "upconv") else {}))
         if W:
             o["hr0"].wgrad(cur, gh0)
+            done(o["hr0"])
         for si in range(len(sv["stages"]) - 1, -1, -1):
             src, dst, t = sv["stages"][si]
             u = o["up"][si]
@@ -214,6 +225,7 @@ class RRDBNet(HipNet):
                 # gcur = grad w.r.t. dst pre-activation (mask applied by the consumer's dgrad epilogue)
                 if W:
                     u.wgrad(src, gcur)
+                    done(u)
                 gup = View(new_act(N, dst.H, dst.W, nf, dev))
                 u.dgrad(gcur, gup)
                 gsrc = View(new_act(N, src.H, src.W, nf, dev))
@@ -223,6 +235,7 @@ class RRDBNet(HipNet):
                 ops.space_to_depth_bwd(gcur, gt, mask=dst, mslope=sl)
                 if W:
                     u.wgrad(src, gt)
+                    done(u)
                 gsrc = View(new_act(N, src.H, src.W, nf, dev))
                 u.dgrad(gt, gsrc)
             gcur = gsrc
@@ -232,6 +245,7 @@ class RRDBNet(HipNet):
         G = [new_act(N, h, w, cb, dev) for _ in range(3 if nrdb else 1)]
         if W:
             o["lr"].wgrad(View(sv["trunk"]), gy0)
+            done(o["lr"])
         o["lr"].dgrad(gy0, View(G[0], 0, nf))
         pin = 0                                        # buffer whose [0:nf) holds the incoming gradient
         for b in range(self.nb - 1, -1, -1):
@@ -241,6 +255,8 @@ class RRDBNet(HipNet):
             self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W)
             self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, View(G[q], 0, nf), View(G[pin], 0, nf), W)
             pin = q
+            if W:
+                done(convs[3 * b][0])                  # everything from this RRDB's first conv onwards is final
         gfea = View(G[pin], 0, nf)
         ops.axpby(gfea, gy0, 1.0, 1.0)                 # ShortcutBlock: both branches reach fea
         if W:

@@ -76,6 +76,7 @@ class SRModel(BaseModel):
             l_g_gan = self.adversarial(self.fake_H, self.var_ref, netD=self.netD, stage="generator", fsfilter=self.f_high)
             self.log_dict["l_g_gan"] = l_g_gan.detach()
             l_g_total = l_g_total + (l_g_gan if self.accumulations == 1 else l_g_gan / self.accumulations)
+        self._arm_bucket_schedule([self.netG])     # G's gradient buckets all-reduce while backward runs
         self.calc_gradients(l_g_total)
 
     def backward_D(self):
