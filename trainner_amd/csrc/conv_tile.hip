@@ -246,37 +246,64 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         if (NTAPS & 1) mma(fa0, fb0);
     }
 
-    // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    // ---- epilogue.  The MFMA result layout gives a lane ONE channel of 16 scattered pixels, which would
+    // mean 16*MT*NT four-byte global stores per lane (store-issue bound).  Instead each wave transposes its
+    // (MT*32 pixels) x (NT*32 channels) tile through LDS and every lane then owns float4s of 4 consecutive
+    // channels of one pixel: 16-byte loads of residuals / masks and 16-byte stores, 4x fewer memory
+    // instructions, whole 128/256-byte pixel rows per wave instruction.
+    __syncthreads();                                   // every wave is done with the operand tiles
+    float *s_o = smem + wave * (MT * 32 * NC);         // this wave's [MT*32][NC] tile (no padding needed)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) {
-        const int co = cb * NC + nn * 32 + li;
-        const bool cok = co < a.Cout;
-        const float bval = (a.bias != nullptr && cok) ? a.bias[co] : 0.f;
-        const bool use_r1 = (a.r1 != nullptr) && (co < a.r1_ch);
-        const bool use_m = (a.m != nullptr) && (co >= a.m_lo) && (co < a.m_hi);
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
+        for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int p = (wave * MT + mi) * 32 + i;
-                const int rr = p / TW, cc = p - rr * TW;
-                const int sy = ty0 + rr, sx = tx0 + cc;
-                if (!cok || sy >= a.th_space || sx >= a.tw_space) continue;
-                const int oy = DG2 ? 2 * sy + py : sy;
-                const int ox = DG2 ? 2 * sx + px : sx;
-                const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
-                float v = acc[mi][nn][r] + bval;
-                v = tnr_act(v, a.act, a.slope);
-                v = v * a.alpha;
-                if (use_r1) v = v + a.beta1 * a.r1[pix * a.r1_ct + a.r1_co + co];
-                if (a.r2 != nullptr) v = v * a.alpha2 + a.r2[pix * a.r2_ct + a.r2_co + co];
-                if (use_m) {
-                    const float mv = a.m[pix * a.m_ct + a.m_co + co];
-                    v *= (mv > 0.f ? 1.f : a.m_slope);
-                }
-                a.y[pix * a.y_ct + a.y_co + co] = v;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // D[i][j]: j = lane&31 (channel), i = pixel
+                s_o[(mi * 32 + i) * NC + nn * 32 + li] = acc[mi][nn][r];
             }
+    __syncthreads();
+    constexpr int C4 = NC / 4;                         // float4 per pixel row
+    constexpr int UNITS = MT * 32 * C4 / 64;           // float4 per lane
+#pragma unroll 4
+    for (int it = 0; it < UNITS; ++it) {
+        const int u = it * 64 + lane;
+        const int pl = u / C4, c4 = u - pl * C4;
+        const int p = wave * (MT * 32) + pl;
+        const int rr = p / TW, cc = p - rr * TW;
+        const int sy = ty0 + rr, sx = tx0 + cc;
+        const int co = cb * NC + c4 * 4;
+        if (co >= a.Cout || sy >= a.th_space || sx >= a.tw_space) continue;
+        const int oy = DG2 ? 2 * sy + py : sy;
+        const int ox = DG2 ? 2 * sx + px : sx;
+        const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(s_o + pl * NC + c4 * 4);
+        const bool full = co + 4 <= a.Cout;            // false only for the 3-channel image output
+        if (a.bias != nullptr) {
+            if (full) {
+                v += *reinterpret_cast<const f32x4 *>(a.bias + co);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (co + k < a.Cout) v[k] += a.bias[co + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = tnr_act(v[k], a.act, a.slope) * a.alpha;
+        if (a.r1 != nullptr && co < a.r1_ch) v += a.beta1 * *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
+        if (a.r2 != nullptr) v = v * a.alpha2 + *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
+        if (a.m != nullptr && co >= a.m_lo && co < a.m_hi) {
+            const f32x4 mv = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f ? 1.f : a.m_slope);
+        }
+        float *yp = a.y + pix * a.y_ct + a.y_co + co;
+        if (full) {
+            *reinterpret_cast<f32x4 *>(yp) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (co + k < a.Cout) yp[k] = v[k];
         }
     }
 }
@@ -286,7 +313,10 @@ int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
     constexpr int TH = 128 * MT / TW;
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
-    constexpr size_t lds = (size_t)((TH + KH - 1) * (TW + KH - 1) + NTAPS * NT * 32) * TNR_PST * sizeof(float);
+    constexpr size_t lds_main = (size_t)((TH + KH - 1) * (TW + KH - 1) + NTAPS * NT * 32) * TNR_PST * sizeof(float);
+    constexpr size_t lds_epi = (size_t)4 * MT * 32 * NT * 32 * sizeof(float);   // output transpose tiles of the 4 waves
+    constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    static_assert(lds <= 80 * 1024, "conv tile exceeds the 2-workgroups-per-CU LDS budget");
     static bool attr_done = false;
     auto fn = conv_tile_kernel<MODE, TW, NT, MT>;
     if (!attr_done) {
@@ -318,6 +348,14 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
     TNR_REQUIRE(d->Cin <= d->KinP && d->Cout <= d->KoutP, "conv: Cin/Cout exceed the packing");
     TNR_REQUIRE((int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 31), "conv: input buffer above 2^31 elements needs 64-bit offsets");
+    TNR_REQUIRE((d->y.ctot % 4) == 0 && (d->y.coff % 4) == 0, "conv: output view must be 4-channel aligned");
+    TNR_REQUIRE(d->r1.ptr == nullptr || ((d->r1.ctot % 4) == 0 && (d->r1.coff % 4) == 0 && (d->r1_ch % 4) == 0),
+                "conv: r1 view / r1_ch must be 4-channel aligned");
+    TNR_REQUIRE(d->r2.ptr == nullptr || ((d->r2.ctot % 4) == 0 && (d->r2.coff % 4) == 0), "conv: r2 view must be 4-channel aligned");
+    TNR_REQUIRE(d->m.ptr == nullptr || ((d->m.ctot % 4) == 0 && (d->m.coff % 4) == 0 && (d->m_lo % 4) == 0 && (d->m_hi % 4) == 0),
+                "conv: mask view / range must be 4-channel aligned");
+    TNR_REQUIRE(d->Cout % 4 == 0 || (d->r1.ptr == nullptr && d->r2.ptr == nullptr && d->m.ptr == nullptr),
+                "conv: residual / mask epilogues need Cout %% 4 == 0");
     ConvK k;
     k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
     k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;

@@ -72,7 +72,9 @@ class HipNet(torch.nn.Module):
         self._packer = None
         self._dense_packer = None
         self._packer_owner = None
+        self._packed_version = None
         self._ops = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._flat.touch())
 
     def flat_params(self):
         return self._flat.ensure()
@@ -88,9 +90,16 @@ class HipNet(torch.nn.Module):
             self._packer = ops.WeightPacker(x.device)
             self._dense_packer = ops.DensePacker(x.device)
             self._packer_owner = fp.flat
+            self._packed_version = None
             self._build_ops(self._packer)
-        self._packer.run()
-        self._dense_packer.run()
+        # parameters only change through FusedAdam.step / load_state_dict / re-flattening, all of which bump
+        # fp.version: the D (4 forwards per step) and the frozen VGG are not re-packed needlessly
+        # (fp.flat._version also moves on any in-place torch write through a parameter view)
+        key = (fp.version, fp.flat._version)
+        if self._packed_version != key:
+            self._packer.run()
+            self._dense_packer.run()
+            self._packed_version = key
 
     def forward(self, x, **kw):
         x = x.contiguous()

@@ -21,6 +21,10 @@ class FlatParams:
         self.grad = None
         self.offsets = []   # (param, offset, numel)
         self.total = 0
+        self.version = 0    # bumped whenever parameter VALUES may have changed (optimizer step, load, rebuild)
+
+    def touch(self):
+        self.version += 1
 
     def params(self):
         return [p for p in self.module.parameters()]
@@ -68,6 +72,7 @@ class FlatParams:
                 p.grad = g
                 p._tnr_flat = (self, o)
         self.flat, self.grad = flat, grad
+        self.version += 1
         return self
 
     def view_of(self, p, which="grad"):

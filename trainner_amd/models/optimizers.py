@@ -79,6 +79,7 @@ class FusedAdam(torch.optim.Optimizer):
                 m, v = self._moments[id(holder)]
                 ops.adam_step(holder.flat, holder.grad, m, v, group["lr"] / bc1, b1, b2, math.sqrt(bc2), group["eps"],
                               group["weight_decay"])
+                holder.touch()                       # packed weights of this network are stale now
             shared = torch.tensor(float(t))
             for p in group["params"]:
                 self.state[p]["step"] = shared
