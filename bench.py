@@ -132,6 +132,23 @@ def cpu_baseline(crop, steps=2):
                       "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps)}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the 3x3 conv family (average over its launches) from the newest committed
+    rocprofv3 --pmc summary (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command).  Counters cannot be read from inside the timed
+    process, so this is the recorded figure for the same kernels and shapes; None if no summary exists."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            return round(json.load(fh)["conv_tile_3x3"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,7 +225,7 @@ def main():
             per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
             roof = {"bound": "mfma", "kernel": "conv_tile_kernel<3x3> (forward + data-gradient launches)",
                     "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
