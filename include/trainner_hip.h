@@ -133,6 +133,13 @@ int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_
 int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
+/* n <= TNR_WGRAD_GROUP_MAX layers in ONE launch (+ one reduce launch).  The layers must share mode and
+ * N/H/W/Ho/Wo and fall into the same workgroup tile class (same Cout <= 32 | > 32 and the same number of
+ * 32-channel input blocks per workgroup: e.g. the 64-input pieces of a dense block's conv1/conv3/conv4);
+ * each needs its own workspace of tnr_wgrad_workspace_bytes().  Results equal n single launches up to
+ * the summation order of the split-K partials (still run-to-run deterministic).                     */
+#define TNR_WGRAD_GROUP_MAX 8
+int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
 /* --- layout / resampling (block.py:326-371 Upsample, :374-387,434-460 PixelShuffle; nn.MaxPool2d) */
 int tnr_nchw_to_nhwc(const float *src, int32_t N, int32_t C, int32_t H, int32_t W, tnr_view dst,

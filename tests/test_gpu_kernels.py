@@ -231,6 +231,44 @@ def test_wgrad_cin_split():
     close(dw.cpu(), ref, tol=5e-5, what="wgrad cin split")
 
 
+def test_wgrad_group_dense_block():
+    """The 64-input pieces of a dense block's conv1 / conv3 (2x) / conv4 in ONE launch, with biases,
+    alpha and beta, against autograd; then the error path for layers of different tile classes."""
+    ops = _ops()
+    N, H, W, nf, gc = 2, 24, 40, 64, 32
+    x = rnd(N, 192, H, W, seed=41)
+    gs = {k: rnd(N, gc, H, W, seed=42 + k) for k in (0, 2, 3)}
+    xb = nhwc_buf(x, 192, 0)
+    gbuf = torch.zeros((N, H, W, 192), device=DEV)
+    items, checks = [], []
+    for k, (lo, n) in ((0, (0, 64)), (2, (0, 64)), (2, (64, 64)), (3, (96, 64))):
+        cin = nf + gc * k
+        goff = nf + (3 - k) * gc
+        gbuf[..., goff:goff + gc] = gs[k].permute(0, 2, 3, 1).to(DEV)
+        key = "dw%d" % k
+        if key not in {c[0] for c in checks}:
+            w = torch.zeros(gc, cin, 3, 3, requires_grad=True)
+            (ref_w,) = torch.autograd.grad(F.conv2d(x[:, :cin], w, None, padding=1), w, gs[k])
+            dw0, db0 = rnd(gc, cin, 3, 3, seed=50 + k), rnd(gc, seed=60 + k)
+            dw, db = dw0.to(DEV), db0.to(DEV)
+            checks.append((key, dw, db, dw0 + 0.25 * ref_w, db0 + 0.25 * gs[k].sum(dim=(0, 2, 3)), lo, n, cin))
+        else:
+            (_, dw, db, *_r) = [c for c in checks if c[0] == key][0]
+        items.append(dict(x=ops.View(xb, lo, n), g=ops.View(gbuf, goff, gc), dw=dw, db=db if lo == 0 else None,
+                          cin_begin=lo, alpha=0.25, beta=1.0))
+    ops.wgrad_group(items)
+    for key, dw, db, ref_w, ref_b, lo, n, cin in checks:
+        covered = {0: (0, 64), 2: (0, 128), 3: (96, 160)}[int(key[2:])]
+        sl = slice(*covered)
+        scale = ref_w.abs().max().item() + 1.0
+        assert (dw.cpu()[:, sl] - ref_w[:, sl]).abs().max().item() <= 5e-5 * scale, key
+        if covered[0] == 0:
+            assert (db.cpu() - ref_b).abs().max().item() <= 5e-5 * (ref_b.abs().max().item() + 1), key + " bias"
+    with pytest.raises(RuntimeError, match="tile class"):
+        ops.wgrad_group([dict(x=ops.View(xb, 0, 64), g=ops.View(gbuf, 64, gc), dw=checks[0][1]),
+                         dict(x=ops.View(xb, 0, 96), g=ops.View(gbuf, 96, gc), dw=torch.zeros(gc, 96, 3, 3, device=DEV))])
+
+
 def test_layout_roundtrip_and_norm():
     ops = _ops()
     x = rnd(2, 3, 10, 14, seed=31)

@@ -13,13 +13,21 @@
 
 namespace {
 
-struct WgK {
-    const float *x; int x_ct, x_co; int N, H, W, Cin;
-    const float *g; int g_ct, g_co; int Ho, Wo, Cout;
-    float *ws; int KoutP, KinVP;  // slab dims
+// A launch carries up to TNR_WGRAD_GROUP_MAX layers that share the pixel geometry and the workgroup tile
+// class ("group"): blockIdx.y enumerates (layer, cin block, cout block), so the chip-filling split count
+// -- and with it the partial-slab round trip and the per-launch prologue -- is paid once per group
+// instead of once per layer.
+struct WgJob {
+    const float *x; const float *g; float *ws; float *dbp;   // dbp: partial bias sums [KoutP][split] or null
+    int x_ct, x_co, Cin, g_ct, g_co, Cout;
+    int KoutP, KinVP;             // slab dims
     int cinp32;                   // per-parity padded channel count (S2D); == KinVP otherwise
-    float *dbp;                   // partial bias sums [split][KoutP] or null
-    int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits;
+    int ncib, job_begin;          // blockIdx.y range of this layer: [job_begin, job_begin + ncib * ncob)
+};
+struct WgK {
+    int N, H, W, Ho, Wo;
+    int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits, njobs;
+    WgJob job[TNR_WGRAD_GROUP_MAX];
 };
 
 // Two occupancy regimes (chosen by the accumulator count J = ceil(A_T*B_T*taps/4) per wave):
@@ -31,13 +39,13 @@ struct WgK {
 template <int A_T, int B_T, int NTAPS_>
 struct WgCfg {
     static constexpr int J = (A_T * B_T * NTAPS_ + 3) / 4;
-    static constexpr bool PIPE = J >= 9;
-    static constexpr int WAVES_PER_SIMD = PIPE ? 1 : 2;
+    static constexpr bool PIPE = true;
+    static constexpr int WAVES_PER_SIMD = (J >= 9) ? 1 : 2;
 };
 
 template <int MODE, int A_T, int B_T, int THG>
 __global__ void __launch_bounds__(256, (WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD))
-wgrad_tile_kernel(const WgK a) {
+wgrad_tile_kernel(const WgK ga) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
     constexpr int TWG = 16, PX = THG * TWG;
@@ -56,10 +64,37 @@ wgrad_tile_kernel(const WgK a) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
     const int lane = tid & 63, li = lane & 31, half = lane >> 5;
-    const int split = blockIdx.x, cib = blockIdx.y, cob = blockIdx.z;
+    const int split = blockIdx.x;
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < TNR_WGRAD_GROUP_MAX; ++q)
+        if (q < ga.njobs && (int)blockIdx.y >= ga.job[q].job_begin) ji = q;
+    // flatten the per-launch + per-layer fields into the names the body uses (all wave-uniform scalars)
+    struct {
+        const float *x; int x_ct, x_co; int N, H, W, Cin;
+        const float *g; int g_ct, g_co; int Ho, Wo, Cout;
+        float *ws; int KoutP, KinVP, cinp32; float *dbp;
+        int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits;
+    } a;
+    a.x = ga.job[ji].x; a.x_ct = ga.job[ji].x_ct; a.x_co = ga.job[ji].x_co;
+    a.N = ga.N; a.H = ga.H; a.W = ga.W; a.Cin = ga.job[ji].Cin;
+    a.g = ga.job[ji].g; a.g_ct = ga.job[ji].g_ct; a.g_co = ga.job[ji].g_co;
+    a.Ho = ga.Ho; a.Wo = ga.Wo; a.Cout = ga.job[ji].Cout;
+    a.ws = ga.job[ji].ws; a.KoutP = ga.job[ji].KoutP; a.KinVP = ga.job[ji].KinVP; a.cinp32 = ga.job[ji].cinp32;
+    a.dbp = ga.job[ji].dbp;
+    a.tiles_x = ga.tiles_x; a.tiles_y = ga.tiles_y; a.tiles_total = ga.tiles_total;
+    a.tiles_per_split = ga.tiles_per_split; a.nsplits = ga.nsplits;
+    const int local = (int)blockIdx.y - ga.job[ji].job_begin;
+    const int ncib = ga.job[ji].ncib;
+    const int cob = local / ncib, cib = local - cob * ncib;
 
     // tile list of this wave (wave-uniform scalars)
-    int t_ok[J], t_tap[J], t_aa[J], t_boff[J];
+    // t = wave + 4 j  ->  (tap, aa, bb) = (t / AB, (t % AB) / B_T, (t % AB) % B_T).  With A_T == 2 the
+    // block count AB is 2 or 4, so t % AB == wave % AB: every tile of a wave uses the SAME cout half
+    // aa_w, and the wave reads a single A fragment per k-step.
+    static_assert(A_T == 1 || (4 % AB) == 0, "A_T == 2 needs AB in {2, 4}");
+    const int aa_w = (A_T == 1) ? 0 : (wave % AB) / B_T;
+    int t_ok[J], t_tap[J], t_boff[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int t = wave + 4 * j;
@@ -69,7 +104,6 @@ wgrad_tile_kernel(const WgK a) {
         const int aa = ab / B_T, bb = ab - aa * B_T;
         const int ty = tap / KH, tx = tap - ty * KH;
         t_tap[j] = tap * 1024 + aa * 32 + bb;  // packed for the store phase
-        t_aa[j] = aa;
         t_boff[j] = (ty * WT + tx) * CIB + bb * 32;  // slots beyond T alias tile 0: computed, never stored
     }
 
@@ -78,9 +112,7 @@ wgrad_tile_kernel(const WgK a) {
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float bsum[A_T];   // per-lane partial bias gradient: sum over pixels of g[p][aa*32 + li] (both pixel parities)
-#pragma unroll
-    for (int aa = 0; aa < A_T; ++aa) bsum[aa] = 0.f;
+    float bsum = 0.f;  // per-lane partial bias gradient: sum over pixels of g[p][aa_w*32 + li] (this lane's parity)
     const bool want_bias = (a.dbp != nullptr) && (cib == 0);
 
     const int t_begin = split * a.tiles_per_split;
@@ -182,36 +214,42 @@ wgrad_tile_kernel(const WgK a) {
             }
             __syncthreads();
         }
-        // ---- K loop: two pixels per MFMA, one tile row (16 pixels = 8 k-steps) per outer iteration.
-        // Inside a row every LDS address is row base + compile-time offset, so the unrolled body is
-        // ds_read (immediate offsets) + MFMA only; the scheduler hoists the reads of later k-steps above
-        // the MFMAs of earlier ones.
+        // ---- K loop: two pixels per MFMA, software-pipelined one k-step deep: the fragments of step
+        // k+1 (one A value, J B values per lane) are read into the second register set BEFORE the J MFMAs
+        // of step k are issued, so the LDS latency hides under >= J*64 matrix-core cycles even with a
+        // single wave per SIMD.  A tile row (16 pixels = 8 k-steps) is fully unrolled: every LDS address
+        // is row base + compile-time offset, including the first step of the next row.
+        {
+            // integer float-offsets into smem[] (keeps the accesses provably LDS: ds_read with immediates)
+            int go = half * COB + li + aa_w * 32;
+            int xo[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j];
+            float fa[2], fb[2][J];
+            fa[0] = smem[go];
+#pragma unroll
+            for (int j = 0; j < J; ++j) fb[0][j] = smem[xo[j]];
 #pragma unroll 1
-        for (int r = 0; r < THG; ++r) {
-            const float *gr = s_g + (r * TWG + half) * COB + li;
-            const float *xr = s_x + (r * WT + half) * CIB + li;
-            const float *xj[J];
+            for (int r = 0; r < THG; ++r) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) xj[j] = xr + t_boff[j];
-            constexpr int KU = PIPE ? 4 : 8;   // k-steps unrolled together
-#pragma unroll 1
-            for (int k0 = 0; k0 < TWG / 2; k0 += KU) {
+                for (int k = 0; k < TWG / 2; ++k) {
+                    const int cur = k & 1, nxt = cur ^ 1;
+                    // step k+1 of this row, or step 0 of the next row (row THG is valid LDS: never consumed)
+                    const int goff = (k + 1 < TWG / 2) ? 2 * (k + 1) * COB : TWG * COB;
+                    const int xoff = (k + 1 < TWG / 2) ? 2 * (k + 1) * CIB : WT * CIB;
+                    fa[nxt] = smem[go + goff];
 #pragma unroll
-                for (int kk = 0; kk < KU; ++kk) {
-                    const int k = k0 + kk;
-                    float av[A_T];
+                    for (int j = 0; j < J; ++j) fb[nxt][j] = smem[xo[j] + xoff];
+                    __builtin_amdgcn_sched_barrier(0);
+                    bsum += fa[cur];
 #pragma unroll
-                    for (int aa = 0; aa < A_T; ++aa) {
-                        av[aa] = gr[2 * k * COB + aa * 32];
-                        bsum[aa] += av[aa];
-                    }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        float aval = av[0];
-                        if (A_T > 1) aval = t_aa[j] ? av[A_T - 1] : av[0];
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, xj[j][2 * k * CIB], acc[j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < J; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                go += TWG * COB;
+#pragma unroll
+                for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
             }
         }
     }
@@ -234,38 +272,46 @@ wgrad_tile_kernel(const WgK a) {
                 a.ws[((((size_t)tap * a.KoutP + co) * nblk + blk) * a.nsplits + split) * 32 + li] = acc[j][r];
         }
     }
-    if (want_bias && wave == 0) {   // every wave accumulated the same sums; wave 0 publishes them
-#pragma unroll
-        for (int aa = 0; aa < A_T; ++aa) {
-            const float tot = bsum[aa] + __shfl_xor(bsum[aa], 32);
-            const int co = cob * COB + aa * 32 + li;
-            if (half == 0 && co < a.KoutP) a.dbp[(size_t)co * a.nsplits + split] = tot;   // [co][split]
-        }
+    // every wave accumulated the sums of its cout half; the first wave of each half (bb == 0) publishes
+    if (want_bias && wave < AB && (wave % B_T) == 0) {
+        const float tot = bsum + __shfl_xor(bsum, 32);
+        const int co = cob * COB + aa_w * 32 + li;
+        if (half == 0 && co < a.KoutP) a.dbp[(size_t)co * a.nsplits + split] = tot;   // [co][split]
     }
 }
 
-struct RedK {
-    const float *ws; const float *dbp;
-    int splits, ntaps, KoutP, KinVP, cinp32;
-    float *dw; float *db;
-    int Cout, Cin, cin_total, cin_begin, kh, kw, s2d;
+struct RedJob {
+    const float *ws; const float *dbp; float *dw; float *db;
+    int KoutP, KinVP, cinp32, Cout, Cin, cin_total, cin_begin;
+    int blk_begin, nrows;         // blockIdx.x range [blk_begin, blk_begin + nrows + bias blocks)
     float alpha, beta;
+};
+struct RedK {
+    int splits, ntaps, kh, kw, s2d, njobs;
+    RedJob job[TNR_WGRAD_GROUP_MAX];
 };
 
 // One block per slab row (tap, co, 32-channel block): 256 threads = 32 channels x 8 split lanes.  The
 // row's partials [split][32] are contiguous, so the 8 lanes stream 1 KiB per step; lane sums are combined
 // in a fixed order through LDS (deterministic).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
     __shared__ float sh[8][33];
+    int ji = 0;
+#pragma unroll
+    for (int q = 1; q < TNR_WGRAD_GROUP_MAX; ++q)
+        if (q < ga.njobs && (int)blockIdx.x >= ga.job[q].blk_begin) ji = q;
+    const RedJob &a = ga.job[ji];
+    const int bx = (int)blockIdx.x - a.blk_begin;
+    const int splits = ga.splits;
     const int nblk = a.KinVP >> 5;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int nrows = a.ntaps * a.KoutP * nblk;
-    if ((int)blockIdx.x >= nrows) {
+    const int nrows = a.nrows;
+    if (bx >= nrows) {
         // bias blocks: 32 output channels each, the 8 split lanes stream dbp[co][split]
-        const int c = ((int)blockIdx.x - nrows) * 32 + el;
+        const int c = (bx - nrows) * 32 + el;
         float part = 0.f;
         if (c < a.Cout)
-            for (int q = sl; q < a.splits; q += 8) part += a.dbp[(size_t)c * a.splits + q];
+            for (int q = sl; q < splits; q += 8) part += a.dbp[(size_t)c * splits + q];
         sh[sl][el] = part;
         __syncthreads();
         if (sl == 0 && c < a.Cout) {
@@ -277,20 +323,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
         }
         return;
     }
-    const int row = blockIdx.x;                         // ((tap * KoutP) + co) * nblk + blk
+    const int row = bx;                                 // ((tap * KoutP) + co) * nblk + blk
     const int blk = row % nblk;
     const int co = (row / nblk) % a.KoutP;
     const int tap = row / (nblk * a.KoutP);
-    const float *src = a.ws + (size_t)row * a.splits * 32 + el;
+    const float *src = a.ws + (size_t)row * splits * 32 + el;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
     int s = sl;
-    for (; s + 24 < a.splits; s += 32) {                // four independent loads in flight per lane
+    for (; s + 24 < splits; s += 32) {                  // four independent loads in flight per lane
         p0 += src[(size_t)s * 32];
         p1 += src[(size_t)(s + 8) * 32];
         p2 += src[(size_t)(s + 16) * 32];
         p3 += src[(size_t)(s + 24) * 32];
     }
-    for (; s < a.splits; s += 8) p0 += src[(size_t)s * 32];
+    for (; s < splits; s += 8) p0 += src[(size_t)s * 32];
     sh[sl][el] = (p0 + p1) + (p2 + p3);
     __syncthreads();
     if (sl == 0) {
@@ -299,18 +345,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK a) {
         for (int l = 0; l < 8; ++l) sum += sh[l][el];
         const int civ = blk * 32 + el;
         int ci, ky, kx;
-        if (a.s2d) {
+        if (ga.s2d) {
             const int pp = civ / a.cinp32;
             ci = civ - pp * a.cinp32;
             ky = 2 * (tap >> 1) + (pp >> 1);
             kx = 2 * (tap & 1) + (pp & 1);
         } else {
             ci = civ;
-            ky = tap / a.kw;
-            kx = tap - ky * a.kw;
+            ky = tap / ga.kw;
+            kx = tap - ky * ga.kw;
         }
         if (co < a.Cout && ci < a.Cin) {
-            const size_t o = (((size_t)co * a.cin_total + a.cin_begin + ci) * a.kh + ky) * a.kw + kx;
+            const size_t o = (((size_t)co * a.cin_total + a.cin_begin + ci) * ga.kh + ky) * ga.kw + kx;
             const float prev = (a.beta != 0.f) ? a.beta * a.dw[o] : 0.f;
             a.dw[o] = prev + a.alpha * sum;
         }
@@ -322,11 +368,13 @@ struct WgPlan {
     int ncib, ncob;
     int KoutP, KinVP, cinp32;
     int tiles_x, tiles_y, tiles_total, splits, tiles_per_split;
-    int ntaps;
+    int ntaps, resident;
     int64_t ws_floats, db_floats;
 };
 
-int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
+// Tile class and slab geometry of one layer; the split count is chosen for `group_jobs` (cin block, cout
+// block) pairs sharing the launch (0: this layer alone).
+int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     const bool s2d = d->mode == TNR_CONV_4x4_S2;
     p.a_t = d->Cout > 32 ? 2 : 1;
     const int vch = s2d ? 4 * tnr_round_up(d->Cin, 32) : tnr_round_up(d->Cin, 32);
@@ -348,12 +396,12 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
     p.tiles_x = tnr_cdiv(d->Wo, 16);
     p.tiles_y = tnr_cdiv(d->Ho, p.thg);
     p.tiles_total = p.tiles_x * p.tiles_y * d->N;
-    // enough workgroups for ~2 per CU, but never fewer than 4 tiles of work per split
     const int J = (p.a_t * p.b_t * p.ntaps + 3) / 4;
-    const int resident = (J >= 9) ? 256 : 512;   // workgroups that fit the chip at once in this regime
-    int want = resident / (p.ncib * p.ncob);     // one full wave of workgroups, never a straggler
+    p.resident = (J >= 9) ? 256 : 512;           // workgroups that fit the chip at once in this regime
+    const int jobs = group_jobs > 0 ? group_jobs : p.ncib * p.ncob;
+    int want = p.resident / jobs;                // one full wave of workgroups, never a straggler
     if (want < 1) want = 1;
-    int max_splits = tnr_cdiv(p.tiles_total, 4);
+    int max_splits = tnr_cdiv(p.tiles_total, 4); // never fewer than 4 tiles of work per split
     if (max_splits < 1) max_splits = 1;
     p.splits = want < max_splits ? want : max_splits;
     if (p.splits < 1) p.splits = 1;
@@ -365,11 +413,12 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p) {
 }
 
 template <int MODE, int A_T, int B_T, int THG>
-int launch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
+int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
-    constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH - 1) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
-    constexpr bool pipe = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::PIPE;
-    static_assert(lds <= (pipe ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
+    // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
+    constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
+    constexpr bool one_wg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD == 1;
+    static_assert(lds <= (one_wg ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
     auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG>;
     if (!attr_done) {
@@ -380,39 +429,30 @@ int launch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(fn, dim3(p.splits, p.ncib, p.ncob), dim3(256), lds, s, k);
+    hipLaunchKernelGGL(fn, dim3(k.nsplits, jobs, 1), dim3(256), lds, s, k);
     return tnr_check_launch("wgrad_tile");
 }
 
 template <int MODE>
-int dispatch_wgrad(const WgK &k, const WgPlan &p, hipStream_t s) {
+int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
     if (p.a_t == 2) {
-        if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, p, s);
-        return launch_wgrad<MODE, 2, 1, 8>(k, p, s);
+        if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, jobs, s);
+        return launch_wgrad<MODE, 2, 1, 8>(k, jobs, s);
     }
     switch (p.b_t) {
-        case 1: return launch_wgrad<MODE, 1, 1, 8>(k, p, s);
-        case 2: return launch_wgrad<MODE, 1, 2, 8>(k, p, s);
-        case 3: return launch_wgrad<MODE, 1, 3, 4>(k, p, s);
+        case 1: return launch_wgrad<MODE, 1, 1, 8>(k, jobs, s);
+        case 2: return launch_wgrad<MODE, 1, 2, 8>(k, jobs, s);
+        case 3: return launch_wgrad<MODE, 1, 3, 4>(k, jobs, s);
         default:
             if constexpr (MODE != TNR_CONV_4x4_S2) {
-                if (p.thg == 8) return launch_wgrad<MODE, 1, 4, 8>(k, p, s);
+                if (p.thg == 8) return launch_wgrad<MODE, 1, 4, 8>(k, jobs, s);
             }
-            return launch_wgrad<MODE, 1, 4, 4>(k, p, s);
+            return launch_wgrad<MODE, 1, 4, 4>(k, jobs, s);
     }
 }
 
-}  // namespace
-
-extern "C" int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d) {
-    if (d == nullptr) return 0;
-    WgPlan p;
-    plan_wgrad(d, p);
-    return (p.ws_floats + p.db_floats) * (int64_t)sizeof(float);
-}
-
-extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
-    TNR_REQUIRE(d != nullptr && d->x.ptr && d->g.ptr && d->dw && d->ws, "wgrad: null pointer");
+int check_wgrad_desc(const tnr_wgrad_desc *d) {
+    TNR_REQUIRE(d->x.ptr && d->g.ptr && d->dw && d->ws, "wgrad: null pointer");
     TNR_REQUIRE(d->mode == TNR_CONV_3x3 || d->mode == TNR_CONV_3x3_UP2 || d->mode == TNR_CONV_4x4_S2,
                 "wgrad: bad mode %d", d->mode);
     TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->g.ctot % 4) == 0 && (d->g.coff % 4) == 0,
@@ -423,32 +463,83 @@ extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
     if (d->mode == TNR_CONV_4x4_S2) TNR_REQUIRE(2 * d->Ho == d->H && 2 * d->Wo == d->W, "wgrad4x4s2: size mismatch");
     TNR_REQUIRE((int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 31) && (int64_t)d->N * d->Ho * d->Wo * d->g.ctot < (1LL << 31),
                 "wgrad: buffers above 2^31 elements need 64-bit offsets");
+    return TNR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d) {
+    if (d == nullptr) return 0;
     WgPlan p;
-    plan_wgrad(d, p);
-    TNR_REQUIRE((p.ws_floats + p.db_floats) * (int64_t)sizeof(float) <= d->ws_bytes, "wgrad: workspace too small (%lld < %lld)",
-                (long long)d->ws_bytes, (long long)((p.ws_floats + p.db_floats) * sizeof(float)));
+    plan_wgrad(d, p, 0);   // a layer alone uses the most splits: this bound also covers any group
+    return (p.ws_floats + p.db_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream) {
+    TNR_REQUIRE(descs != nullptr && n >= 1 && n <= TNR_WGRAD_GROUP_MAX, "wgrad_group: 1..%d layers per group", TNR_WGRAD_GROUP_MAX);
+    WgPlan plans[TNR_WGRAD_GROUP_MAX];
+    int jobs = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = check_wgrad_desc(&descs[i]);
+        if (rc != TNR_OK) return rc;
+        plan_wgrad(&descs[i], plans[i], 0);
+        jobs += plans[i].ncib * plans[i].ncob;
+        const tnr_wgrad_desc &d0 = descs[0], &di = descs[i];
+        TNR_REQUIRE(di.mode == d0.mode && di.N == d0.N && di.H == d0.H && di.W == d0.W && di.Ho == d0.Ho && di.Wo == d0.Wo,
+                    "wgrad_group: layer %d does not share the pixel geometry of layer 0", i);
+        TNR_REQUIRE(plans[i].a_t == plans[0].a_t && plans[i].b_t == plans[0].b_t && plans[i].thg == plans[0].thg,
+                    "wgrad_group: layer %d (%d->%d channels) is not in the tile class of layer 0 (%d->%d)", i, di.Cin,
+                    di.Cout, d0.Cin, d0.Cout);
+    }
+    TNR_REQUIRE(jobs <= 65535, "wgrad_group: too many channel blocks");
     WgK k;
-    k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff; k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
-    k.g = d->g.ptr; k.g_ct = d->g.ctot; k.g_co = d->g.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
-    k.ws = d->ws; k.KoutP = p.KoutP; k.KinVP = p.KinVP; k.cinp32 = p.cinp32;
-    k.dbp = d->db ? d->ws + p.ws_floats : nullptr;
-    k.tiles_x = p.tiles_x; k.tiles_y = p.tiles_y; k.tiles_total = p.tiles_total; k.tiles_per_split = p.tiles_per_split;
-    k.nsplits = p.splits;
+    RedK r;
+    int job_begin = 0, blk_begin = 0;
+    for (int i = 0; i < n; ++i) {
+        const tnr_wgrad_desc *d = &descs[i];
+        WgPlan &p = plans[i];
+        if (n > 1) plan_wgrad(d, p, jobs);
+        TNR_REQUIRE(p.splits == plans[0].splits && p.tiles_per_split == plans[0].tiles_per_split, "wgrad_group: split mismatch");
+        TNR_REQUIRE((p.ws_floats + p.db_floats) * (int64_t)sizeof(float) <= d->ws_bytes,
+                    "wgrad: workspace too small (%lld < %lld)", (long long)d->ws_bytes,
+                    (long long)((p.ws_floats + p.db_floats) * sizeof(float)));
+        for (int q = 0; q < i; ++q) TNR_REQUIRE(descs[q].ws != d->ws, "wgrad_group: layers %d and %d share a workspace", q, i);
+        WgJob &j = k.job[i];
+        j.x = d->x.ptr; j.x_ct = d->x.ctot; j.x_co = d->x.coff; j.Cin = d->Cin;
+        j.g = d->g.ptr; j.g_ct = d->g.ctot; j.g_co = d->g.coff; j.Cout = d->Cout;
+        j.ws = d->ws; j.dbp = d->db ? d->ws + p.ws_floats : nullptr;
+        j.KoutP = p.KoutP; j.KinVP = p.KinVP; j.cinp32 = p.cinp32;
+        j.ncib = p.ncib; j.job_begin = job_begin;
+        job_begin += p.ncib * p.ncob;
+        RedJob &q = r.job[i];
+        q.ws = d->ws; q.dbp = j.dbp; q.dw = d->dw; q.db = d->db;
+        q.KoutP = p.KoutP; q.KinVP = p.KinVP; q.cinp32 = p.cinp32; q.Cout = d->Cout; q.Cin = d->Cin;
+        q.cin_total = d->cin_total; q.cin_begin = d->cin_begin; q.alpha = d->alpha; q.beta = d->beta;
+        q.blk_begin = blk_begin;
+        q.nrows = p.ntaps * p.KoutP * (p.KinVP / 32);
+        blk_begin += q.nrows + (d->db ? tnr_cdiv(d->Cout, 32) : 0);
+    }
+    for (int i = n; i < TNR_WGRAD_GROUP_MAX; ++i) { k.job[i] = k.job[0]; r.job[i] = r.job[0]; }
+    const tnr_wgrad_desc &d0 = descs[0];
+    const WgPlan &p0 = plans[0];
+    k.N = d0.N; k.H = d0.H; k.W = d0.W; k.Ho = d0.Ho; k.Wo = d0.Wo;
+    k.tiles_x = p0.tiles_x; k.tiles_y = p0.tiles_y; k.tiles_total = p0.tiles_total;
+    k.tiles_per_split = p0.tiles_per_split; k.nsplits = p0.splits; k.njobs = n;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (d->mode) {
-        case TNR_CONV_3x3: rc = dispatch_wgrad<TNR_CONV_3x3>(k, p, s); break;
-        case TNR_CONV_3x3_UP2: rc = dispatch_wgrad<TNR_CONV_3x3_UP2>(k, p, s); break;
-        default: rc = dispatch_wgrad<TNR_CONV_4x4_S2>(k, p, s); break;
+    switch (d0.mode) {
+        case TNR_CONV_3x3: rc = dispatch_wgrad<TNR_CONV_3x3>(k, p0, jobs, s); break;
+        case TNR_CONV_3x3_UP2: rc = dispatch_wgrad<TNR_CONV_3x3_UP2>(k, p0, jobs, s); break;
+        default: rc = dispatch_wgrad<TNR_CONV_4x4_S2>(k, p0, jobs, s); break;
     }
     if (rc != TNR_OK) return rc;
-    RedK r;
-    r.ws = d->ws; r.dbp = k.dbp; r.splits = p.splits; r.ntaps = p.ntaps; r.KoutP = p.KoutP; r.KinVP = p.KinVP;
-    r.cinp32 = p.cinp32; r.dw = d->dw; r.db = d->db; r.Cout = d->Cout; r.Cin = d->Cin; r.cin_total = d->cin_total;
-    r.cin_begin = d->cin_begin; r.s2d = d->mode == TNR_CONV_4x4_S2;
-    r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.alpha = d->alpha; r.beta = d->beta;
-    const int64_t rows = (int64_t)p.ntaps * p.KoutP * (p.KinVP / 32);
-    const int bias_blocks = d->db ? tnr_cdiv(d->Cout, 32) : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(rows + bias_blocks)), dim3(256), 0, s, r);
+    r.splits = p0.splits; r.ntaps = p0.ntaps; r.s2d = d0.mode == TNR_CONV_4x4_S2;
+    r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.njobs = n;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blk_begin), dim3(256), 0, s, r);
     return tnr_check_launch("wgrad_reduce");
+}
+
+extern "C" int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream) {
+    TNR_REQUIRE(d != nullptr, "wgrad: null descriptor");
+    return tnr_conv_wgrad_group(d, 1, stream);
 }

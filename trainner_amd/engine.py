@@ -33,10 +33,14 @@ class ConvOp:
         """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
         ops.conv(g, self.packer.get(self.i_d), gx, mode=self.mode_d, **epi)
 
-    def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+    def wgrad_item(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+        """Descriptor of dW[:, cin_begin : cin_begin + x.C] (+ db) += alpha * (g (x) x) for ops.wgrad_group."""
         w = self.mod.weight
         db = self.mod.bias.grad if (with_bias and self.mod.bias is not None and cin_begin == 0) else None
-        ops.wgrad(x, g, w.grad, db, mode=self.mode_f, cin_begin=cin_begin, alpha=alpha, beta=1.0)
+        return dict(x=x, g=g, dw=w.grad, db=db, cin_begin=cin_begin, alpha=alpha, beta=1.0)
+
+    def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+        ops.wgrad_group([self.wgrad_item(x, g, alpha, cin_begin, with_bias)], mode=self.mode_f)
 
 
 class _NetFn(torch.autograd.Function):

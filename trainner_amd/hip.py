@@ -69,6 +69,7 @@ _SIGS = {
     "tnr_conv_forward": (c_i, [C.POINTER(ConvDesc), c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
     "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
+    "tnr_conv_wgrad_group": (c_i, [C.POINTER(WgradDesc), c_i, c_p]),
     "tnr_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, CView, c_i, c_p, c_p, c_p]),
     "tnr_nhwc_to_nchw": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "tnr_upsample2x_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),

@@ -178,17 +178,20 @@ class RRDBNet(HipNet):
         ops.conv(View(GP), dp.get(dense[4]), gnext, r1=g, beta1=s, **kw)
         if want_w:
             convs[4].wgrad(View(buf), g, alpha=0.2 * s)
-            for k in (3, 2, 1, 0):               # conv4 .. conv1: g_k lives at GP[nf + (3-k)*gc : +gc)
+            # conv1..conv4 (32 couts; g_k lives at GP[nf + (3-k)*gc : +gc)) as 32 x 64 and 32 x 96 channel
+            # workgroup tiles (wgrad_tile.hip): 128 inputs = 64 + 64, 160 inputs = 96 + 64.  Pieces of one
+            # tile class share a launch, so a block costs 3 weight-gradient launches instead of 7.
+            groups = {}
+            for k in (3, 2, 1, 0):
                 cin = nf + gc * k
                 gk = View(GP, nf + (3 - k) * gc, gc)
-                # 32-cout weight gradients run best as (32 x 64|96)-channel workgroup tiles (wgrad_tile.hip):
-                # 160 inputs = 96 + 64, 128 inputs = 64 + 64
-                if cin > 96:
-                    first = 96 if cin > 128 else 64
-                    convs[k].wgrad(View(buf, 0, first), gk, cin_begin=0)
-                    convs[k].wgrad(View(buf, first, cin - first), gk, cin_begin=first)
-                else:
-                    convs[k].wgrad(View(buf, 0, cin), gk)
+                first = cin if cin <= 96 else (96 if cin > 128 else 64)
+                pieces = [(0, first)] + ([(first, cin - first)] if cin > first else [])
+                for lo, n in pieces:
+                    groups.setdefault(n, []).append(convs[k].wgrad_item(View(buf, lo, n), gk, cin_begin=lo))
+            for items in groups.values():
+                for i in range(0, len(items), ops.WGRAD_GROUP_MAX):
+                    ops.wgrad_group(items[i:i + ops.WGRAD_GROUP_MAX])
 
     def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
         o, nf, gc, sl = self._ops, self.nf, self.gc, self.slope

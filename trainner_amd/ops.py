@@ -263,10 +263,10 @@ def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0,
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
 
 
-def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
-    """dw (OIHW, full tensor) += alpha * sum g (x) x over input channels [cin_begin, cin_begin+x.C)."""
-    lib = hip.load()
-    d = WgradDesc()
+WGRAD_GROUP_MAX = 8
+
+
+def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.g = g.c()
@@ -275,16 +275,37 @@ def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
     d.dw, d.cin_total, d.cin_begin = dw.data_ptr(), dw.shape[1], cin_begin
     d.db = hip.ptr(db)
     d.alpha, d.beta = alpha, beta
-    need = lib.tnr_wgrad_workspace_bytes(C.byref(d))
-    ws = WS.get("wgrad", need, x.buf.device)
-    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
+
+
+def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
+    """dw (OIHW, full tensor) += alpha * sum g (x) x over input channels [cin_begin, cin_begin+x.C)."""
+    wgrad_group([dict(x=x, g=g, dw=dw, db=db, cin_begin=cin_begin, alpha=alpha, beta=beta)], mode=mode)
+
+
+def wgrad_group(items, mode=CONV_3x3):
+    """Several weight gradients of one pixel geometry and one workgroup tile class in a single launch
+    (tnr_conv_wgrad_group).  items: dicts with x, g, dw and optional db, cin_begin, alpha, beta."""
+    lib = hip.load()
+    n = len(items)
+    assert 1 <= n <= WGRAD_GROUP_MAX
+    descs = (WgradDesc * n)()
+    for d, it in zip(descs, items):
+        _wgrad_desc(d, it["x"], it["g"], it["dw"], it.get("db"), mode, it.get("cin_begin", 0),
+                    it.get("alpha", 1.0), it.get("beta", 1.0))
+    dev = items[0]["x"].buf.device
+    for i, d in enumerate(descs):
+        need = lib.tnr_wgrad_workspace_bytes(C.byref(d))
+        ws = WS.get("wgrad%d" % i, need, dev)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
     if PROFILE is None:
-        hip.check(lib.tnr_conv_wgrad(C.byref(d), hip.stream()), "conv_wgrad")
+        hip.check(lib.tnr_conv_wgrad_group(descs, n, hip.stream()), "conv_wgrad_group")
         return
     t0 = PROFILE.begin()
-    hip.check(lib.tnr_conv_wgrad(C.byref(d), hip.stream()), "conv_wgrad")
+    hip.check(lib.tnr_conv_wgrad_group(descs, n, hip.stream()), "conv_wgrad_group")
     taps = 16 if mode == CONV_4x4_S2 else 9
-    PROFILE.end("wgrad_tile", 2.0 * g.pixels * taps * x.C * g.C, t0, (x.C, g.C, g.H, mode))
+    x0, g0 = items[0]["x"], items[0]["g"]
+    flops = sum(2.0 * it["g"].pixels * taps * it["x"].C * it["g"].C for it in items)
+    PROFILE.end("wgrad_tile", flops, t0, (sum(it["x"].C for it in items) if n > 1 else x0.C, g0.C, g0.H, mode + 100 * (n - 1)))
 
 
 # ----------------------------------------------------------------------------------------------
