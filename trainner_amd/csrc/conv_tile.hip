@@ -177,10 +177,16 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         store_chunk();
         __syncthreads();
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase below
-        // ---- MFMA over taps x 16 channels.  Explicit two-deep software pipeline over taps: the
-        // ds_read_b128 fragment fetches of tap t+1 are issued before the 8*NT*2 MFMAs of tap t (two
-        // register sets, statically indexed), so LDS latency never stalls the matrix pipe.
-        auto tap_offsets = [&](int t, int &tapoff, int &woff) {
+        // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
+        // 8-channel group: MT + NT ds_read_b128 feeding 4*MT*NT MFMAs (>= 1024 matrix-core cycles).  The
+        // fragments of step s+1 are read into the other register set BEFORE the MFMAs of step s issue, so
+        // a wave keeps the matrix pipe busy on its own; sched_barrier(0) pins that order (the scheduler
+        // would otherwise sink the reads next to their first use).  All steps are unrolled: every LDS
+        // address is a per-lane base + compile-time offset.
+        constexpr int KG = CK / 8, NSTEP = NTAPS * KG;
+        f32x4 fa[2][MT], fb[2][NT];
+        auto fetch = [&](int s_, int set) {
+            const int t = s_ / KG, kk = s_ - t * KG;
             int pos_y, pos_x;
             if (DG2) {
                 pos_y = 1 + py - (t >> 1);
@@ -192,58 +198,30 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
                 pos_y = t / 3;
                 pos_x = t - pos_y * 3;
             }
-            tapoff = (pos_y * WT + pos_x) * PST;
-            woff = t * NC * PST + boff;
-        };
-        auto fetch = [&](int t, f32x4 (&fa)[MT][CK / 8], f32x4 (&fb)[NT][CK / 8]) {
-            int tapoff, woff;
-            tap_offsets(t, tapoff, woff);
+            const int tapoff = (pos_y * WT + pos_x) * PST + kk * 8;
+            const int woff = t * NC * PST + boff + kk * 8;
 #pragma unroll
-            for (int kk = 0; kk < CK / 8; ++kk) {
+            for (int mi = 0; mi < MT; ++mi) fa[set][mi] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff);
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) fb[set][nn] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
-                    fa[mi][kk] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + kk * 8);
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn)
-                    fb[nn][kk] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + kk * 8);
-            }
+                    for (int nn = 0; nn < NT; ++nn)
+                        acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mi][j], fb[set][nn][j], acc[mi][nn], 0, 0, 0);
         };
-        auto mma = [&](const f32x4 (&fa)[MT][CK / 8], const f32x4 (&fb)[NT][CK / 8]) {
+        fetch(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < CK / 8; ++kk)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][kk][j], fb[nn][kk][j], acc[mi][nn], 0, 0, 0);
-        };
-        f32x4 fa0[MT][CK / 8], fb0[NT][CK / 8], fa1[MT][CK / 8], fb1[NT][CK / 8];
-        // sched_barrier(0) pins the fetches ABOVE the MFMA block they overlap with (the scheduler would
-        // otherwise sink them next to their first use to save registers)
-        if (MT > 2) {
-            // 4 M-tiles per wave: one fragment set (register budget); 2 workgroups per CU cover the LDS latency
-#pragma unroll 1
-            for (int t = 0; t < NTAPS; ++t) {
-                fetch(t, fa0, fb0);
-                mma(fa0, fb0);
-            }
-            continue;
-        }
-        fetch(0, fa0, fb0);
-#pragma unroll 1
-        for (int t = 0; t + 1 < NTAPS; t += 2) {
-            fetch(t + 1, fa1, fb1);
+        for (int s_ = 0; s_ < NSTEP; ++s_) {
+            if (s_ + 1 < NSTEP) fetch(s_ + 1, (s_ + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < NTAPS) fetch(t + 2, fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(fa1, fb1);
+            mma(s_ & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (NTAPS & 1) mma(fa0, fb0);
     }
 
     // ---- epilogue.  The MFMA result layout gives a lane ONE channel of 16 scattered pixels, which would
