@@ -1,0 +1,63 @@
+// Probe: per-workgroup timeline of conv_tile launches (s_memtime stamps: entry, first chunk in LDS, main loop
+// done, epilogue issued).  Shows how much of a launch is prologue / epilogue / ragged tail.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DTNR_TIMELINE tools/probes/conv_timeline.hip -o tools/probes/conv_timeline
+#include "../../trainner_amd/csrc/pack_api.hip"
+#include "../../trainner_amd/csrc/conv_tile.hip"
+#include <algorithm>
+#include <vector>
+
+static void run(int Cin, int Cout, int N, int H, int W) {
+    const size_t px = (size_t)N * H * W;
+    float *x, *y, *wp, *bias;
+    const int KinP = (Cin + 15) / 16 * 16, KoutP = (Cout + 31) / 32 * 32;
+    hipMalloc(&x, px * 192 * 4);
+    hipMalloc(&y, px * KoutP * 4);
+    hipMalloc(&wp, (size_t)9 * KoutP * KinP * 4);
+    hipMalloc(&bias, KoutP * 4);
+    hipMemset(x, 0, px * 192 * 4);
+    hipMemset(wp, 0, (size_t)9 * KoutP * KinP * 4);
+    hipMemset(bias, 0, KoutP * 4);
+    tnr_conv_desc d = {};
+    d.x.ptr = x; d.x.ctot = 192; d.x.coff = 0; d.N = N; d.H = H; d.W = W; d.Cin = Cin;
+    d.wp = wp; d.KinP = KinP; d.KoutP = KoutP;
+    d.y.ptr = y; d.y.ctot = KoutP; d.y.coff = 0; d.Ho = H; d.Wo = W; d.Cout = Cout;
+    d.mode = TNR_CONV_3x3; d.bias = bias; d.act = 1; d.slope = 0.2f; d.alpha = 1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) tnr_conv_forward(&d, nullptr);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, nullptr);
+    if (tnr_conv_forward(&d, nullptr) != 0) { printf("error: %s\n", tnr_last_error()); return; }
+    hipEventRecord(e1, nullptr);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(8 * 8192);
+    hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tnr_timeline), h.size() * 8);
+    const int tiles = (int)(px / (Cout > 32 ? 256 : 512));
+    // per-XCD clocks may differ in offset: report per-workgroup deltas and, per XCD (b % 8), the span
+    std::vector<double> pro, mainl, epi, tot, p_issue, e_bar1, e_tr, e_bar2, e_store;
+    for (int b = 0; b < tiles && b < 8192; ++b) {
+        const unsigned long long *t = &h[b * 8];
+        pro.push_back((double)(t[1] - t[0])); mainl.push_back((double)(t[2] - t[1])); epi.push_back((double)(t[3] - t[2]));
+        tot.push_back((double)(t[3] - t[0]));
+        p_issue.push_back((double)(t[4] - t[0])); e_bar1.push_back((double)(t[5] - t[2])); e_tr.push_back((double)(t[6] - t[5]));
+        e_bar2.push_back((double)(t[7] - t[6])); e_store.push_back((double)(t[3] - t[7]));
+    }
+    auto stat = [](std::vector<double> v, const char *n) {
+        std::sort(v.begin(), v.end());
+        double s = 0; for (double q : v) s += q;
+        printf("   %-9s mean %9.0f  min %9.0f  p50 %9.0f  max %9.0f ticks\n", n, s / v.size(), v.front(), v[v.size() / 2], v.back());
+    };
+    printf("conv %d->%d  N=%d %dx%d  tiles=%d  event time %.1f us\n", Cin, Cout, N, H, W, tiles, ms * 1e3);
+    stat(pro, "prologue"); stat(p_issue, " p.issue"); stat(mainl, "main"); stat(epi, "epilogue");
+    stat(e_bar1, " e.bar1"); stat(e_tr, " e.transp"); stat(e_bar2, " e.bar2"); stat(e_store, " e.store"); stat(tot, "total");
+    hipFree(x); hipFree(y); hipFree(wp); hipFree(bias);
+}
+
+int main() {
+    run(160, 32, 16, 128, 128);
+    run(64, 32, 16, 128, 128);
+    run(192, 64, 16, 128, 128);
+    return 0;
+}

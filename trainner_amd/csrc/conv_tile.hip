@@ -31,8 +31,16 @@ struct ConvK {
     int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
 };
 
+#ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps */
+__device__ unsigned long long tnr_timeline[8 * 8192];
+#define TNR_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TNR_STAMP(i) do { } while (0)
+#endif
+
 template <int MODE, int TW, int NT, int MT>
 __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
+    TNR_STAMP(0);
     constexpr int TH = 128 * MT / TW;   // 4 waves x MT M-tiles of 32 pixels
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
@@ -172,10 +180,12 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     };
 
     load_chunk(0);
+    TNR_STAMP(4);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();  // previous chunk's fragments are consumed
         store_chunk();
         __syncthreads();
+        if (chunk == 0) TNR_STAMP(1);
         if (chunk + 1 < nchunks) load_chunk(chunk + 1);  // in flight during the MFMA phase below
         // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
         // 8-channel group: MT + NT ds_read_b128 feeding 4*MT*NT MFMAs (>= 1024 matrix-core cycles).  The
@@ -229,7 +239,9 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     // (MT*32 pixels) x (NT*32 channels) tile through LDS and every lane then owns float4s of 4 consecutive
     // channels of one pixel: 16-byte loads of residuals / masks and 16-byte stores, 4x fewer memory
     // instructions, whole 128/256-byte pixel rows per wave instruction.
+    TNR_STAMP(2);
     __syncthreads();                                   // every wave is done with the operand tiles
+    TNR_STAMP(5);
     float *s_o = smem + wave * (MT * 32 * NC);         // this wave's [MT*32][NC] tile (no padding needed)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -240,50 +252,86 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // D[i][j]: j = lane&31 (channel), i = pixel
                 s_o[(mi * 32 + i) * NC + nn * 32 + li] = acc[mi][nn][r];
             }
+    TNR_STAMP(6);
     __syncthreads();
+    TNR_STAMP(7);
     constexpr int C4 = NC / 4;                         // float4 per pixel row
     constexpr int UNITS = MT * 32 * C4 / 64;           // float4 per lane
-#pragma unroll 4
-    for (int it = 0; it < UNITS; ++it) {
-        const int u = it * 64 + lane;
-        const int pl = u / C4, c4 = u - pl * C4;
-        const int p = wave * (MT * 32) + pl;
-        const int rr = p / TW, cc = p - rr * TW;
-        const int sy = ty0 + rr, sx = tx0 + cc;
-        const int co = cb * NC + c4 * 4;
-        if (co >= a.Cout || sy >= a.th_space || sx >= a.tw_space) continue;
-        const int oy = DG2 ? 2 * sy + py : sy;
-        const int ox = DG2 ? 2 * sx + px : sx;
-        const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(s_o + pl * NC + c4 * 4);
-        const bool full = co + 4 <= a.Cout;            // false only for the 3-channel image output
-        if (a.bias != nullptr) {
-            if (full) {
-                v += *reinterpret_cast<const f32x4 *>(a.bias + co);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (co + k < a.Cout) v[k] += a.bias[co + k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = tnr_act(v[k], a.act, a.slope) * a.alpha;
-        if (a.r1 != nullptr && co < a.r1_ch) v += a.beta1 * *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
-        if (a.r2 != nullptr) v = v * a.alpha2 + *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
-        if (a.m != nullptr && co >= a.m_lo && co < a.m_hi) {
-            const f32x4 mv = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f ? 1.f : a.m_slope);
-        }
-        float *yp = a.y + pix * a.y_ct + a.y_co + co;
+    constexpr int G = 4, NG = UNITS / G;               // units are handled in groups of 4
+    static_assert(UNITS % G == 0 && 64 % C4 == 0, "epilogue grouping");
+    // 64 % C4 == 0: a lane keeps the same channel quad for all its units
+    const int c4 = lane % C4, co = cb * NC + c4 * 4;
+    const bool co_ok = co < a.Cout;
+    const bool full = co + 4 <= a.Cout;                // false only for the 3-channel image output
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && co_ok) {
         if (full) {
-            *reinterpret_cast<f32x4 *>(yp) = v;
+            bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (co + k < a.Cout) yp[k] = v[k];
+                if (co + k < a.Cout) bv[k] = a.bias[co + k];
         }
     }
+    const bool use_r1 = a.r1 != nullptr && co < a.r1_ch;
+    const bool use_r2 = a.r2 != nullptr;
+    const bool use_m = a.m != nullptr && co >= a.m_lo && co < a.m_hi;
+    // Residual / mask loads of group g+1 are issued BEFORE the stores of group g (two register sets): on
+    // gfx9 stores count in vmcnt like loads, so a load placed after a store in program order makes its
+    // consumer wait for that store's acknowledgement -- serialising the whole tail on write latency.
+    bool ok[2][G];
+    size_t pixi[2][G];
+    f32x4 q1[2][G], q2[2][G], qm[2][G];
+    auto prep = [&](int g, int set) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int pl = (g * G + k) * (64 / C4) + lane / C4;
+            const int p = wave * (MT * 32) + pl;
+            const int rr = p / TW, cc = p - rr * TW;
+            const int sy = ty0 + rr, sx = tx0 + cc;
+            ok[set][k] = co_ok && sy < a.th_space && sx < a.tw_space;
+            const int oy = DG2 ? 2 * sy + py : sy;
+            const int ox = DG2 ? 2 * sx + px : sx;
+            const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+            pixi[set][k] = pix;
+            if (ok[set][k]) {
+                if (use_r1) q1[set][k] = *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
+                if (use_r2) q2[set][k] = *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
+                if (use_m) qm[set][k] = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
+            }
+        }
+    };
+    auto finish = [&](int g, int set) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            if (!ok[set][k]) continue;
+            const int pl = (g * G + k) * (64 / C4) + lane / C4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(s_o + pl * NC + c4 * 4) + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tnr_act(v[e], a.act, a.slope) * a.alpha;
+            if (use_r1) v += a.beta1 * q1[set][k];
+            if (use_r2) v = v * a.alpha2 + q2[set][k];
+            if (use_m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (qm[set][k][e] > 0.f ? 1.f : a.m_slope);
+            }
+            float *yp = a.y + pixi[set][k] * a.y_ct + a.y_co + co;
+            if (full) {
+                *reinterpret_cast<f32x4 *>(yp) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < a.Cout) yp[e] = v[e];
+            }
+        }
+    };
+    prep(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) prep(g + 1, (g + 1) & 1);
+        finish(g, g & 1);
+    }
+    TNR_STAMP(3);
 }
 
 template <int MODE, int TW, int NT, int MT = 2>
@@ -293,8 +341,12 @@ int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
     constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
     constexpr size_t lds_main = (size_t)((TH + KH - 1) * (TW + KH - 1) + NTAPS * NT * 32) * TNR_PST * sizeof(float);
     constexpr size_t lds_epi = (size_t)4 * MT * 32 * NT * 32 * sizeof(float);   // output transpose tiles of the 4 waves
+#ifdef TNR_DEBUG_LDS_PAD   /* experiment knob: force one workgroup per CU */
+    constexpr size_t lds = (lds_main > lds_epi ? lds_main : lds_epi) + TNR_DEBUG_LDS_PAD;
+#else
     constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
     static_assert(lds <= 80 * 1024, "conv tile exceeds the 2-workgroups-per-CU LDS budget");
+#endif
     static bool attr_done = false;
     auto fn = conv_tile_kernel<MODE, TW, NT, MT>;
     if (!attr_done) {

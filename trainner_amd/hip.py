@@ -106,7 +106,8 @@ class HipEngineError(RuntimeError):
 
 
 def library_path():
-    return _build.LIB
+    """In-tree build by default; TNR_HIP_LIB points at another build of the same C ABI (kernel experiments)."""
+    return os.environ.get("TNR_HIP_LIB") or _build.LIB
 
 
 def load(build_if_missing=False):
