@@ -131,6 +131,20 @@ int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out,
 int tnr_pack_dense_dims(int32_t nf, int32_t gc, int32_t t, int32_t *KoutP, int32_t *KinP, int64_t *n_out);
 int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
 int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
+/* n <= TNR_CHAIN_MAX dependent 3x3 convolutions over one pixel grid in ONE launch: the five convolutions of a
+ * ResidualDenseBlock_5C (RRDBNet_arch.py:150-163) or of its gradient mirror.  Stage i may read what stages
+ * < i of the same call wrote: fresh_from[i] is the first input channel of stage i that stage i-1 produced
+ * (-1: none; channels below it must predate the call or come from stages <= i-2).  A workgroup keeps its
+ * 16x32-pixel tile through all stages and waits, at that channel, for the 8 neighbouring tiles (3x3 halo)
+ * through per-tile progress counters in ws (tnr_conv_chain_workspace_bytes(), zeroed once; the last word
+ * becomes nonzero if a wait ever gave up).  epoch must grow by 1 per call on the same ws.  Every stage:
+ * mode TNR_CONV_3x3, same N/H/W, Cout % 32 == 0, KoutP == Cout; epilogues as in tnr_conv_forward.  Outputs of
+ * different stages must not overlap, and no stage may write channels another stage of the call reads
+ * before its fresh_from point.  Results are bit-identical to n tnr_conv_forward calls.                    */
+#define TNR_CHAIN_MAX 6
+int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *stage0);
+int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,
+                   uint32_t epoch, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 /* n <= TNR_WGRAD_GROUP_MAX layers in ONE launch (+ one reduce launch).  The layers must share mode and

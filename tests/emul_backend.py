@@ -308,13 +308,18 @@ def adam_step(p, g, m, v, step_size, b1, b2, bc2_sqrt, eps, wd=0.0):
     p.addcdiv_(m, v.sqrt() / bc2_sqrt + eps, value=-step_size)
 
 
+def conv_chain(stages):
+    for st in stages:
+        conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+
+
 def wgrad_group(items, mode=ops.CONV_3x3):
     for it in items:
         wgrad(it["x"], it["g"], it["dw"], it.get("db"), mode=mode, cin_begin=it.get("cin_begin", 0),
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
 
 
-_NAMES = ["conv", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

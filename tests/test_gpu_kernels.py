@@ -231,6 +231,54 @@ def test_wgrad_cin_split():
     close(dw.cpu(), ref, tol=5e-5, what="wgrad cin split")
 
 
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 16, 32), (3, 128, 128)])
+def test_conv_chain_equals_per_layer_launches(shape):
+    """A dense block's five convolutions (fused LeakyReLU, residual epilogue) as one tnr_conv_chain launch must
+    equal five tnr_conv_forward launches bit for bit -- including across tile borders (neighbour hand-off)
+    and with more tiles than one residency round is not needed here: (3,128,128) = 96 tiles, (2,40,72) ragged."""
+    ops = _ops()
+    N, H, W = shape
+    nf, gc = 64, 32
+    ws = [rnd(gc, nf + k * gc, 3, 3, seed=70 + k, lo=-0.05, hi=0.05).to(DEV) for k in range(4)]
+    ws.append(rnd(nf, nf + 4 * gc, 3, 3, seed=74, lo=-0.05, hi=0.05).to(DEV))
+    bs = [rnd(w.shape[0], seed=80 + k).to(DEV) for k, w in enumerate(ws)]
+    p = ops.WeightPacker(DEV)
+    idx = [p.add(w, ops.PACK_FWD) for w in ws]
+    p.run()
+    x0 = rnd(N, nf, H, W, seed=90).permute(0, 2, 3, 1).contiguous().to(DEV)
+    skip = rnd(N, nf, H, W, seed=91).permute(0, 2, 3, 1).contiguous().to(DEV)
+
+    def run(chain):
+        buf = torch.zeros((N, H, W, nf + 4 * gc), device=DEV)
+        buf[..., :nf] = x0
+        out = torch.zeros((N, H, W, nf), device=DEV)
+        st = []
+        for k in range(4):
+            cin = nf + gc * k
+            st.append(dict(x=ops.View(buf, 0, cin), wp=p.get(idx[k]), y=ops.View(buf, cin, gc), bias=bs[k],
+                           act=ops.ACT_LRELU, slope=0.2, fresh_from=(cin - gc if k else None)))
+        st.append(dict(x=ops.View(buf), wp=p.get(idx[4]), y=ops.View(out), bias=bs[4], alpha=0.2, r1=ops.View(buf, 0, nf),
+                       r2=ops.View(skip), alpha2=0.2, fresh_from=nf + 3 * gc))
+        if chain:
+            ops.conv_chain(st)
+        else:
+            for d in st:
+                ops.conv(**{k: v for k, v in d.items() if k != "fresh_from"})
+        torch.cuda.synchronize()
+        return buf.cpu(), out.cpu()
+
+    assert ops.CONV_CHAIN
+    ref_buf, ref_out = run(False)
+    for rep in range(3):                    # repeated: the progress counters are reused with a growing epoch
+        got_buf, got_out = run(True)
+        assert torch.equal(got_buf, ref_buf), "dense buffer differs (rep %d)" % rep
+        assert torch.equal(got_out, ref_out), "block output differs (rep %d)" % rep
+    assert ops.chain_error_flag() == 0
+    # and against autograd-free fp32 PyTorch for the first stage (sanity of the reference itself)
+    y1 = F.leaky_relu(F.conv2d(x0.cpu().permute(0, 3, 1, 2), ws[0].cpu(), bs[0].cpu(), padding=1), 0.2)
+    close(ref_buf[..., nf:nf + gc].permute(0, 3, 1, 2), y1, what="chain stage 0")
+
+
 def test_wgrad_group_dense_block():
     """The 64-input pieces of a dense block's conv1 / conv3 (2x) / conv4 in ONE launch, with biases,
     alpha and beta, against autograd; then the error path for layers of different tile classes."""

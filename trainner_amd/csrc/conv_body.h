@@ -1,0 +1,349 @@
+// Device body of the tiled implicit-GEMM convolution, shared by the one-launch-per-layer kernel
+// (conv_tile.hip) and the multi-layer chain kernel (conv_chain.hip).  See conv_tile.hip for the design.
+#pragma once
+#include "common.h"
+
+namespace {
+
+typedef unsigned tnr_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | sc1 (bit 4) = system-coherent
+
+struct ConvK {
+    const float *x; int x_ct, x_co;
+    int N, H, W, Cin;
+    const float *wp; int KinP, KoutP;
+    float *y; int y_ct, y_co; int Ho, Wo, Cout;
+    const float *bias; int act; float slope; float alpha;
+    const float *r1; int r1_ct, r1_co, r1_ch; float beta1;
+    const float *r2; int r2_ct, r2_co; float alpha2;
+    const float *m; int m_ct, m_co, m_lo, m_hi; float m_slope;
+    int tiles_x, tiles_y, ncb;
+    int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
+};
+
+#ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps */
+__device__ unsigned long long tnr_timeline[8 * 8192];
+#define TNR_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TNR_STAMP(i) do { } while (0)
+#endif
+
+// One output tile of one convolution: (MT*128 pixels at tile (n, ty, tx), parity class `par` for the
+// strided data-gradient) x (NT*32 output channels of block cb).
+//   COH      activations cross workgroups INSIDE a launch (conv_chain.hip): input-tile loads and output
+//            stores are system-coherent buffer accesses (sc0 sc1), which makes a flag hand-off between
+//            workgroups on different CUs / XCDs correct without cache write-back / invalidate fences
+//            (tools/probes/flag_sync.hip: fences cost 4x the whole tile, sc0 sc1 accesses cost nothing).
+//   wait()   called once, before the loads of input chunk `wait_chunk` are issued (-1: never).
+//            wait.drain() / wait.publish() bracket the barrier after the LDS refill of chunk 1: the chain
+//            kernel publishes the PREVIOUS stage's tile there, one MFMA phase after its stores were issued.
+template <int MODE, int TW, int NT, int MT, bool COH, class WaitFn>
+__device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, const int tx, const int ty, const int n,
+                                               const int par, float *smem, const int wait_chunk, WaitFn &&wait) {
+    constexpr int TH = 128 * MT / TW;   // 4 waves x MT M-tiles of 32 pixels
+    constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
+    constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
+    constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
+    constexpr int KH = S2D ? 2 : 3;
+    constexpr int NTAPS = (S2D || DG2) ? 4 : 9;
+    constexpr int HT = TH + KH - 1, WT = TW + KH - 1;
+    constexpr int NC = NT * 32;
+    constexpr int PST = TNR_PST, CK = TNR_CK;
+
+    float *s_in = smem;                 // HT*WT*PST
+    float *s_w = smem + HT * WT * PST;  // NTAPS*NC*PST
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
+
+    // coherent path: raw buffer descriptors over the whole input / output buffers (out-of-range -> 0)
+    // (dead code, removed by the compiler, when !COH)
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+    const int ty0 = ty * TH, tx0 = tx * TW;
+    const int py = par >> 1, px = par & 1;
+
+    const float *wbase = a.wp + (DG2 ? (size_t)par * 4 * a.KoutP * a.KinP : (size_t)0);
+    const int nck = a.KinP / CK;
+    const int nchunks = S2D ? 4 * nck : nck;
+
+    // per-lane A offsets (dwords) of the MT M-tiles this wave owns
+    int aoff[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int p = (wave * MT + mi) * 32 + li;
+        const int r = p / TW, c = p - r * TW;
+        aoff[mi] = (r * WT + c) * PST + half * 4;
+    }
+    const int boff = li * PST + half * 4;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nn][r] = 0.f;
+
+    // ---- staging plan.  Every item is one float4 (4 channels); the per-item global offsets do not
+    // depend on the chunk (except the parity of the space-to-depth view), so they are computed once.
+    // Loads of chunk k+1 are issued into registers BEFORE the MFMA phase of chunk k and written to
+    // LDS after it (issue-early / write-late): HBM/L2 latency hides under ~10-20k cycles of MFMA.
+    constexpr int IN_ITEMS = HT * WT * 4, IN_IT = (IN_ITEMS + 255) / 256;
+    constexpr int W_ITEMS = NTAPS * NC * 4, W_IT = (W_ITEMS + 255) / 256;
+    int in_off[IN_IT];   // element offset into x (without the chunk's channel offset), -1 = zero fill
+    int w_off[W_IT];     // element offset into the packed weights (without chunk offset), -1 = zero fill
+    if (!S2D) {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            const int pix = i >> 2, q = i & 3;
+            const int hr = pix / WT, hc = pix - hr * WT;
+            int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            bool ok = i < IN_ITEMS;
+            if (UP) {
+                ok = ok & (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
+                Y >>= 1;
+                X >>= 1;
+            } else {
+                ok = ok & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            }
+            in_off[it] = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int i = tid + it * 256;
+        const int row = i >> 2, q = i & 3;
+        const int t = row / NC, co = row - t * NC;
+        const int cog = cb * NC + co;
+        const bool ok = (i < W_ITEMS) & (cog < a.KoutP);
+        w_off[it] = ok ? ((t * a.KoutP + cog) * (S2D ? 4 * a.KinP : a.KinP) + q * 4) : -1;
+    }
+    f32x4 rin[IN_IT], rw[W_IT];
+
+    auto load_chunk = [&](int chunk) {
+        int c0, pp = 0;
+        if (S2D) {
+            pp = chunk / nck;
+            c0 = (chunk - pp * nck) * CK;
+        } else {
+            c0 = chunk * CK;
+        }
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            const int q = i & 3;
+            int off;
+            if (S2D) {
+                const int pix = i >> 2;
+                const int hr = pix / WT, hc = pix - hr * WT;
+                const int Y = 2 * (ty0 + hr) - 1 + (pp >> 1), X = 2 * (tx0 + hc) - 1 + (pp & 1);
+                const bool ok = (i < IN_ITEMS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+            } else {
+                off = in_off[it];
+            }
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
+                const unsigned bo = (off >= 0 && c0 + q * 4 < a.Cin) ? (unsigned)(off + c0) * 4u : 0xfffffff0u;
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_AUX_SC0_SC1));
+            } else if (off >= 0 && c0 + q * 4 < a.Cin) {
+                v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
+            }
+            rin[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_off[it] >= 0) v = *reinterpret_cast<const f32x4 *>(wbase + (size_t)w_off[it] + (S2D ? pp * a.KinP : 0) + c0);
+            rw[it] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < IN_ITEMS) *reinterpret_cast<f32x4 *>(s_in + (i >> 2) * PST + (i & 3) * 4) = rin[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int i = tid + it * 256;
+            if (i < W_ITEMS) *reinterpret_cast<f32x4 *>(s_w + (i >> 2) * PST + (i & 3) * 4) = rw[it];
+        }
+    };
+
+    if (wait_chunk == 0) wait();
+    load_chunk(0);
+    TNR_STAMP(4);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // previous chunk's fragments are consumed
+        store_chunk();
+        if (chunk == 1) wait.drain();
+        __syncthreads();
+        if (chunk == 1) wait.publish();
+        if (chunk == 0) TNR_STAMP(1);
+        if (chunk + 1 < nchunks) {
+            if (chunk + 1 == wait_chunk) wait();
+            load_chunk(chunk + 1);                       // in flight during the MFMA phase below
+        }
+        // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
+        // 8-channel group: MT + NT ds_read_b128 feeding 4*MT*NT MFMAs (>= 1024 matrix-core cycles).  The
+        // fragments of step s+1 are read into the other register set BEFORE the MFMAs of step s issue, so
+        // a wave keeps the matrix pipe busy on its own; sched_barrier(0) pins that order (the scheduler
+        // would otherwise sink the reads next to their first use).  All steps are unrolled: every LDS
+        // address is a per-lane base + compile-time offset.
+        constexpr int KG = CK / 8, NSTEP = NTAPS * KG;
+        f32x4 fa[2][MT], fb[2][NT];
+        auto fetch = [&](int s_, int set) {
+            const int t = s_ / KG, kk = s_ - t * KG;
+            int pos_y, pos_x;
+            if (DG2) {
+                pos_y = 1 + py - (t >> 1);
+                pos_x = 1 + px - (t & 1);
+            } else if (S2D) {
+                pos_y = t >> 1;
+                pos_x = t & 1;
+            } else {
+                pos_y = t / 3;
+                pos_x = t - pos_y * 3;
+            }
+            const int tapoff = (pos_y * WT + pos_x) * PST + kk * 8;
+            const int woff = t * NC * PST + boff + kk * 8;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fa[set][mi] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff);
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) fb[set][nn] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn)
+                        acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][mi][j], fb[set][nn][j], acc[mi][nn], 0, 0, 0);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s_ = 0; s_ < NSTEP; ++s_) {
+            if (s_ + 1 < NSTEP) fetch(s_ + 1, (s_ + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s_ & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue.  The MFMA result layout gives a lane ONE channel of 16 scattered pixels, which would
+    // mean 16*MT*NT four-byte global stores per lane (store-issue bound).  Instead each wave transposes its
+    // (MT*32 pixels) x (NT*32 channels) tile through LDS and every lane then owns float4s of 4 consecutive
+    // channels of one pixel: 16-byte loads of residuals / masks and 16-byte stores, 4x fewer memory
+    // instructions, whole 128/256-byte pixel rows per wave instruction.
+    TNR_STAMP(2);
+    __syncthreads();                                   // every wave is done with the operand tiles
+    TNR_STAMP(5);
+    float *s_o = smem + wave * (MT * 32 * NC);         // this wave's [MT*32][NC] tile (no padding needed)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;   // D[i][j]: j = lane&31 (channel), i = pixel
+                s_o[(mi * 32 + i) * NC + nn * 32 + li] = acc[mi][nn][r];
+            }
+    TNR_STAMP(6);
+    __syncthreads();
+    TNR_STAMP(7);
+    constexpr int C4 = NC / 4;                         // float4 per pixel row
+    constexpr int UNITS = MT * 32 * C4 / 64;           // float4 per lane
+    constexpr int G = 4, NG = UNITS / G;               // units are handled in groups of 4
+    static_assert(UNITS % G == 0 && 64 % C4 == 0, "epilogue grouping");
+    // 64 % C4 == 0: a lane keeps the same channel quad for all its units
+    const int c4 = lane % C4, co = cb * NC + c4 * 4;
+    const bool co_ok = co < a.Cout;
+    const bool full = co + 4 <= a.Cout;                // false only for the 3-channel image output
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && co_ok) {
+        if (full) {
+            bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (co + k < a.Cout) bv[k] = a.bias[co + k];
+        }
+    }
+    const bool use_r1 = a.r1 != nullptr && co < a.r1_ch;
+    const bool use_r2 = a.r2 != nullptr;
+    const bool use_m = a.m != nullptr && co >= a.m_lo && co < a.m_hi;
+    // Residual / mask loads of group g+1 are issued BEFORE the stores of group g (two register sets): on
+    // gfx9 stores count in vmcnt like loads, so a load placed after a store in program order makes its
+    // consumer wait for that store's acknowledgement -- serialising the whole tail on write latency.
+    bool ok[2][G];
+    size_t pixi[2][G];
+    f32x4 q1[2][G], q2[2][G], qm[2][G];
+    auto prep = [&](int g, int set) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int pl = (g * G + k) * (64 / C4) + lane / C4;
+            const int p = wave * (MT * 32) + pl;
+            const int rr = p / TW, cc = p - rr * TW;
+            const int sy = ty0 + rr, sx = tx0 + cc;
+            ok[set][k] = co_ok && sy < a.th_space && sx < a.tw_space;
+            const int oy = DG2 ? 2 * sy + py : sy;
+            const int ox = DG2 ? 2 * sx + px : sx;
+            const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
+            pixi[set][k] = pix;
+            if (ok[set][k]) {
+                if (use_r1) q1[set][k] = *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
+                if (use_r2) q2[set][k] = *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
+                if (use_m) qm[set][k] = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
+            }
+        }
+    };
+    auto finish = [&](int g, int set) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            if (!ok[set][k]) continue;
+            const int pl = (g * G + k) * (64 / C4) + lane / C4;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(s_o + pl * NC + c4 * 4) + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tnr_act(v[e], a.act, a.slope) * a.alpha;
+            if (use_r1) v += a.beta1 * q1[set][k];
+            if (use_r2) v = v * a.alpha2 + q2[set][k];
+            if (use_m) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (qm[set][k][e] > 0.f ? 1.f : a.m_slope);
+            }
+            float *yp = a.y + pixi[set][k] * a.y_ct + a.y_co + co;
+            if (COH) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnr_u32x4, v), y_rs,
+                                                       (int)((unsigned)(pixi[set][k] * a.y_ct + a.y_co + co) * 4u), 0, TNR_AUX_SC0_SC1);
+            } else if (full) {
+                *reinterpret_cast<f32x4 *>(yp) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (co + e < a.Cout) yp[e] = v[e];
+            }
+        }
+    };
+    prep(0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) prep(g + 1, (g + 1) & 1);
+        finish(g, g & 1);
+    }
+    TNR_STAMP(3);
+}
+
+
+struct NoWait {
+    __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void drain() const {}
+    __device__ __forceinline__ void publish() const {}
+};
+
+}  // namespace

@@ -1,0 +1,220 @@
+// Several dependent 3x3 convolutions over the same pixel grid in ONE launch ("chain"): the five growing-K
+// convolutions of a residual dense block (RRDBNet_arch.py:150-163) and the five of its gradient mirror.
+//
+// Why: a trunk layer is a single residency round (512 tiles = 2 workgroups x 256 CUs at batch 16).  As a
+// launch of its own, every workgroup runs its prologue (first-tile fetch: a 37 MB HBM read burst) and its
+// epilogue (a 33 MB write burst) at the same time as all others, with the matrix pipes idle -- 17 % of the
+// layer (tools/probes/conv_timeline.hip).  In a chain a workgroup keeps its pixel tile through all stages:
+// the stores of stage s drain while stage s+1 already runs on the channels that existed before, and only
+// the chunk that first touches stage-s output waits -- for the 8 neighbouring tiles (3x3 halo), through a
+// per-tile progress counter.
+//
+// Hand-off protocol (tools/probes/flag_sync.hip): producer = system-coherent stores (sc0 sc1), s_waitcnt
+// vmcnt(0), workgroup barrier, one relaxed agent-scope store of the counter; consumer = relaxed
+// agent-scope loads of the 8 counters, workgroup barrier, system-coherent loads.  No cache write-back /
+// invalidate fences (they cost 4x a whole tile on this part).
+// Deadlock freedom: the grid never exceeds the co-resident capacity and every workgroup walks its tiles
+// stage-major, so a waited-for tile always belongs to a running workgroup at an earlier program point.
+#include <stddef.h>
+#include "conv_body.h"
+
+namespace {
+
+struct ChainK {
+    int nstages;
+    int tiles_x, tiles_y, tiles;       // 16 x 32 pixel tiles over (N, H, W)
+    unsigned *progress;                // [tiles]: base + (stages of that tile whose output is visible)
+    unsigned base;
+    unsigned *err;                     // set to 1 when a dependency wait gives up (never in a healthy run)
+    int wait_chunk[TNR_CHAIN_MAX];
+    ConvK st[TNR_CHAIN_MAX];
+};
+
+struct ChainWait {
+    unsigned *progress;
+    unsigned need;
+    int n, ty, tx, tiles_x, tiles_y;
+    unsigned *err;
+    int *pend_tile;          // tile whose previous-stage output still has to be published (-1: none)
+    unsigned pend_value;
+    // Deferred publish: the stores of the previous stage were issued a whole MFMA phase ago; waiting for
+    // them here costs nothing, whereas waiting right after the epilogue would expose the full write burst.
+    __device__ __forceinline__ void drain() const {
+        if (*pend_tile >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void publish() const {
+        if (*pend_tile >= 0) {
+            if (threadIdx.x == 0) __hip_atomic_store(progress + *pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *pend_tile = -1;
+        }
+    }
+    __device__ __forceinline__ void operator()() const {
+        if (*pend_tile >= 0) {   // a wait before chunk 2: our own previous stage must be visible first (no circular wait)
+            drain();
+            __syncthreads();
+            publish();
+        }
+        const int t = threadIdx.x;
+        if (t < 9 && t != 4) {
+            const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
+            if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) {
+                const unsigned *p = progress + ((size_t)n * tiles_y + yy) * tiles_x + xx;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                // (int) difference: robust to the counter base wrapping around
+                while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {   // ~2 s: report instead of hanging the GPU
+                        *err = 1u;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// Stage s of the kernel-argument table, fetched with scalar loads: indexing the by-value struct with a
+// run-time s would make the compiler copy all of it to scratch and turn every field into a VGPR.
+__device__ __forceinline__ ConvK chain_stage(int s, int *wait_chunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) ChainK karg_chain;
+    karg_chain *ka = (karg_chain *)__builtin_amdgcn_kernarg_segment_ptr();   // constant address space: s_load
+    *wait_chunk = ka->wait_chunk[s];
+    return ka->st[s];
+#else
+    *wait_chunk = -1;
+    return ConvK();
+#endif
+}
+
+__global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int pend_tile = -1;          // wave-uniform
+    unsigned pend_value = 0;
+    for (int s = 0; s < c.nstages; ++s) {
+        int wait_chunk;
+        const ConvK st = chain_stage(s, &wait_chunk);
+        const int ncb = st.KoutP >> 5;
+        for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+            int q = tile;
+            const int tx = q % c.tiles_x;
+            q /= c.tiles_x;
+            const int ty = q % c.tiles_y;
+            const int n = q / c.tiles_y;
+            const ChainWait w{c.progress, c.base + (unsigned)s, n, ty, tx, c.tiles_x, c.tiles_y, c.err, &pend_tile, pend_value};
+            for (int cb = 0; cb < ncb; ++cb) {
+                // opaque copies: keep the per-tile index arithmetic of the body INSIDE the loops (hoisted out of
+                // them it stays live across the whole kernel and spills)
+                int txo = tx, tyo = ty, no = n;
+                asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(no));
+                conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
+            }
+            // this tile's stage-s output is on its way to memory: published from inside the next tile body
+            // (every stage has >= 2 input chunks, so the previous pending tile has been published by now)
+            pend_tile = tile;
+            pend_value = c.base + (unsigned)s + 1u;
+        }
+    }
+    // nothing in this launch waits for the last stage; publish it anyway so the counters stay consistent
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pend_tile >= 0 && threadIdx.x == 0)
+        __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int CH_TH = 16, CH_TW = 32;
+constexpr size_t chain_lds() {
+    constexpr size_t lds_main = (size_t)((CH_TH + 2) * (CH_TW + 2) + 9 * 32) * TNR_PST * sizeof(float);
+    constexpr size_t lds_epi = (size_t)4 * 4 * 32 * 32 * sizeof(float);
+    return lds_main > lds_epi ? lds_main : lds_epi;
+}
+
+int chain_capacity(int *out) {
+    static int cap = 0;
+    if (cap == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            tnr_set_error("conv_chain: cannot query the device");
+            return TNR_ELAUNCH;
+        }
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds()) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel, 256, chain_lds()) != hipSuccess) {
+            tnr_set_error("conv_chain: cannot size the grid");
+            return TNR_ELAUNCH;
+        }
+        // LDS allows two workgroups per CU; never trust a larger answer (the progress waits need every
+        // workgroup of the grid to be resident at once)
+        if (per_cu > 2) per_cu = 2;
+        if (per_cu < 1 || cus < 1) {
+            tnr_set_error("conv_chain: kernel does not fit a CU");
+            return TNR_ELAUNCH;
+        }
+        cap = per_cu * cus;
+    }
+    *out = cap;
+    return TNR_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *d) {
+    if (d == nullptr) return 0;
+    const int64_t tiles = (int64_t)tnr_cdiv(d->Wo, CH_TW) * tnr_cdiv(d->Ho, CH_TH) * d->N;
+    return (tiles + 1) * (int64_t)sizeof(uint32_t);   // progress counters + the error word
+}
+
+extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,
+                              uint32_t epoch, void *stream) {
+    TNR_REQUIRE(stages != nullptr && fresh_from != nullptr && ws != nullptr && n >= 1 && n <= TNR_CHAIN_MAX,
+                "conv_chain: 1..%d stages", TNR_CHAIN_MAX);
+    const tnr_conv_desc &d0 = stages[0];
+    TNR_REQUIRE(tnr_conv_chain_workspace_bytes(&d0) <= ws_bytes, "conv_chain: workspace too small");
+    ChainK c;
+    c.nstages = n;
+    c.tiles_x = tnr_cdiv(d0.Wo, CH_TW);
+    c.tiles_y = tnr_cdiv(d0.Ho, CH_TH);
+    c.tiles = c.tiles_x * c.tiles_y * d0.N;
+    c.progress = ws;
+    c.err = ws + c.tiles;
+    c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
+    for (int i = 0; i < n; ++i) {
+        const tnr_conv_desc *d = &stages[i];
+        TNR_REQUIRE(d->x.ptr && d->y.ptr && d->wp, "conv_chain: null pointer in stage %d", i);
+        TNR_REQUIRE(d->mode == TNR_CONV_3x3 && d->N == d0.N && d->H == d0.H && d->W == d0.W && d->Ho == d0.H && d->Wo == d0.W,
+                    "conv_chain: stage %d is not a 3x3 convolution over the pixel grid of stage 0", i);
+        TNR_REQUIRE(d->KinP >= 2 * TNR_CK, "conv_chain: stage %d needs at least 32 (padded) input channels", i);
+        TNR_REQUIRE((d->Cout % 32) == 0 && d->KoutP == d->Cout && (d->Cin % 4) == 0 && (d->KinP % TNR_CK) == 0 && d->Cin <= d->KinP,
+                    "conv_chain: stage %d: Cout must be a multiple of 32, Cin of 4", i);
+        TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->y.ctot % 4) == 0 && (d->y.coff % 4) == 0,
+                    "conv_chain: stage %d: views must be 4-channel aligned", i);
+        TNR_REQUIRE(d->r1.ptr == nullptr || ((d->r1.ctot % 4) == 0 && (d->r1.coff % 4) == 0 && (d->r1_ch % 4) == 0),
+                    "conv_chain: stage %d: r1 view must be 4-channel aligned", i);
+        TNR_REQUIRE(d->r2.ptr == nullptr || ((d->r2.ctot % 4) == 0 && (d->r2.coff % 4) == 0), "conv_chain: stage %d: r2 view", i);
+        TNR_REQUIRE(d->m.ptr == nullptr || ((d->m.ctot % 4) == 0 && (d->m.coff % 4) == 0 && (d->m_lo % 4) == 0 && (d->m_hi % 4) == 0),
+                    "conv_chain: stage %d: mask view", i);
+        TNR_REQUIRE((int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->H * d->W * d->y.ctot < (1LL << 30),
+                    "conv_chain: stage %d: buffers above 4 GiB are not addressable through a buffer descriptor", i);
+        TNR_REQUIRE(fresh_from[i] < d->Cin && (i > 0 || fresh_from[i] < 0), "conv_chain: stage %d: bad fresh_from %d", i, fresh_from[i]);
+        ConvK &k = c.st[i];
+        k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
+        k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+        k.wp = d->wp; k.KinP = d->KinP; k.KoutP = d->KoutP;
+        k.y = d->y.ptr; k.y_ct = d->y.ctot; k.y_co = d->y.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+        k.bias = d->bias; k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+        k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
+        k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
+        k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+        k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
+        k.th_space = d->Ho; k.tw_space = d->Wo;
+        c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
+    }
+    for (int i = n; i < TNR_CHAIN_MAX; ++i) { c.st[i] = c.st[0]; c.wait_chunk[i] = -1; }
+    int cap = 0;
+    const int rc = chain_capacity(&cap);
+    if (rc != TNR_OK) return rc;
+    const int grid = c.tiles < cap ? c.tiles : cap;
+    hipLaunchKernelGGL(conv_chain_kernel, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    return tnr_check_launch("conv_chain");
+}

@@ -30,6 +30,9 @@ class DPGroup:
         self.active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("TNR_DP_SELFTEST") == "1")
         self._side = None
         self._pending = []
+        if self.active:
+            from . import ops
+            ops.COLLECTIVES_IN_FLIGHT = True     # see ops.conv_chain
 
     # ---------------------------------------------------------------- small forward exchanges
     def all_reduce_sum(self, t):

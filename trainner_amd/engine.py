@@ -29,6 +29,10 @@ class ConvOp:
     def fwd(self, x, y, **epi):
         ops.conv(x, self.packer.get(self.i_f), y, mode=self.mode_f, bias=self.mod.bias, **epi)
 
+    def fwd_stage(self, x, y, fresh_from=None, **epi):
+        """Stage descriptor of this layer's forward for ops.conv_chain."""
+        return dict(x=x, wp=self.packer.get(self.i_f), y=y, mode=self.mode_f, bias=self.mod.bias, fresh_from=fresh_from, **epi)
+
     def dgrad(self, g, gx, **epi):
         """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
         ops.conv(g, self.packer.get(self.i_d), gx, mode=self.mode_d, **epi)

@@ -67,6 +67,8 @@ _SIGS = {
     "tnr_pack_dense_dims": (c_i, [c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_l)]),
     "tnr_pack_dense_dgrad": (c_i, [c_p, c_i, c_l, c_p]),
     "tnr_conv_forward": (c_i, [C.POINTER(ConvDesc), c_p]),
+    "tnr_conv_chain_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
+    "tnr_conv_chain": (c_i, [C.POINTER(ConvDesc), C.POINTER(C.c_int32), c_i, c_p, c_l, C.c_uint32, c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
     "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "tnr_conv_wgrad_group": (c_i, [C.POINTER(WgradDesc), c_i, c_p]),

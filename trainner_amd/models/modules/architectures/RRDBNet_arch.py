@@ -126,14 +126,20 @@ class RRDBNet(HipNet):
         for i in range(nrdb):
             buf = bufs[i % nbuf]
             convs = o["rdb"][i]
+            # the five convolutions of the block as ONE launch (conv_chain.hip): conv_{k+1} first meets the
+            # output of conv_k at input channel nf + gc*(k-1)
+            st = []
             for k in range(4):
                 cin = nf + gc * k
-                convs[k].fwd(View(buf, 0, cin), View(buf, cin, gc), act=act, slope=sl)
+                st.append(convs[k].fwd_stage(View(buf, 0, cin), View(buf, cin, gc), fresh_from=(cin - gc if k else None),
+                                             act=act, slope=sl))
             dst = View(bufs[(i + 1) % nbuf], 0, nf) if i + 1 < nrdb else View(trunk)
             if i % 3 == 2:   # RDB3 also closes the RRDB: (x5*0.2 + x)*0.2 + x_rrdb
-                convs[4].fwd(View(buf), dst, alpha=0.2, r1=View(buf, 0, nf), r2=View(bufs[(i - 2) % nbuf], 0, nf), alpha2=0.2)
+                st.append(convs[4].fwd_stage(View(buf), dst, fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf),
+                                             r2=View(bufs[(i - 2) % nbuf], 0, nf), alpha2=0.2))
             else:
-                convs[4].fwd(View(buf), dst, alpha=0.2, r1=View(buf, 0, nf))
+                st.append(convs[4].fwd_stage(View(buf), dst, fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf)))
+            ops.conv_chain(st)
         y0 = new_act(N, h, w, nf, dev)
         o["lr"].fwd(View(trunk), View(y0), r1=fea_keep)          # ShortcutBlock: fea + trunk(fea)
         cur, stages = View(y0), []
@@ -169,13 +175,16 @@ class RRDBNet(HipNet):
         + s*g (+ extra, the RRDB skip), into `gnext` (64-ch view)."""
         nf, gc, sl = self.nf, self.gc, self.slope
         dp = self._dense_packer
+        st = []
         for t in range(4):                       # targets x4, x3, x2, x1: LeakyReLU' fused as mask
             cin = nf + t * gc
             xk = View(buf, nf + (3 - t) * gc, gc)
-            ops.conv(View(GP, 0, cin), dp.get(dense[t]), View(GP, cin, gc), mask=xk, m_lo=0, m_hi=gc, m_slope=sl)
+            st.append(dict(x=View(GP, 0, cin), wp=dp.get(dense[t]), y=View(GP, cin, gc), fresh_from=(cin - gc if t else None),
+                           mask=xk, m_lo=0, m_hi=gc, m_slope=sl))
         g = View(GP, 0, nf)
         kw = dict(r2=extra, alpha2=1.0) if extra is not None else {}
-        ops.conv(View(GP), dp.get(dense[4]), gnext, r1=g, beta1=s, **kw)
+        st.append(dict(x=View(GP), wp=dp.get(dense[4]), y=gnext, fresh_from=nf + 3 * gc, r1=g, beta1=s, **kw))
+        ops.conv_chain(st)                       # one launch for the block's data-gradient (conv_chain.hip)
         if want_w:
             convs[4].wgrad(View(buf), g, alpha=0.2 * s)
             # conv1..conv4 (32 couts; g_k lives at GP[nf + (3-k)*gc : +gc)) as 32 x 64 and 32 x 96 channel

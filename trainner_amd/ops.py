@@ -4,6 +4,8 @@ Nothing here computes with torch; torch only allocates the buffers the kernels r
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import hip
@@ -231,9 +233,8 @@ class ConvProfile:
 PROFILE = None      # set to a ConvProfile() to time launches
 
 
-def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
-    d = ConvDesc()
+def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
+               beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.wp, d.KinP, d.KoutP = wp.t.data_ptr(), wp.KinP, wp.KoutP
@@ -251,6 +252,11 @@ def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0,
     d.m_lo = m_lo
     d.m_hi = (y.C if m_hi is None else m_hi)
     d.m_slope = m_slope
+
+
+def conv(x, wp, y, mode=CONV_3x3, **epi):
+    d = ConvDesc()
+    _conv_desc(d, x, wp, y, mode, **epi)
     if PROFILE is None:
         hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
         return
@@ -261,6 +267,60 @@ def conv(x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0,
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
            DGRAD_4x4_S2: "conv_tile_dgrad4x4s2"}[mode]
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
+
+
+CHAIN_MAX = 6
+CONV_CHAIN = os.environ.get("TNR_CONV_CHAIN", "1") != "0"     # 0: one launch per layer (A/B switch)
+COLLECTIVES_IN_FLIGHT = False   # set by dp.py when gradient buckets are all-reduced on a side stream during backward:
+                                # a chain launch needs every workgroup of its grid co-resident, which RCCL kernels
+                                # sharing the CUs could delay -> multi-GPU runs keep one launch per layer
+_chain_epoch = {}
+
+
+def conv_chain(stages):
+    """Dependent 3x3 convolutions over one pixel grid in one launch (tnr_conv_chain).  stages: dicts with the
+    arguments of conv() (x, wp, y, bias, act, ..., mask) plus fresh_from: first input channel produced by the
+    previous stage of this chain (None for the first stage).  Same results as calling conv() per stage."""
+    n = len(stages)
+    assert 1 <= n <= CHAIN_MAX
+    eligible = all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages)
+    if not CONV_CHAIN or COLLECTIVES_IN_FLIGHT or not eligible:
+        for st in stages:
+            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+        return
+    lib = hip.load()
+    descs = (ConvDesc * n)()
+    fresh = (C.c_int32 * n)()
+    flops = 0.0
+    for i, st in enumerate(stages):
+        kw = {k: v for k, v in st.items() if k != "fresh_from"}
+        _conv_desc(descs[i], **kw)
+        ff = st.get("fresh_from")
+        fresh[i] = -1 if ff is None else ff
+        flops += 2.0 * st["y"].pixels * 9 * min(st["x"].C, st["wp"].KinP) * st["y"].C
+    dev = stages[0]["x"].buf.device
+    need = lib.tnr_conv_chain_workspace_bytes(C.byref(descs[0]))
+    key = ("chain", str(dev), hip.stream(), need)    # one counter set per (stream, tile grid)
+    ws = WS.bufs.get(key)
+    if ws is None:
+        ws = torch.zeros(need // 4, dtype=torch.int32, device=dev)     # progress counters start at 0; last word = error flag
+        WS.bufs[key] = ws
+        _chain_epoch[key] = 0
+    _chain_epoch[key] = (_chain_epoch[key] + 1) & 0x0FFFFFFF
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_conv_chain(descs, fresh, n, ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_chain")
+    if PROFILE is not None:
+        x0, yl = stages[0]["x"], stages[-1]["y"]
+        PROFILE.end("conv_chain", flops, t0, (x0.C, yl.C, yl.H, stages[0]["wp"].kind))
+
+
+def chain_error_flag():
+    """Nonzero if a tnr_conv_chain dependency wait ever gave up in this process (checked by tests / smoke)."""
+    bad = 0
+    for key, ws in WS.bufs.items():
+        if isinstance(key, tuple) and key[0] == "chain":
+            bad += int(ws[-1].item() != 0)
+    return bad
 
 
 WGRAD_GROUP_MAX = 8
