@@ -39,7 +39,9 @@ enum {
     TNR_CONV_3x3 = 0,      /* k3 s1 p1: every G / VGG conv, D odd layers (block.py:214-256)              */
     TNR_CONV_3x3_UP2 = 1,  /* nearest x2 (block.py:326-371,390-404) folded into the k3 s1 p1 gather       */
     TNR_CONV_4x4_S2 = 2,   /* k4 s2 p1: Discriminator_VGG even layers (discriminators.py:24-34)           */
-    TNR_DGRAD_4x4_S2 = 3   /* data-gradient of k4 s2 p1 (aten convolution_backward), parity-decomposed    */
+    TNR_DGRAD_4x4_S2 = 3,  /* data-gradient of k4 s2 p1 (aten convolution_backward), parity-decomposed    */
+    TNR_CONV_1x1 = 4       /* k1 s1: the GEMM behind tnr_im2col for the small-spatial layers of the       */
+                           /* discriminator tail (discriminators.py:24-36 at 16x16 and below)             */
 };
 
 /* weight packings produced by tnr_pack_weights */
@@ -47,7 +49,9 @@ enum {
     TNR_PACK_FWD = 0,       /* [kh*kw][KoutP][KinP]            <- W[co][ci][ky][kx]                         */
     TNR_PACK_DGRAD_3x3 = 1, /* [9][KoutP=ci][KinP=co]          <- W[co][ci][2-ky][2-kx]                     */
     TNR_PACK_FWD_S2D = 2,   /* [4][KoutP][4*KinP] (space-to-depth view of k4 s2)                           */
-    TNR_PACK_DGRAD_S2 = 3   /* [4 parities][4][KoutP=ci][KinP=co]                                          */
+    TNR_PACK_DGRAD_S2 = 3,  /* [4 parities][4][KoutP=ci][KinP=co]                                          */
+    TNR_PACK_COL_FWD = 4,   /* [1][KoutP][KinP = kh*kw*Cin]: column (ky*kw+kx)*Cin+ci of tnr_im2col          */
+    TNR_PACK_COL_DGRAD3 = 5 /* [1][KoutP=ci][KinP = 9*Cout]: column t*Cout+co <- W[co][ci][2-ty][2-tx]      */
 };
 
 typedef struct tnr_view {
@@ -79,6 +83,11 @@ typedef struct tnr_conv_desc {
     tnr_view r1; int32_t r1_ch; float beta1;   /* r1.ptr NULL = none */
     tnr_view r2; float alpha2;                 /* r2.ptr NULL = none */
     tnr_view m;  int32_t m_lo, m_hi; float m_slope; /* m.ptr NULL = none */
+    /* optional split-K workspace (tnr_conv_workspace_bytes()).  A launch with too few output tiles to
+     * fill the chip and a long reduction (the 512-channel layers at 16x16 and below) is split along K
+     * into partial sums in ws, reduced in a fixed order by a second launch that applies bias / act / alpha.
+     * NULL: never split.                                                                               */
+    float *ws; int64_t ws_bytes;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -131,6 +140,12 @@ int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out,
 int tnr_pack_dense_dims(int32_t nf, int32_t gc, int32_t t, int32_t *KoutP, int32_t *KinP, int64_t *n_out);
 int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
 int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
+int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d);   /* 0 when the launch would not be split */
+/* out[(n*Ho + oy)*Wo + ox][(ky*kw + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside):
+ * the patch matrix of a k x k convolution as an NHWC "image" of Ho*Wo*N pixels with kh*kw*C channels, for
+ * TNR_CONV_1x1 with TNR_PACK_COL_* weights.  C % 4 == 0.                                                */
+int tnr_im2col(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+               int32_t Ho, int32_t Wo, float *out, void *stream);
 /* n <= TNR_CHAIN_MAX dependent 3x3 convolutions over one pixel grid in ONE launch: the five convolutions of a
  * ResidualDenseBlock_5C (RRDBNet_arch.py:150-163) or of its gradient mirror.  Stage i may read what stages
  * < i of the same call wrote: fresh_from[i] is the first input channel of stage i that stage i-1 produced

@@ -279,6 +279,55 @@ def test_conv_chain_equals_per_layer_launches(shape):
     close(ref_buf[..., nf:nf + gc].permute(0, 3, 1, 2), y1, what="chain stage 0")
 
 
+@pytest.mark.parametrize("case", [("3x3", 2, 8, 8, 256, 96), ("3x3", 16, 4, 4, 512, 512), ("s2", 2, 16, 16, 128, 64),
+                                  ("s2", 4, 8, 8, 512, 160), ("dgrad3", 2, 8, 8, 96, 256)])
+def test_conv_small_im2col_splitk(case):
+    """Small-spatial layers as tnr_im2col + TNR_CONV_1x1 (split-K partial sums + reduce launch) against F.conv2d."""
+    ops = _ops()
+    kind, N, H, W, Cin, Cout = case
+    x = rnd(N, Cin, H, W, seed=101)
+    b = rnd(Cout, seed=103)
+    if kind == "3x3":
+        w = rnd(Cout, Cin, 3, 3, seed=102, lo=-0.05, hi=0.05)
+        ref = F.conv2d(x, w, b, padding=1)
+        wp, _ = pack(ops, w.to(DEV), ops.PACK_COL_FWD)
+        y = torch.zeros((N, H, W, Cout), device=DEV)
+        ops.conv_small(ops.View(nhwc_buf(x)), wp, ops.View(y), 3, 1, bias=b.to(DEV))
+    elif kind == "s2":
+        w = rnd(Cout, Cin, 4, 4, seed=102, lo=-0.05, hi=0.05)
+        ref = F.conv2d(x, w, b, stride=2, padding=1)
+        wp, _ = pack(ops, w.to(DEV), ops.PACK_COL_FWD)
+        y = torch.zeros((N, H // 2, W // 2, Cout), device=DEV)
+        ops.conv_small(ops.View(nhwc_buf(x)), wp, ops.View(y), 4, 2, bias=b.to(DEV))
+    else:   # data-gradient of a 3x3 convolution with Cin -> Cout channels: g has Cout channels, result Cin
+        w = rnd(Cout, Cin, 3, 3, seed=102, lo=-0.05, hi=0.05)
+        xin = x.clone().requires_grad_(True)
+        g = rnd(N, Cout, H, W, seed=104)
+        (ref,) = torch.autograd.grad(F.conv2d(xin, w, None, padding=1), xin, g)
+        wp, _ = pack(ops, w.to(DEV), ops.PACK_COL_DGRAD3)
+        y = torch.zeros((N, H, W, Cin), device=DEV)
+        ops.conv_small(ops.View(nhwc_buf(g)), wp, ops.View(y), 3, 1)
+    close(to_nchw(y, 0, y.shape[3]), ref, what="conv_small " + kind)
+
+
+def test_conv_direct_splitk():
+    """The direct 3x3 kernel with a split-K workspace (512 -> 512 channels at 16x16: 16 tiles for 512 slots)."""
+    ops = _ops()
+    N, H, W, Cin, Cout = 2, 16, 16, 512, 512
+    x, w, b = rnd(N, Cin, H, W, seed=111), rnd(Cout, Cin, 3, 3, seed=112, lo=-0.03, hi=0.03), rnd(Cout, seed=113)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    wp, _ = pack(ops, w.to(DEV), ops.PACK_FWD)
+    y = torch.zeros((N, H, W, Cout), device=DEV)
+    from trainner_amd.hip import ConvDesc
+    d = ConvDesc()
+    ops._conv_desc(d, ops.View(nhwc_buf(x)), wp, ops.View(y), ops.CONV_3x3, bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2)
+    import ctypes
+    from trainner_amd import hip
+    assert hip.load().tnr_conv_workspace_bytes(ctypes.byref(d)) > 0, "launch should be split"
+    ops.conv(ops.View(nhwc_buf(x)), wp, ops.View(y), bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2)
+    close(to_nchw(y, 0, Cout), ref, what="direct split-K")
+
+
 def test_wgrad_group_dense_block():
     """The 64-input pieces of a dense block's conv1 / conv3 (2x) / conv4 in ONE launch, with biases,
     alpha and beta, against autograd; then the error path for layers of different tile classes."""

@@ -158,5 +158,9 @@ def test_vgg19_features():
     lref = F.l1_loss(O.vgg19_conv54(xr2, vsd), O.vgg19_conv54(y, vsd))
     lref.backward()
     assert abs(float(loss) - float(lref)) < 2e-5 * max(1.0, abs(float(lref)))
+    # d|f - fy|/df = sign(f - fy): a feature element whose difference is at rounding level takes the other sign
+    # under a different (equally valid) fp32 summation order -- the split-K GEMM of the 4x6 / 8x12 layers here --
+    # and conv5_4's receptive field spans this whole image, so a handful of flips moves every input-gradient
+    # element a little: bound the median at 5e-4 (measured 8e-5 with flips, 2e-7 without) and the L2 as before
     l2, med = robust_err(xd2.grad, xr2.grad)
-    assert l2 < 0.1 and med < 2e-5, (l2, med)
+    assert l2 < 0.1 and med < 5e-4, (l2, med)

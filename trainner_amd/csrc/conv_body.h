@@ -19,6 +19,8 @@ struct ConvK {
     const float *m; int m_ct, m_co, m_lo, m_hi; float m_slope;
     int tiles_x, tiles_y, ncb;
     int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
+    int ksplit;              // split-K factor (1: none); split s writes its partial sums to y + s * split_stride
+    size_t split_stride;
 };
 
 #ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps */
@@ -39,13 +41,15 @@ __device__ unsigned long long tnr_timeline[8 * 8192];
 //            kernel publishes the PREVIOUS stage's tile there, one MFMA phase after its stores were issued.
 template <int MODE, int TW, int NT, int MT, bool COH, class WaitFn>
 __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, const int tx, const int ty, const int n,
-                                               const int par, float *smem, const int wait_chunk, WaitFn &&wait) {
+                                               const int par, float *smem, const int wait_chunk, WaitFn &&wait,
+                                               const int ksplit = 1, const int split = 0) {
     constexpr int TH = 128 * MT / TW;   // 4 waves x MT M-tiles of 32 pixels
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
-    constexpr int KH = S2D ? 2 : 3;
-    constexpr int NTAPS = (S2D || DG2) ? 4 : 9;
+    constexpr bool P11 = (MODE == TNR_CONV_1x1);
+    constexpr int KH = S2D ? 2 : (P11 ? 1 : 3);
+    constexpr int NTAPS = (S2D || DG2) ? 4 : (P11 ? 1 : 9);
     constexpr int HT = TH + KH - 1, WT = TW + KH - 1;
     constexpr int NC = NT * 32;
     constexpr int PST = TNR_PST, CK = TNR_CK;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             const int i = tid + it * 256;
             const int pix = i >> 2, q = i & 3;
             const int hr = pix / WT, hc = pix - hr * WT;
-            int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            int Y = ty0 + hr - (P11 ? 0 : 1), X = tx0 + hc - (P11 ? 0 : 1);
             bool ok = i < IN_ITEMS;
             if (UP) {
                 ok = ok & (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
@@ -175,17 +179,21 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         }
     };
 
-    if (wait_chunk == 0) wait();
-    load_chunk(0);
+    // split-K: this workgroup reduces input chunks [c_begin, c_end) only
+    const int per_split = (nchunks + ksplit - 1) / ksplit;
+    const int c_begin = split * per_split;
+    const int c_end = (c_begin + per_split < nchunks) ? c_begin + per_split : nchunks;
+    if (wait_chunk == c_begin) wait();
+    load_chunk(c_begin);
     TNR_STAMP(4);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
         __syncthreads();  // previous chunk's fragments are consumed
         store_chunk();
-        if (chunk == 1) wait.drain();
+        if (chunk == c_begin + 1) wait.drain();
         __syncthreads();
-        if (chunk == 1) wait.publish();
-        if (chunk == 0) TNR_STAMP(1);
-        if (chunk + 1 < nchunks) {
+        if (chunk == c_begin + 1) wait.publish();
+        if (chunk == c_begin) TNR_STAMP(1);
+        if (chunk + 1 < c_end) {
             if (chunk + 1 == wait_chunk) wait();
             load_chunk(chunk + 1);                       // in flight during the MFMA phase below
         }
@@ -206,6 +214,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             } else if (S2D) {
                 pos_y = t >> 1;
                 pos_x = t & 1;
+            } else if (P11) {
+                pos_y = 0;
+                pos_x = 0;
             } else {
                 pos_y = t / 3;
                 pos_x = t - pos_y * 3;

@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     TNR_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
+    const int split = bid % a.ksplit;   // innermost: the splits of a tile run side by side and share its input in L2
+    bid /= a.ksplit;
     const int cb = bid % a.ncb;
     bid /= a.ncb;
     const int tx = bid % a.tiles_x;
@@ -34,7 +36,37 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
         par = bid & 3;
         bid >>= 2;
     }
-    conv_tile_body<MODE, TW, NT, MT, false>(a, cb, tx, ty, bid, par, smem, -1, NoWait());
+    ConvK b = a;
+    b.y = a.y + (size_t)split * a.split_stride;
+    conv_tile_body<MODE, TW, NT, MT, false>(b, cb, tx, ty, bid, par, smem, -1, NoWait(), a.ksplit, split);
+}
+
+// Second launch of a split-K convolution: y = act(sum_s ws[s] + bias) * alpha, splits summed in index order.
+struct SplitRedK {
+    const float *ws; size_t split_stride; int ksplit;
+    float *y; int y_ct, y_co, Cout, CoutP;
+    long long pixels;
+    const float *bias; int act; float slope, alpha;
+};
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const SplitRedK a) {
+    const int c4n = a.CoutP >> 2;
+    const long long total = a.pixels * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / c4n;
+        const int co = (int)(i - p * c4n) * 4;
+        if (co >= a.Cout) continue;
+        const float *src = a.ws + (size_t)p * a.CoutP + co;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+        for (int s = 1; s < a.ksplit; ++s) v += *reinterpret_cast<const f32x4 *>(src + (size_t)s * a.split_stride);
+        float *yp = a.y + (size_t)p * a.y_ct + a.y_co + co;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (co + k < a.Cout) {
+                const float b = a.bias != nullptr ? a.bias[co + k] : 0.f;
+                yp[k] = tnr_act(v[k] + b, a.act, a.slope) * a.alpha;
+            }
+        }
+    }
 }
 
 template <int MODE, int TW, int NT, int MT = 2>
@@ -71,11 +103,26 @@ int dispatch_conv(const ConvK &k, int tw, int nt, int tiles, hipStream_t s) {
     return nt == 2 ? launch_conv<MODE, 8, 2>(k, tiles, s) : launch_conv<MODE, 8, 1>(k, tiles, s);
 }
 
+// Split-K factor of a launch.  Only plain epilogues (bias / activation / alpha) can be deferred to the reduce
+// launch, and only launches that leave most of the 512 workgroup slots empty while looping over >= 32 input
+// chunks are worth a second launch: the 512-channel discriminator layers at 16x16 and below.
+int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
+    if (d->r1.ptr || d->r2.ptr || d->m.ptr || (d->Cout % 4) != 0 || d->mode == TNR_DGRAD_4x4_S2) return 1;
+    const int nchunks = (d->KinP / TNR_CK) * (d->mode == TNR_CONV_4x4_S2 ? 4 : 1);
+    if (tiles >= 192 || nchunks < 32) return 1;
+    int want = (int)((512 + tiles - 1) / tiles);
+    const int max_split = nchunks / 8;          // at least 8 chunks per split
+    if (want > max_split) want = max_split;
+    if (want < 2) return 1;
+    const int per = (nchunks + want - 1) / want;
+    return (nchunks + per - 1) / per;           // every split gets a non-empty chunk range
+}
+
 }  // namespace
 
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
-    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_DGRAD_4x4_S2, "conv: bad mode %d", d->mode);
+    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_1x1, "conv: bad mode %d", d->mode);
     TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->Cin % 4) == 0,
                 "conv: input view must be 4-channel aligned (ctot %d coff %d Cin %d)", d->x.ctot, d->x.coff, d->Cin);
     TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
@@ -102,7 +149,8 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     int sh, sw;  // tile space
     switch (d->mode) {
         case TNR_CONV_3x3:
-            TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3: output must match input size");
+        case TNR_CONV_1x1:
+            TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3 / conv1x1: output must match input size");
             sh = d->Ho; sw = d->Wo;
             break;
         case TNR_CONV_3x3_UP2:
@@ -128,14 +176,56 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     k.tiles_x = tnr_cdiv(sw, tw);
     k.tiles_y = tnr_cdiv(sh, th);
     k.ncb = tnr_cdiv(d->Cout, nt * 32);
-    const int64_t tiles = (int64_t)k.tiles_x * k.tiles_y * k.ncb * d->N * (d->mode == TNR_DGRAD_4x4_S2 ? 4 : 1);
+    int64_t tiles = (int64_t)k.tiles_x * k.tiles_y * k.ncb * d->N * (d->mode == TNR_DGRAD_4x4_S2 ? 4 : 1);
     TNR_REQUIRE(tiles > 0 && tiles < (1LL << 31), "conv: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (big_m) return launch_conv<TNR_CONV_3x3, 32, 1, 4>(k, (int)tiles, s);
-    switch (d->mode) {
-        case TNR_CONV_3x3: return dispatch_conv<TNR_CONV_3x3>(k, tw, nt, (int)tiles, s);
-        case TNR_CONV_3x3_UP2: return dispatch_conv<TNR_CONV_3x3_UP2>(k, tw, nt, (int)tiles, s);
-        case TNR_CONV_4x4_S2: return dispatch_conv<TNR_CONV_4x4_S2>(k, tw, nt, (int)tiles, s);
-        default: return dispatch_conv<TNR_DGRAD_4x4_S2>(k, tw, nt, (int)tiles, s);
+    // split-K for launches that cannot fill the chip (see tnr_conv_workspace_bytes)
+    const int ksplit = conv_ksplit(d, tiles);
+    k.ksplit = 1;
+    k.split_stride = 0;
+    SplitRedK red;
+    if (ksplit > 1 && d->ws != nullptr) {
+        const int64_t plane = (int64_t)d->N * d->Ho * d->Wo * k.KoutP;
+        TNR_REQUIRE(plane * ksplit * (int64_t)sizeof(float) <= d->ws_bytes, "conv: split-K workspace too small");
+        red.ws = d->ws; red.split_stride = (size_t)plane; red.ksplit = ksplit;
+        red.y = k.y; red.y_ct = k.y_ct; red.y_co = k.y_co; red.Cout = k.Cout; red.CoutP = k.KoutP;
+        red.pixels = (long long)d->N * d->Ho * d->Wo;
+        red.bias = k.bias; red.act = k.act; red.slope = k.slope; red.alpha = k.alpha;
+        k.y = d->ws; k.y_ct = k.KoutP; k.y_co = 0; k.Cout = k.KoutP;   // raw partial sums, all padded channels
+        k.bias = nullptr; k.act = TNR_ACT_NONE; k.alpha = 1.f;
+        k.ksplit = ksplit; k.split_stride = (size_t)plane;
+        tiles *= ksplit;
     }
+    int rc;
+    if (big_m) {
+        rc = launch_conv<TNR_CONV_3x3, 32, 1, 4>(k, (int)tiles, s);
+    } else {
+        switch (d->mode) {
+            case TNR_CONV_3x3: rc = dispatch_conv<TNR_CONV_3x3>(k, tw, nt, (int)tiles, s); break;
+            case TNR_CONV_3x3_UP2: rc = dispatch_conv<TNR_CONV_3x3_UP2>(k, tw, nt, (int)tiles, s); break;
+            case TNR_CONV_4x4_S2: rc = dispatch_conv<TNR_CONV_4x4_S2>(k, tw, nt, (int)tiles, s); break;
+            case TNR_CONV_1x1: rc = dispatch_conv<TNR_CONV_1x1>(k, tw, nt, (int)tiles, s); break;
+            default: rc = dispatch_conv<TNR_DGRAD_4x4_S2>(k, tw, nt, (int)tiles, s); break;
+        }
+    }
+    if (rc != TNR_OK || k.ksplit == 1) return rc;
+    const long long work = red.pixels * (red.CoutP >> 2);
+    long long blocks = (work + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, red);
+    return tnr_check_launch("conv_splitk_reduce");
+}
+
+extern "C" int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d) {
+    if (d == nullptr) return 0;
+    int sh = d->Ho, sw = d->Wo;
+    if (d->mode == TNR_DGRAD_4x4_S2) { sh = d->H; sw = d->W; }
+    const int tw = sw >= 32 ? 32 : (sw >= 16 ? 16 : 8);
+    const int nt = d->Cout > 32 ? 2 : 1;
+    const bool big_m = (d->mode == TNR_CONV_3x3) && nt == 1 && tw == 32 && sh >= 16;
+    const int th = (big_m ? 512 : 256) / tw;
+    const int64_t tiles = (int64_t)tnr_cdiv(sw, tw) * tnr_cdiv(sh, th) * tnr_cdiv(d->Cout, nt * 32) * d->N *
+                          (d->mode == TNR_DGRAD_4x4_S2 ? 4 : 1);
+    const int ks = conv_ksplit(d, tiles);
+    return ks > 1 ? (int64_t)ks * d->N * d->Ho * d->Wo * tnr_round_up(d->Cout, 32) * (int64_t)sizeof(float) : 0;
 }

@@ -127,6 +127,27 @@ __global__ void space_to_depth_bwd_kernel(const float *gy, int g_ct, int g_co, f
     }
 }
 
+// patch matrix of a k x k convolution: out[pixel][(ky*k + kx)*C + c] (float4 granularity)
+__global__ void im2col_kernel(const float *x, int x_ct, int x_co, int N, int H, int W, int C, int k, int stride, int pad, int Ho,
+                              int Wo, float *out) {
+    const int c4n = C / 4, kk = k * k;
+    const int64_t total = (int64_t)N * Ho * Wo * kk * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        int64_t q = e / c4n;
+        const int t = (int)(q % kk);
+        const int64_t pix = q / kk;
+        const int ox = (int)(pix % Wo);
+        q = pix / Wo;
+        const int oy = (int)(q % Ho);
+        const int64_t n = q / Ho;
+        const int Y = oy * stride - pad + t / k, X = ox * stride - pad + t % k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (Y >= 0 && Y < H && X >= 0 && X < W) v = *reinterpret_cast<const f32x4 *>(x + ((n * H + Y) * W + X) * x_ct + x_co + c4 * 4);
+        *reinterpret_cast<f32x4 *>(out + (pix * kk + t) * C + c4 * 4) = v;
+    }
+}
+
 __global__ void maxpool2_fwd_kernel(const float *x, int x_ct, int x_co, float *y, int y_ct, int y_co, int N, int H, int W,
                                     int C) {
     const int Ho = H / 2, Wo = W / 2, c4n = C / 4;
@@ -291,6 +312,16 @@ extern "C" int tnr_maxpool2_bwd(tnr_view gy, tnr_view x, tnr_view gx, int32_t N,
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, gy.ptr, gy.ctot,
                        gy.coff, x.ptr, x.ctot, x.coff, gx.ptr, gx.ctot, gx.coff, N, H, W, C);
     return tnr_check_launch("maxpool2_bwd");
+}
+
+extern "C" int tnr_im2col(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k, int32_t stride, int32_t pad,
+                          int32_t Ho, int32_t Wo, float *out, void *stream) {
+    TNR_REQUIRE(view_ok(x) && out != nullptr && (C % 4) == 0 && k >= 1 && stride >= 1 && pad >= 0, "im2col: bad arguments");
+    TNR_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "im2col: output size mismatch");
+    const int64_t total = (int64_t)N * Ho * Wo * k * k * (C / 4);
+    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x.ptr, x.ctot, x.coff, N, H, W,
+                       C, k, stride, pad, Ho, Wo, out);
+    return tnr_check_launch("im2col");
 }
 
 extern "C" int tnr_axpby(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, float a, float b, void *stream) {

@@ -48,6 +48,15 @@ extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, 
             ko = tnr_round_up(Cin, 32); ki = tnr_round_up(Cout, TNR_CK);
             n = (int64_t)16 * ko * ki;
             break;
+        case TNR_PACK_COL_FWD:
+            ko = tnr_round_up(Cout, 32); ki = tnr_round_up(kh * kw * Cin, TNR_CK);
+            n = (int64_t)ko * ki;
+            break;
+        case TNR_PACK_COL_DGRAD3:
+            TNR_REQUIRE(kh == 3 && kw == 3, "pack col dgrad3: kernel must be 3x3");
+            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(9 * Cout, TNR_CK);
+            n = (int64_t)ko * ki;
+            break;
         default:
             tnr_set_error("pack: bad kind %d", kind);
             return TNR_EINVAL;
@@ -85,6 +94,16 @@ __global__ void pack_weights_kernel(const tnr_pack_item *items) {
             const int pp = vch / ki, ci = vch - pp * ki;
             const int ky = 2 * (t >> 1) + (pp >> 1), kx = 2 * (t & 1) + (pp & 1);
             if (co < Cout && ci < Cin) v = it.w[(((size_t)co * Cin + ci) * 4 + ky) * 4 + kx];
+        } else if (it.kind == TNR_PACK_COL_FWD) {      // [co][t*Cin + ci]
+            const int v_ = (int)(e % ki);
+            const int co = (int)(e / ki);
+            const int t = v_ / Cin, ci = v_ - t * Cin;
+            if (co < Cout && t < kh * kw) v = it.w[((size_t)co * Cin + ci) * kh * kw + t];
+        } else if (it.kind == TNR_PACK_COL_DGRAD3) {   // [ci][t*Cout + co], taps flipped
+            const int v_ = (int)(e % ki);
+            const int ci = (int)(e / ki);
+            const int t = v_ / Cout, co = v_ - t * Cout;
+            if (ci < Cin && t < 9) v = it.w[(((size_t)co * Cin + ci) * 3 + (2 - t / 3)) * 3 + (2 - t % 3)];
         } else {  // TNR_PACK_DGRAD_S2: [par][t][ci][co]
             const int co = (int)(e % ki);
             int64_t q = e / ki;

@@ -25,8 +25,17 @@ class ConvOp:
             raise NotImplementedError("conv k=%d s=%d is not on the SR hot path" % (k, s))
         self.i_f = packer.add(mod.weight, pf)
         self.i_d = packer.add(mod.weight, pd) if need_dgrad else None
+        # deep layers that can meet a tiny spatial extent (discriminator tail): column-layout packings for the
+        # im2col + split-K GEMM path (ops.conv_small)
+        deep = mod.in_channels * k * k >= 2048 and not ups
+        self.i_fc = packer.add(mod.weight, ops.PACK_COL_FWD) if deep else None
+        self.i_dc = packer.add(mod.weight, ops.PACK_COL_DGRAD3) if (deep and need_dgrad and k == 3) else None
+        self.k, self.stride = k, s
 
     def fwd(self, x, y, **epi):
+        if self.i_fc is not None and ops.small_gemm_ok(x, y, self.k, self.stride, epi):
+            ops.conv_small(x, self.packer.get(self.i_fc), y, self.k, self.stride, bias=self.mod.bias, **epi)
+            return
         ops.conv(x, self.packer.get(self.i_f), y, mode=self.mode_f, bias=self.mod.bias, **epi)
 
     def fwd_stage(self, x, y, fresh_from=None, **epi):
@@ -35,6 +44,9 @@ class ConvOp:
 
     def dgrad(self, g, gx, **epi):
         """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
+        if self.i_dc is not None and ops.small_gemm_ok(g, gx, 3, 1, epi):
+            ops.conv_small(g, self.packer.get(self.i_dc), gx, 3, 1, **epi)
+            return
         ops.conv(g, self.packer.get(self.i_d), gx, mode=self.mode_d, **epi)
 
     def wgrad_item(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):

@@ -17,8 +17,8 @@ c_l = C.c_int64
 c_p = C.c_void_p
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
-CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2 = 0, 1, 2, 3
-PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2 = 0, 1, 2, 3
+CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2, CONV_1x1 = 0, 1, 2, 3, 4
+PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2, PACK_COL_FWD, PACK_COL_DGRAD3 = 0, 1, 2, 3, 4, 5
 PACK_DENSE_DGRAD = 16      # host-side tag of tnr_pack_dense_dgrad slabs (consumed like PACK_FWD by conv_tile)
 
 
@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("r1", CView), ("r1_ch", c_i), ("beta1", c_f),
         ("r2", CView), ("alpha2", c_f),
         ("m", CView), ("m_lo", c_i), ("m_hi", c_i), ("m_slope", c_f),
+        ("ws", c_p), ("ws_bytes", c_l),
     ]
 
 
@@ -67,6 +68,8 @@ _SIGS = {
     "tnr_pack_dense_dims": (c_i, [c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), C.POINTER(c_l)]),
     "tnr_pack_dense_dgrad": (c_i, [c_p, c_i, c_l, c_p]),
     "tnr_conv_forward": (c_i, [C.POINTER(ConvDesc), c_p]),
+    "tnr_conv_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
+    "tnr_im2col": (c_i, [CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "tnr_conv_chain_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
     "tnr_conv_chain": (c_i, [C.POINTER(ConvDesc), C.POINTER(C.c_int32), c_i, c_p, c_l, C.c_uint32, c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),

@@ -9,8 +9,9 @@ import os
 import torch
 
 from . import hip
-from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
-                  PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView, ConvDesc,
+from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_1x1, CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
+                  PACK_COL_DGRAD3, PACK_COL_FWD, PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView,
+                  ConvDesc,
                   DensePackItem, PackItem, WgradDesc)
 
 
@@ -254,18 +255,26 @@ def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, a
     d.m_slope = m_slope
 
 
+SMALL_GEMM = os.environ.get("TNR_SMALL_GEMM", "1") != "0"   # im2col + split-K GEMM for <= 4096-pixel layers (A/B switch)
+
+
 def conv(x, wp, y, mode=CONV_3x3, **epi):
     d = ConvDesc()
     _conv_desc(d, x, wp, y, mode, **epi)
+    if y.pixels <= 16384 and wp.KinP >= 512:      # candidates for split-K (tnr_conv_workspace_bytes decides)
+        need = hip.load().tnr_conv_workspace_bytes(C.byref(d))
+        if need > 0:
+            ws = WS.get("splitk@%x" % hip.stream(), need, x.buf.device)
+            d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
     if PROFILE is None:
         hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
         return
     t0 = PROFILE.begin()
     hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
-    taps = 9 if mode in (CONV_3x3, CONV_3x3_UP2) else 16
+    taps = {CONV_3x3: 9, CONV_3x3_UP2: 9, CONV_1x1: 1}.get(mode, 16)
     opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
-           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2"}[mode]
+           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1"}[mode]
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
 
 
@@ -321,6 +330,26 @@ def chain_error_flag():
         if isinstance(key, tuple) and key[0] == "chain":
             bad += int(ws[-1].item() != 0)
     return bad
+
+
+def small_gemm_ok(x, y, k, stride, epi):
+    """A k x k convolution runs as im2col + split-K GEMM when it has <= 4096 output pixels (tiles of the direct
+    kernel would be mostly padding and too few to fill the chip) and a plain epilogue."""
+    if not SMALL_GEMM or y.pixels > 4096 or (y.pixels % 8) != 0 or (x.C % 4) != 0:
+        return False
+    return not any(epi.get(n) is not None for n in ("r1", "r2", "mask"))
+
+
+def conv_small(x, wp_col, y, k, stride, pad=1, **epi):
+    """y = conv_kxk(x) through the patch matrix: tnr_im2col, then TNR_CONV_1x1 over [pixels][k*k*C] (split-K)."""
+    M, K = y.pixels, k * k * x.C
+    dev = x.buf.device
+    col = WS.get("im2col@%x" % hip.stream(), M * K * 4, dev)
+    hip.check(hip.load().tnr_im2col(x.c(), x.N, x.H, x.W, x.C, k, stride, pad, y.H, y.W, col.data_ptr(), hip.stream()), "im2col")
+    wimg = 32 if M % 32 == 0 else (16 if M % 16 == 0 else 8)
+    cimg = col.view(torch.float32)[:M * K].view(1, M // wimg, wimg, K)
+    yimg = View(y.buf.view(1, M // wimg, wimg, y.ctot), y.coff, y.C)
+    conv(View(cimg), wp_col, yimg, mode=CONV_1x1, **epi)
 
 
 WGRAD_GROUP_MAX = 8
