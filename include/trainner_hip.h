@@ -40,8 +40,11 @@ enum {
     TNR_CONV_3x3_UP2 = 1,  /* nearest x2 (block.py:326-371,390-404) folded into the k3 s1 p1 gather       */
     TNR_CONV_4x4_S2 = 2,   /* k4 s2 p1: Discriminator_VGG even layers (discriminators.py:24-34)           */
     TNR_DGRAD_4x4_S2 = 3,  /* data-gradient of k4 s2 p1 (aten convolution_backward), parity-decomposed    */
-    TNR_CONV_1x1 = 4       /* k1 s1: the GEMM behind tnr_im2col for the small-spatial layers of the       */
+    TNR_CONV_1x1 = 4,      /* k1 s1: the GEMM behind tnr_im2col for the small-spatial layers of the       */
                            /* discriminator tail (discriminators.py:24-36 at 16x16 and below)             */
+    TNR_CONV_3x3_C4 = 5    /* k3 s1 p1 over a <= 4-channel NHWC4 image (VGG conv1_1, D conv0, and the     */
+                           /* data-gradient of G's last conv): the 9 taps are folded into K = 36 -> 48    */
+                           /* inside the stager instead of padding 3 channels to 16 per tap               */
 };
 
 /* weight packings produced by tnr_pack_weights */
@@ -51,7 +54,9 @@ enum {
     TNR_PACK_FWD_S2D = 2,   /* [4][KoutP][4*KinP] (space-to-depth view of k4 s2)                           */
     TNR_PACK_DGRAD_S2 = 3,  /* [4 parities][4][KoutP=ci][KinP=co]                                          */
     TNR_PACK_COL_FWD = 4,   /* [1][KoutP][KinP = kh*kw*Cin]: column (ky*kw+kx)*Cin+ci of tnr_im2col          */
-    TNR_PACK_COL_DGRAD3 = 5 /* [1][KoutP=ci][KinP = 9*Cout]: column t*Cout+co <- W[co][ci][2-ty][2-tx]      */
+    TNR_PACK_COL_DGRAD3 = 5,/* [1][KoutP=ci][KinP = 9*Cout]: column t*Cout+co <- W[co][ci][2-ty][2-tx]      */
+    TNR_PACK_C4_FWD = 6,    /* [1][KoutP][48]: column 4*t + ci (Cin <= 4)        for TNR_CONV_3x3_C4             */
+    TNR_PACK_C4_DGRAD3 = 7  /* [1][KoutP=ci][48]: column 4*t + co (Cout <= 4), taps flipped                     */
 };
 
 typedef struct tnr_view {

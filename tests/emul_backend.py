@@ -329,6 +329,7 @@ def install(monkeypatch):
     g = globals()
     for n in _NAMES:
         monkeypatch.setattr(ops, n, g[n])
+    monkeypatch.setattr(ops, "IMAGE_C4", False)
     monkeypatch.setattr(ops, "SMALL_GEMM", False)     # the emulation has no im2col path: layers stay direct convolutions
     monkeypatch.setattr(ops, "WeightPacker", EmulPacker)
     monkeypatch.setattr(ops, "DensePacker", EmulDensePacker)

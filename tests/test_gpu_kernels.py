@@ -310,6 +310,32 @@ def test_conv_small_im2col_splitk(case):
     close(to_nchw(y, 0, y.shape[3]), ref, what="conv_small " + kind)
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 37), (1, 64, 96)])
+def test_conv3x3_image_channels_c4(shape):
+    """TNR_CONV_3x3_C4: 3 -> 64 forward over an NHWC4 image and the 64 <- 3 data-gradient (taps folded into K)."""
+    ops = _ops()
+    N, H, W = shape
+    x = rnd(N, 3, H, W, seed=121)
+    w = rnd(64, 3, 3, 3, seed=122, lo=-0.2, hi=0.2)
+    b = rnd(64, seed=123)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    x4 = nhwc_buf(F.pad(x, (0, 0, 0, 0, 0, 1)), fill=0.0)
+    wp, _ = pack(ops, w.to(DEV), ops.PACK_C4_FWD)
+    y = torch.zeros((N, H, W, 64), device=DEV)
+    ops.conv(ops.View(x4), wp, ops.View(y), mode=ops.CONV_3x3_C4, bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2)
+    close(to_nchw(y, 0, 64), ref, what="c4 forward")
+    # data-gradient of a 64 -> 3 convolution: incoming gradient has 3 (+1 zero) channels, result 64
+    w2 = rnd(3, 64, 3, 3, seed=124, lo=-0.2, hi=0.2)
+    xin = rnd(N, 64, H, W, seed=125).requires_grad_(True)
+    g = rnd(N, 3, H, W, seed=126)
+    (gref,) = torch.autograd.grad(F.conv2d(xin, w2, None, padding=1), xin, g)
+    g4 = nhwc_buf(F.pad(g, (0, 0, 0, 0, 0, 1)), fill=0.0)
+    wp2, _ = pack(ops, w2.to(DEV), ops.PACK_C4_DGRAD3)
+    gx = torch.zeros((N, H, W, 64), device=DEV)
+    ops.conv(ops.View(g4), wp2, ops.View(gx), mode=ops.CONV_3x3_C4)
+    close(to_nchw(gx, 0, 64), gref, what="c4 dgrad")
+
+
 def test_conv_direct_splitk():
     """The direct 3x3 kernel with a split-K workspace (512 -> 512 channels at 16x16: 16 tiles for 512 slots)."""
     ops = _ops()

@@ -47,7 +47,8 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
-    constexpr bool P11 = (MODE == TNR_CONV_1x1);
+    constexpr bool IMG4 = (MODE == TNR_CONV_3x3_C4);     // 3x3 over a 4-channel image: the 9 taps become K (36 -> 48)
+    constexpr bool P11 = (MODE == TNR_CONV_1x1) || IMG4;  // no halo, a single "tap"
     constexpr int KH = S2D ? 2 : (P11 ? 1 : 3);
     constexpr int NTAPS = (S2D || DG2) ? 4 : (P11 ? 1 : 9);
     constexpr int HT = TH + KH - 1, WT = TW + KH - 1;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     constexpr int W_ITEMS = NTAPS * NC * 4, W_IT = (W_ITEMS + 255) / 256;
     int in_off[IN_IT];   // element offset into x (without the chunk's channel offset), -1 = zero fill
     int w_off[W_IT];     // element offset into the packed weights (without chunk offset), -1 = zero fill
-    if (!S2D) {
+    if (!S2D && !IMG4) {
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int i = tid + it * 256;
@@ -147,11 +148,21 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 const int Y = 2 * (ty0 + hr) - 1 + (pp >> 1), X = 2 * (tx0 + hc) - 1 + (pp & 1);
                 const bool ok = (i < IN_ITEMS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
                 off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+            } else if (IMG4) {
+                // virtual channels 16*chunk + 4*q .. +3 = the 4 image channels of tap t = 4*chunk + q
+                const int pix = i >> 2;
+                const int hr = pix / WT, hc = pix - hr * WT;
+                const int t = chunk * 4 + q;
+                const int Y = ty0 + hr + t / 3 - 1, X = tx0 + hc + t % 3 - 1;
+                const bool ok = (i < IN_ITEMS) & (t < 9) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co - c0) : -1;   // (+ c0 below cancels: whole pixel)
             } else {
                 off = in_off[it];
             }
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
+            if (IMG4) {
+                if (off != -1) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)(off + c0));
+            } else if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
                 const unsigned bo = (off >= 0 && c0 + q * 4 < a.Cin) ? (unsigned)(off + c0) * 4u : 0xfffffff0u;
                 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_AUX_SC0_SC1));
             } else if (off >= 0 && c0 + q * 4 < a.Cin) {

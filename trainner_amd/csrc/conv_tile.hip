@@ -122,7 +122,9 @@ int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
 
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
-    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_1x1, "conv: bad mode %d", d->mode);
+    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_3x3_C4, "conv: bad mode %d", d->mode);
+    if (d->mode == TNR_CONV_3x3_C4)
+        TNR_REQUIRE(d->x.ctot == 4 && d->x.coff == 0 && d->Cin == 4 && d->KinP == 48, "conv3x3_c4: needs an NHWC4 input view and a C4 packing");
     TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->Cin % 4) == 0,
                 "conv: input view must be 4-channel aligned (ctot %d coff %d Cin %d)", d->x.ctot, d->x.coff, d->Cin);
     TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
@@ -150,6 +152,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     switch (d->mode) {
         case TNR_CONV_3x3:
         case TNR_CONV_1x1:
+        case TNR_CONV_3x3_C4:
             TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3 / conv1x1: output must match input size");
             sh = d->Ho; sw = d->Wo;
             break;
@@ -205,6 +208,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
             case TNR_CONV_3x3_UP2: rc = dispatch_conv<TNR_CONV_3x3_UP2>(k, tw, nt, (int)tiles, s); break;
             case TNR_CONV_4x4_S2: rc = dispatch_conv<TNR_CONV_4x4_S2>(k, tw, nt, (int)tiles, s); break;
             case TNR_CONV_1x1: rc = dispatch_conv<TNR_CONV_1x1>(k, tw, nt, (int)tiles, s); break;
+            case TNR_CONV_3x3_C4: rc = dispatch_conv<TNR_CONV_3x3_C4>(k, tw, nt, (int)tiles, s); break;
             default: rc = dispatch_conv<TNR_DGRAD_4x4_S2>(k, tw, nt, (int)tiles, s); break;
         }
     }

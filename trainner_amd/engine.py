@@ -31,8 +31,23 @@ class ConvOp:
         self.i_fc = packer.add(mod.weight, ops.PACK_COL_FWD) if deep else None
         self.i_dc = packer.add(mod.weight, ops.PACK_COL_DGRAD3) if (deep and need_dgrad and k == 3) else None
         self.k, self.stride = k, s
+        # <= 4-channel image on either side of a 3x3 layer: taps folded into K (TNR_CONV_3x3_C4)
+        img = k == 3 and s == 1 and not ups
+        self.i_f4 = packer.add(mod.weight, ops.PACK_C4_FWD) if (img and mod.in_channels <= 4) else None
+        self.i_d4 = packer.add(mod.weight, ops.PACK_C4_DGRAD3) if (img and need_dgrad and mod.out_channels <= 4) else None
+
+    @staticmethod
+    def _image4(v):
+        """The whole 4-channel pixel of an NHWC4 image view (3 channels + the zero pad), or None."""
+        if ops.IMAGE_C4 and v.ctot == 4 and v.coff == 0:
+            return v if v.C == 4 else ops.View(v.buf)
+        return None
 
     def fwd(self, x, y, **epi):
+        x4 = self._image4(x) if self.i_f4 is not None else None
+        if x4 is not None:
+            ops.conv(x4, self.packer.get(self.i_f4), y, mode=ops.CONV_3x3_C4, bias=self.mod.bias, **epi)
+            return
         if self.i_fc is not None and ops.small_gemm_ok(x, y, self.k, self.stride, epi):
             ops.conv_small(x, self.packer.get(self.i_fc), y, self.k, self.stride, bias=self.mod.bias, **epi)
             return
@@ -44,6 +59,10 @@ class ConvOp:
 
     def dgrad(self, g, gx, **epi):
         """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
+        g4 = self._image4(g) if self.i_d4 is not None else None
+        if g4 is not None:
+            ops.conv(g4, self.packer.get(self.i_d4), gx, mode=ops.CONV_3x3_C4, **epi)
+            return
         if self.i_dc is not None and ops.small_gemm_ok(g, gx, 3, 1, epi):
             ops.conv_small(g, self.packer.get(self.i_dc), gx, 3, 1, **epi)
             return

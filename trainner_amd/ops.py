@@ -9,8 +9,8 @@ import os
 import torch
 
 from . import hip
-from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_1x1, CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
-                  PACK_COL_DGRAD3, PACK_COL_FWD, PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView,
+from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_1x1, CONV_3x3, CONV_3x3_C4, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
+                  PACK_C4_DGRAD3, PACK_C4_FWD, PACK_COL_DGRAD3, PACK_COL_FWD, PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView,
                   ConvDesc,
                   DensePackItem, PackItem, WgradDesc)
 
@@ -255,6 +255,7 @@ def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, a
     d.m_slope = m_slope
 
 
+IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel for <= 4-channel image layers (A/B switch)
 SMALL_GEMM = os.environ.get("TNR_SMALL_GEMM", "1") != "0"   # im2col + split-K GEMM for <= 4096-pixel layers (A/B switch)
 
 
@@ -271,10 +272,10 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
         return
     t0 = PROFILE.begin()
     hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
-    taps = {CONV_3x3: 9, CONV_3x3_UP2: 9, CONV_1x1: 1}.get(mode, 16)
+    taps = {CONV_3x3: 9, CONV_3x3_UP2: 9, CONV_1x1: 1, CONV_3x3_C4: 9}.get(mode, 16)
     opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
-           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1"}[mode]
+           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1", CONV_3x3_C4: "conv_tile_3x3_c4"}[mode]
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
 
 
