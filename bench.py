@@ -132,8 +132,8 @@ def cpu_baseline(crop, steps=2):
                       "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps)}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the 3x3 conv family (average over its launches) from the newest committed
+def pmc_traffic(family="conv_tile_3x3"):
+    """HBM bytes per launch of the dominant kernel family (average over its launches) from the newest committed
     rocprofv3 --pmc summary (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same command).  Counters cannot be read from inside the timed
     process, so this is the recorded figure for the same kernels and shapes; None if no summary exists."""
@@ -144,7 +144,8 @@ def pmc_traffic():
         return None
     try:
         with open(files[-1]) as fh:
-            return round(json.load(fh)["conv_tile_3x3"]["hbm_bytes_per_launch"])
+            e = json.load(fh)[family]
+            return round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -219,13 +220,18 @@ def main():
             for key, v in rows:
                 print("%-22s %5d %5d %5d %4d %7d %9.3f %8.1f" % (key[0], key[1], key[2], key[3], key[4], v["launches"] // nprof,
                                                              v["ms"] / nprof, v["flops"] / (v["ms"] * 1e-3) / 1e12), file=sys.stderr)
-        dom = summ.get("conv_tile_3x3")
+        # dominant kernel: the dense-block chain (RRDB trunk, forward + data-gradient) when it is in use,
+        # else the per-layer 3x3 kernel family
+        fam = max((f for f in ("conv_chain", "conv_tile_3x3") if f in summ), key=lambda f: summ[f]["ms"], default=None)
+        dom = summ.get(fam)
         if dom:
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
-            roof = {"bound": "mfma", "kernel": "conv_tile_kernel<3x3> (forward + data-gradient launches)",
+            kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
+                     "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
+            roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(fam),
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],

@@ -19,20 +19,23 @@ def read(path, counter):
 
 def main(fetch_csv, write_csv, out_json):
     f, w = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
-    kernels, fam_bytes, fam_n = {}, 0.0, 0
+    kernels = {}
+    fams = {"conv_tile_3x3": ["conv_tile_kernel<0,", 0.0, 0], "conv_chain": ["conv_chain_kernel", 0.0, 0]}
     for k in f:
         if k not in w:
             continue
         n = f[k][0]
         b = (2.0 * f[k][1] + w[k][1]) * 1024.0
         kernels[k] = {"dispatches": n, "hbm_bytes_per_launch": b / max(n, 1)}
-        if k.startswith("conv_tile_kernel<0,"):
-            fam_bytes += b
-            fam_n += n
-    json.dump({"source": [fetch_csv, write_csv],
-               "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, separate --pmc passes",
-               "conv_tile_3x3": {"dispatches": fam_n, "hbm_bytes_per_launch": fam_bytes / max(fam_n, 1)},
-               "kernels": kernels}, open(out_json, "w"), indent=1)
+        for fam in fams.values():
+            if k.startswith(fam[0]):
+                fam[1] += b
+                fam[2] += n
+    out = {"source": [fetch_csv, write_csv], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, separate --pmc passes",
+           "kernels": kernels}
+    for name, (_, b, n) in fams.items():
+        out[name] = {"dispatches": n, "hbm_bytes_per_launch": b / max(n, 1)}
+    json.dump(out, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
