@@ -39,3 +39,7 @@ def test_vgg_schedule():
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
+
+
+def test_validation_forward_and_self_ensemble(tmp_path):
+    TS.test_validation_forward_and_self_ensemble(tmp_path)

@@ -112,6 +112,48 @@ def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
         assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
 
 
+def test_validation_forward_and_self_ensemble(tmp_path):
+    """SRModel.test() (no-grad forward, sr_model.py:268-276) and test_x8() (8-fold geometric self-ensemble,
+    :277-315) on a non-square LR batch against the oracle's functional RRDBNet."""
+    kw = dict(nb=1, batch=1, crop=64, d_nf=16)
+    opt, model = build_engine_model(kw, tmp_path)
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 303)
+    model.netG.load_state_dict(g)
+    LR = detrand.uniform((2, 3, 12, 20), 31, 0.0, 1.0)
+    model.feed_data({"LR": LR}, need_HR=False)
+    model.test()
+    ref = O.rrdbnet_forward(LR, g, nb=1)
+    got = model.fake_H.detach().cpu()
+    assert got.shape == ref.shape == (2, 3, 48, 80)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert model.netG.training                      # test() puts the generator back into train mode
+
+    model.test_x8()
+    outs = []
+    for i in range(8):                              # bit 0: flip W, bit 1: flip H, bit 2: transpose (applied in that order)
+        v = LR
+        if i & 1:
+            v = v.flip(3)
+        if i & 2:
+            v = v.flip(2)
+        if i & 4:
+            v = v.transpose(2, 3)
+        o = O.rrdbnet_forward(v.contiguous(), g, nb=1)
+        if i & 4:
+            o = o.transpose(2, 3)
+        if i & 2:
+            o = o.flip(2)
+        if i & 1:
+            o = o.flip(3)
+        outs.append(o)
+    ens = torch.cat(outs, 0).mean(0, keepdim=True)
+    got = model.fake_H.detach().cpu()
+    assert got.shape == ens.shape == (1, 3, 48, 80)
+    assert (got - ens).abs().max().item() <= 2e-5 * max(1.0, ens.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        model.test_chop()
+
+
 def test_full_config_properties(tmp_path):
     """BASELINE.json configs[1] (batch 16, 128 -> 512, all losses): properties that do not need the CPU
     oracle at full size -- finiteness, run-to-run bit reproducibility, and batch linearity of the

@@ -104,6 +104,39 @@ class SRModel(BaseModel):
             self.forward()
         self.netG.train()
 
+    def test_x8(self, CEM_net=None):
+        """Geometric self-ensemble (sr_model.py:277-315): the 8 flip / transpose variants of the LR batch are
+        super-resolved, mapped back and averaged.  Variant i is built by the reference's doubling order
+        (i bit 0: flip W, bit 1: flip H, bit 2: transpose) and undone in the order transpose, flip H, flip W;
+        like the reference the result is the mean over the concatenated batch dimension ([1, C, H, W])."""
+        self.netG.eval()
+
+        def tf(v, op):
+            if op == "v":
+                return v.flip(3).contiguous()
+            if op == "h":
+                return v.flip(2).contiguous()
+            return v.transpose(2, 3).contiguous()
+
+        lr_list = [self.var_L]
+        for op in ("v", "h", "t"):
+            lr_list.extend([tf(t, op) for t in lr_list])
+        with torch.no_grad():
+            sr_list = [self.forward(data=aug) for aug in lr_list]
+        for i in range(len(sr_list)):
+            if i > 3:
+                sr_list[i] = tf(sr_list[i], "t")
+            if i % 4 > 1:
+                sr_list[i] = tf(sr_list[i], "h")
+            if (i % 4) % 2 == 1:
+                sr_list[i] = tf(sr_list[i], "v")
+        self.fake_H = torch.cat(sr_list, dim=0).mean(dim=0, keepdim=True)
+        self.netG.train()
+
+    def test_chop(self, patch_size=200, step=1.0, CEM_net=None):
+        raise NotImplementedError("test_chop (patch-wise inference, sr_model.py:317-350) belongs to the validation path, "
+                                  "SURVEY.md section 8(f) row 4 -- not part of the training hot path built so far")
+
     def get_current_log(self):
         return self.log_dict.materialize()
 
