@@ -231,11 +231,12 @@ def test_wgrad_cin_split():
     close(dw.cpu(), ref, tol=5e-5, what="wgrad cin split")
 
 
-@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 16, 32), (3, 128, 128)])
+@pytest.mark.parametrize("shape", [(2, 40, 72), (1, 16, 32), (3, 128, 128), (20, 128, 128)])
 def test_conv_chain_equals_per_layer_launches(shape):
     """A dense block's five convolutions (fused LeakyReLU, residual epilogue) as one tnr_conv_chain launch must
-    equal five tnr_conv_forward launches bit for bit -- including across tile borders (neighbour hand-off)
-    and with more tiles than one residency round is not needed here: (3,128,128) = 96 tiles, (2,40,72) ragged."""
+    equal five tnr_conv_forward launches bit for bit -- including across tile borders (neighbour hand-off):
+    (2,40,72) ragged tiles, (3,128,128) = 96 tiles, (20,128,128) = 640 tiles > the 512 resident workgroups, so
+    workgroups walk several tiles per stage and publish across tile boundaries."""
     ops = _ops()
     N, H, W = shape
     nf, gc = 64, 32
