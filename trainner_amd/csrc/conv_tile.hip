@@ -2,8 +2,8 @@
 // exact f32 == an fmaf chain), NHWC views, fused bias / activation / residual / mask epilogue.
 //
 // One workgroup = 256 threads = 4 waves (one per SIMD), two workgroups per CU (LDS <= 80 KiB).
-//   M  = 256 output pixels (TH x TW spatial tile; TW in {32,16,8}); wave w owns pixels
-//        [64w, 64w+64) = two 32-row MFMA tiles
+//   M  = 128*MT output pixels (TH x TW spatial tile; TW in {32,16,8}; MT = 2, or 4 for 32-cout 3x3 layers);
+//        wave w owns MT 32-pixel MFMA tiles
 //   N  = NT*32 output channels (NT in {1,2})
 //   K  = taps x Cin, streamed in chunks of 16 channels: the (TH+KH-1) x (TW+KW-1) halo tile of the
 //        chunk and the chunk's [tap][cout][16] weight slab are staged in LDS with a 20-dword pixel
@@ -14,6 +14,10 @@
 //   3x3 s1 p1 of up2(x)  same, stager reads x[Y>>1][X>>1]          (block.py upconv_block)
 //   4x4 s2 p1            as a 2x2 s1 conv over the space-to-depth view: chunk = (parity, 16 ch)
 //   dgrad of 4x4 s2 p1   per output parity (py,px): 4 of the 9 halo taps, output scattered at stride 2
+//   1x1                  no halo, one tap: the GEMM over tnr_im2col's patch matrix (small-spatial layers)
+//   3x3 over <= 4 ch     the 9 taps gathered into K = 36 -> 48 by the stager (RGB image layers)
+// This file: the one-launch-per-layer kernel (optionally split along K, with a reduce launch) and the host
+// side of tnr_conv_forward.  The device body is conv_body.h; conv_chain.hip runs it for several layers per launch.
 #include "conv_body.h"
 
 namespace {
