@@ -133,3 +133,33 @@ def test_psnr_definition():
     b = torch.full((1, 3, 16, 16), 10.0 / 255.0)
     import math
     assert abs(O.psnr_reference(a, b) - 20 * math.log10(255.0 / 10.0)) < 1e-9
+
+
+def test_esrgan_checkpoint_key_converters():
+    """old-arch <-> new-arch ESRGAN key renaming (networks.py:400-481 of the reference) for any trunk length:
+    round trip restores keys, order and tensors; the new-arch names are the community ones; model_val applies
+    the conversion only to rrdb_net / esrgan generators."""
+    import torch
+    from collections import OrderedDict
+    from trainner_amd.models import networks as NW
+    old = OrderedDict()
+    old["model.0.weight"], old["model.0.bias"] = torch.zeros(4, 3, 3, 3), torch.zeros(4)
+    for b in range(2):
+        for r in (1, 2, 3):
+            for c in range(1, 6):
+                pre = "model.1.sub.%d.RDB%d.conv%d.0" % (b, r, c)
+                old[pre + ".weight"], old[pre + ".bias"] = torch.full((1,), float(100 * b + 10 * r + c)), torch.zeros(1)
+    old["model.1.sub.2.weight"], old["model.1.sub.2.bias"] = torch.ones(1), torch.ones(1)
+    for i in (3, 6, 8, 10):
+        old["model.%d.weight" % i], old["model.%d.bias" % i] = torch.full((1,), float(i)), torch.zeros(1)
+    new = NW.normal2mod(old)
+    assert list(new)[:2] == ["conv_first.weight", "conv_first.bias"]
+    assert "RRDB_trunk.1.RDB3.conv5.weight" in new and "trunk_conv.bias" in new and "conv_last.weight" in new
+    assert float(new["RRDB_trunk.1.RDB2.conv4.weight"]) == 124.0 and float(new["HRconv.weight"]) == 8.0
+    back = NW.mod2normal(new)
+    assert list(back) == list(old) and all(torch.equal(back[k], old[k]) for k in old)
+    assert NW.mod2normal(old) is old and NW.normal2mod(new) is new            # already in the target layout
+    opt = {"network_G": {"type": "esrgan"}}
+    assert list(NW.model_val(opt, new, "G")) == list(old)
+    assert NW.model_val({"network_G": {"type": "sr_resnet"}}, new, "G") is new
+    assert NW.model_val(opt, new, "D") is new

@@ -121,12 +121,12 @@ class BaseModel:
             load_net = load_net["state_dict"]
         if param_key is not None:
             load_net = load_net[param_key]
+        if model_type:                     # e.g. new-arch ESRGAN keys -> this package's layout
+            load_net = model_val(opt_net=self.opt, state_dict=load_net, model_type=model_type)
         own = network.state_dict()
         if len(load_net) == len(own):      # same layout, mismatching shapes keep the initialised tensor
             load_net = OrderedDict((k, v if v.size() == own[k].size() else own[k])
                                    for k, v in zip(own.keys(), load_net.values()))
-        if model_type:
-            load_net = model_val(opt_net=self.opt, state_dict=load_net, model_type=model_type)
         network.load_state_dict(load_net, strict=bool(strict))
 
     def save_training_state(self, epoch, iter_step, latest=False):

@@ -10,6 +10,7 @@ Same entry points and option handling as codes/models/networks.py: `define_G(opt
   * kinds outside the SR hot path raise NotImplementedError instead of importing other archs.
 """
 import functools
+from collections import OrderedDict
 import logging
 
 import torch.nn as nn
@@ -107,8 +108,58 @@ def define_F(opt):
     return perceptual.FeatureExtractor(listen_list=list(w_l.keys()), net=net, z_norm=bool(z_norm), pooling_stride=2, **kw)
 
 
+# ESRGAN checkpoints exist in two key layouts: the "old arch" one this package (and the reference) uses
+# (model.0 / model.1.sub.<i>.RDBk.convj.0 / model.3,6,8,10) and the "new arch" one of later community models
+# (conv_first / RRDB_trunk.<i>.RDBk.convj / trunk_conv / upconv1,2 / HRconv / conv_last).  Same tensors, other
+# names (codes/models/networks.py:400-481).  The trunk length is read from the keys, not assumed to be 23.
+_NEW_HEAD = {"conv_first": "model.0", "upconv1": "model.3", "upconv2": "model.6", "HRconv": "model.8", "conv_last": "model.10"}
+
+
+def mod2normal(state_dict):
+    """new-arch -> old-arch ESRGAN keys (no-op for anything else)."""
+    if "conv_first.weight" not in state_dict:
+        return state_dict
+    nb = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("RRDB_trunk."))
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        name, _, leaf = k.rpartition(".")                       # leaf: weight | bias
+        if name in _NEW_HEAD:
+            out["%s.%s" % (_NEW_HEAD[name], leaf)] = v
+        elif name == "trunk_conv":
+            out["model.1.sub.%d.%s" % (nb, leaf)] = v
+        elif name.startswith("RRDB_trunk."):
+            out["model.1.sub.%s.0.%s" % (name[len("RRDB_trunk."):], leaf)] = v
+        else:
+            raise KeyError("unexpected key %r in a new-arch ESRGAN checkpoint" % k)
+    return out
+
+
+def normal2mod(state_dict):
+    """old-arch -> new-arch ESRGAN keys (for exporting to tools that expect the new layout)."""
+    if "model.0.weight" not in state_dict:
+        return state_dict
+    old_head = {v: k for k, v in _NEW_HEAD.items()}
+    trunk = [k for k in state_dict if k.startswith("model.1.sub.")]
+    nb = max(int(k.split(".")[3]) for k in trunk)               # index of the trunk's closing conv
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        name, _, leaf = k.rpartition(".")
+        if name in old_head:
+            out["%s.%s" % (old_head[name], leaf)] = v
+        elif name == "model.1.sub.%d" % nb:
+            out["trunk_conv.%s" % leaf] = v
+        elif name.startswith("model.1.sub.") and name.endswith(".0"):
+            out["RRDB_trunk.%s.%s" % (name[len("model.1.sub."):-2], leaf)] = v
+        else:
+            raise KeyError("unexpected key %r in an old-arch ESRGAN checkpoint" % k)
+    return out
+
+
 def model_val(opt_net=None, state_dict=None, model_type=None):
-    """Checkpoint key validation hook (codes/models/networks.py:483-497).  The old<->new ESRGAN key
-    converters are a 'next' row; state_dicts in the reference's own (old-arch)
-    layout load unchanged."""
+    """Checkpoint key validation on load (codes/models/networks.py:483-497): a generator of type
+    rrdb_net / esrgan accepts new-arch community checkpoints by renaming them to this package's layout."""
+    if model_type == "G":
+        kind = str(((opt_net or {}).get("network_G") or {}).get("type", "")).lower()
+        if kind in ("rrdb_net", "esrgan"):
+            return mod2normal(state_dict)
     return state_dict
