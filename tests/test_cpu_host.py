@@ -163,3 +163,23 @@ def test_esrgan_checkpoint_key_converters():
     assert list(NW.model_val(opt, new, "G")) == list(old)
     assert NW.model_val({"network_G": {"type": "sr_resnet"}}, new, "G") is new
     assert NW.model_val(opt, new, "D") is new
+
+
+def test_patch_extraction_and_recomposition_match_reference():
+    """trainner_amd.dataops.common against fixtures produced by the reference's own extract_patches_2d /
+    recompose_tensor (oracle/make_golden_patches.py): exact-grid, ragged, 25 % and 50 % overlap."""
+    import os
+    import torch
+    from trainner_amd.dataops.common import extract_patches_2d, recompose_tensor
+    fx = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patches.pt"), weights_only=False)
+    assert set(fx) == {"exact_grid", "ragged", "overlap_075", "overlap_05"}
+    for name, c in fx.items():
+        B, C, H, W, p, step, scale = c["spec"]
+        pat = extract_patches_2d(c["img"], (p, p), step=[step, step], batch_first=True)
+        assert pat.shape == c["patches"].shape and torch.equal(pat, c["patches"]), name
+        other = extract_patches_2d(c["img"], (p, p), step=[step, step])
+        assert torch.equal(other.permute(1, 0, 2, 3, 4), pat), name
+        sr = c["sr"][:c["sr"].size(0) // B] if B > 1 else c["sr"]
+        rec = recompose_tensor(sr, H, W, step=step, scale=scale)
+        assert rec.shape == c["recomposed"].shape, name
+        assert (rec - c["recomposed"]).abs().max().item() <= 1e-6, name

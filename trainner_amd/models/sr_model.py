@@ -134,8 +134,19 @@ class SRModel(BaseModel):
         self.netG.train()
 
     def test_chop(self, patch_size=200, step=1.0, CEM_net=None):
-        raise NotImplementedError("test_chop (patch-wise inference, sr_model.py:317-350) belongs to the validation path, "
-                                  "SURVEY.md section 8(f) row 4 -- not part of the training hot path built so far")
+        """Patch-wise inference for images that do not fit in one forward (sr_model.py:317-350): the LR image is cut
+        into patch_size x patch_size windows (step = fraction of the patch between window starts, 0.5 .. 1.0), each is
+        super-resolved on its own and the results are cross-faded back together.  Like the reference this handles one
+        image per call (batch 1)."""
+        from ..dataops.common import extract_patches_2d, recompose_tensor
+        _, _, h, w = self.var_L.size()
+        patch_size = min(h, w, patch_size)
+        patches = extract_patches_2d(self.var_L, (patch_size, patch_size), step=[step, step], batch_first=True).squeeze(0)
+        self.netG.eval()
+        with torch.no_grad():
+            sr = [self.forward(data=patches[i:i + 1].contiguous()) for i in range(patches.size(0))]
+        self.fake_H = recompose_tensor(torch.cat(sr, 0), h, w, step=step, scale=self.opt["scale"])
+        self.netG.train()
 
     def get_current_log(self):
         return self.log_dict.materialize()
