@@ -165,6 +165,15 @@ int tnr_im2col(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k
 int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *stage0);
 int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,
                    uint32_t epoch, void *stream);
+/* 3x3 s1 p1 convolution with Cout <= 4 on the vector ALUs (one thread = one pixel x 4 outputs): G's last conv
+ * (RRDBNet_arch.py:44) and the data-gradients that end in the RGB image (VGG features[0], D's first conv).
+ * y[c] = (sum + bias[c]) * alpha for c < Cout.  Weights: tnr_conv_thin_pack (dgrad = 0: forward of a layer with
+ * Cout <= 4; dgrad = 1: data-gradient of a layer with Cin <= 4, then Cin/Cout of tnr_conv_thin are the layer's
+ * Cout/Cin) into tnr_conv_thin_pack_floats(reduction channels) floats.                                     */
+int64_t tnr_conv_thin_pack_floats(int32_t reduce_channels);
+int tnr_conv_thin_pack(const float *w_oihw, float *wp, int32_t Cout, int32_t Cin, int32_t dgrad, void *stream);
+int tnr_conv_thin(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *wp, tnr_view y, int32_t Cout,
+                  const float *bias, float alpha, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 /* n <= TNR_WGRAD_GROUP_MAX layers in ONE launch (+ one reduce launch).  The layers must share mode and

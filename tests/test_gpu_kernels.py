@@ -337,6 +337,30 @@ def test_conv3x3_image_channels_c4(shape):
     close(to_nchw(gx, 0, 64), gref, what="c4 dgrad")
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 33, 16, 16), (1, 64, 96, 64)])
+def test_conv_thin_small_cout(shape):
+    """tnr_conv_thin: 64 -> 3 forward (bias, alpha) and the 3 <- 64 data-gradient of a 3 -> 64 layer (vector-ALU kernel)."""
+    ops = _ops()
+    N, H, W, C = shape
+    x = rnd(N, C, H, W, seed=131)
+    w = rnd(3, C, 3, 3, seed=132, lo=-0.1, hi=0.1)
+    b = rnd(3, seed=133)
+    ref = 0.5 * F.conv2d(x, w, b, padding=1)
+    y = torch.full((N, H, W, 4), 9.0, device=DEV)
+    ops.conv_thin(ops.View(nhwc_buf(x)), w.to(DEV), ops.View(y, 0, 3), bias=b.to(DEV), alpha=0.5)
+    close(to_nchw(y, 0, 3), ref, what="thin forward")
+    assert (y[..., 3] == 9.0).all()                   # a 3-channel view leaves the 4th channel alone
+    # data-gradient of a 3 -> C layer: g has C channels, the result 3 (+ a zero 4th channel)
+    w2 = rnd(C, 3, 3, 3, seed=134, lo=-0.1, hi=0.1)
+    xin = rnd(N, 3, H, W, seed=135).requires_grad_(True)
+    g = rnd(N, C, H, W, seed=136)
+    (gref,) = torch.autograd.grad(F.conv2d(xin, w2, None, padding=1), xin, g)
+    gx = torch.full((N, H, W, 4), 9.0, device=DEV)
+    ops.conv_thin(ops.View(nhwc_buf(g)), w2.to(DEV), ops.View(gx), dgrad=True)
+    close(to_nchw(gx, 0, 3), gref, what="thin dgrad")
+    assert (gx[..., 3] == 0.0).all()
+
+
 def test_conv_direct_splitk():
     """The direct 3x3 kernel with a split-K workspace (512 -> 512 channels at 16x16: 16 tiles for 512 slots)."""
     ops = _ops()

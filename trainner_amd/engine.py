@@ -33,6 +33,7 @@ class ConvOp:
         self.k, self.stride = k, s
         # <= 4-channel image on either side of a 3x3 layer: taps folded into K (TNR_CONV_3x3_C4)
         img = k == 3 and s == 1 and not ups
+        self.thin = img                 # <= 4 channels on the OUTPUT side of a launch: vector-ALU kernel (conv_thin.hip)
         self.i_f4 = packer.add(mod.weight, ops.PACK_C4_FWD) if (img and mod.in_channels <= 4) else None
         self.i_d4 = packer.add(mod.weight, ops.PACK_C4_DGRAD3) if (img and need_dgrad and mod.out_channels <= 4) else None
 
@@ -43,7 +44,15 @@ class ConvOp:
             return v if v.C == 4 else ops.View(v.buf)
         return None
 
+    @staticmethod
+    def _plain(epi):
+        """Only bias / alpha: what the vector-ALU thin kernel's epilogue covers."""
+        return all(epi.get(n) is None for n in ("r1", "r2", "mask")) and epi.get("act", ops.ACT_NONE) == ops.ACT_NONE
+
     def fwd(self, x, y, **epi):
+        if self.thin and ops.IMAGE_C4 and self.mod.out_channels <= 4 and y.C <= 4 and self._plain(epi):
+            ops.conv_thin(x, self.mod.weight, y, bias=self.mod.bias, alpha=epi.get("alpha", 1.0))
+            return
         x4 = self._image4(x) if self.i_f4 is not None else None
         if x4 is not None:
             ops.conv(x4, self.packer.get(self.i_f4), y, mode=ops.CONV_3x3_C4, bias=self.mod.bias, **epi)
@@ -59,6 +68,9 @@ class ConvOp:
 
     def dgrad(self, g, gx, **epi):
         """gx = conv_transpose(g); for an UP2 layer gx lives in the up-sampled domain."""
+        if self.thin and ops.IMAGE_C4 and self.mod.in_channels <= 4 and gx.C <= 4 and self._plain(epi):
+            ops.conv_thin(g, self.mod.weight, gx, alpha=epi.get("alpha", 1.0), dgrad=True)
+            return
         g4 = self._image4(g) if self.i_d4 is not None else None
         if g4 is not None:
             ops.conv(g4, self.packer.get(self.i_d4), gx, mode=ops.CONV_3x3_C4, **epi)

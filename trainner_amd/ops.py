@@ -333,6 +333,22 @@ def chain_error_flag():
     return bad
 
 
+def conv_thin(x, w, y, bias=None, alpha=1.0, dgrad=False):
+    """3x3 s1 p1 convolution with <= 4 output channels on the vector ALUs (tnr_conv_thin).  w is the layer's OIHW
+    weight; dgrad=True computes the data-gradient of a layer with <= 4 INPUT channels (x = gradient of its output).
+    The [tap][channel][4] weight layout is rebuilt on every call (a 2 304-element launch) so it is never stale."""
+    lib = hip.load()
+    Cout, Cin = w.shape[0], w.shape[1]
+    red = Cout if dgrad else Cin
+    n = lib.tnr_conv_thin_pack_floats(red)
+    wp = WS.get("thin_w@%x" % hip.stream(), n * 4, x.buf.device)
+    hip.check(lib.tnr_conv_thin_pack(w.data_ptr(), wp.data_ptr(), Cout, Cin, int(dgrad), hip.stream()), "conv_thin_pack")
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_conv_thin(x.c(), x.N, x.H, x.W, x.C, wp.data_ptr(), y.c(), y.C, hip.ptr(bias), alpha, hip.stream()), "conv_thin")
+    if PROFILE is not None:
+        PROFILE.end("conv_thin", 2.0 * y.pixels * 9 * x.C * y.C, t0, (x.C, y.C, y.H, int(dgrad)))
+
+
 def small_gemm_ok(x, y, k, stride, epi):
     """A k x k convolution runs as im2col + split-K GEMM when it has <= 4096 output pixels (tiles of the direct
     kernel would be mostly padding and too few to fill the chip) and a plain epilogue."""
