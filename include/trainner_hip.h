@@ -175,6 +175,15 @@ int tnr_conv_thin_pack(const float *w_oihw, float *wp, int32_t Cout, int32_t Cin
 int tnr_conv_thin(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *wp, tnr_view y, int32_t Cout,
                   const float *bias, float alpha, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
+/* Weight (+ bias) gradient of a 3x3 s1 p1 layer with <= 3 channels on one side, on the vector ALUs:
+ * flip = 0: a Csmall -> Cbig layer (big = gradient of its output, small = its NHWC4 input image),
+ *           dw = [Cbig][Csmall][3][3], db = [Cbig];
+ * flip = 1: a Cbig -> Csmall layer (big = its input, small = NHWC4 gradient of its output),
+ *           dw = [Csmall][Cbig][3][3], db = [Csmall].
+ * dw = beta*dw + alpha*sum (db likewise, may be NULL).  Cbig in {16, 32, 64}.  Deterministic.               */
+int64_t tnr_wgrad_thin_workspace_bytes(int32_t N, int32_t H, int32_t Cbig);
+int tnr_wgrad_thin(tnr_view big, tnr_view small, int32_t N, int32_t H, int32_t W, int32_t Cbig, int32_t Csmall, int32_t flip,
+                   float *dw, float *db, float alpha, float beta, float *ws, int64_t ws_bytes, void *stream);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 /* n <= TNR_WGRAD_GROUP_MAX layers in ONE launch (+ one reduce launch).  The layers must share mode and
  * N/H/W/Ho/Wo and fall into the same workgroup tile class (same Cout <= 32 | > 32 and the same number of

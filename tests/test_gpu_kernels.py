@@ -361,6 +361,33 @@ def test_conv_thin_small_cout(shape):
     assert (gx[..., 3] == 0.0).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 9, 530, 16), (3, 33, 16, 32)])
+def test_wgrad_thin_image_layers(shape):
+    """tnr_wgrad_thin against autograd: a 3 -> C layer (flip=0) and a C -> 3 layer (flip=1), with bias, alpha, beta;
+    W = 530 exercises the 512-pixel row passes."""
+    ops = _ops()
+    N, H, W, C = shape
+    img = rnd(N, 3, H, W, seed=141)
+    img4 = nhwc_buf(F.pad(img, (0, 0, 0, 0, 0, 1)), fill=0.0)
+    # flip = 0: y = conv(img; w[C,3,3,3]) with gradient g[C]
+    w = torch.zeros(C, 3, 3, 3, requires_grad=True)
+    g = rnd(N, C, H, W, seed=142)
+    (ref_w,) = torch.autograd.grad(F.conv2d(img, w, None, padding=1), w, g)
+    dw0, db0 = rnd(C, 3, 3, 3, seed=143), rnd(C, seed=144)
+    dw, db = dw0.to(DEV), db0.to(DEV)
+    ops.wgrad_thin(ops.View(nhwc_buf(g)), ops.View(img4), dw, db, flip=False, alpha=0.5, beta=1.0)
+    close(dw.cpu(), dw0 + 0.5 * ref_w, tol=5e-5, what="thin wgrad 3->C weights")
+    close(db.cpu(), db0 + 0.5 * g.sum(dim=(0, 2, 3)), tol=5e-5, what="thin wgrad 3->C bias")
+    # flip = 1: y = conv(x[C]; w[3,C,3,3]) with gradient = the 3-channel image tensor
+    x = rnd(N, C, H, W, seed=145)
+    w2 = torch.zeros(3, C, 3, 3, requires_grad=True)
+    (ref_w2,) = torch.autograd.grad(F.conv2d(x, w2, None, padding=1), w2, img)
+    dw2, db2 = torch.zeros(3, C, 3, 3, device=DEV), torch.zeros(3, device=DEV)
+    ops.wgrad_thin(ops.View(nhwc_buf(x)), ops.View(img4), dw2, db2, flip=True, alpha=1.0, beta=0.0)
+    close(dw2.cpu(), ref_w2, tol=5e-5, what="thin wgrad C->3 weights")
+    close(db2.cpu(), img.sum(dim=(0, 2, 3)), tol=5e-5, what="thin wgrad C->3 bias")
+
+
 def test_conv_direct_splitk():
     """The direct 3x3 kernel with a split-K workspace (512 -> 512 channels at 16x16: 16 tiles for 512 slots)."""
     ops = _ops()

@@ -87,6 +87,15 @@ class ConvOp:
         return dict(x=x, g=g, dw=w.grad, db=db, cin_begin=cin_begin, alpha=alpha, beta=1.0)
 
     def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+        if self.thin and ops.IMAGE_C4 and cin_begin == 0 and x.N == g.N and (x.H, x.W) == (g.H, g.W):
+            m = self.mod
+            db = m.bias.grad if (with_bias and m.bias is not None) else None
+            if m.in_channels <= 3 and x.ctot == 4 and x.coff == 0 and g.C in (16, 32, 64):      # image -> features
+                ops.wgrad_thin(g, ops.View(x.buf), m.weight.grad, db, flip=False, alpha=alpha)
+                return
+            if m.out_channels <= 3 and g.ctot == 4 and g.coff == 0 and x.C in (16, 32, 64):     # features -> image
+                ops.wgrad_thin(x, ops.View(g.buf), m.weight.grad, db, flip=True, alpha=alpha)
+                return
         ops.wgrad_group([self.wgrad_item(x, g, alpha, cin_begin, with_bias)], mode=self.mode_f)
 
 

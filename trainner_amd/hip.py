@@ -77,6 +77,8 @@ _SIGS = {
     "tnr_conv_thin_pack": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "tnr_conv_thin": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_p, c_f, c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
+    "tnr_wgrad_thin_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "tnr_wgrad_thin": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_l, c_p]),
     "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "tnr_conv_wgrad_group": (c_i, [C.POINTER(WgradDesc), c_i, c_p]),
     "tnr_nchw_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, CView, c_i, c_p, c_p, c_p]),

@@ -414,6 +414,21 @@ def wgrad_group(items, mode=CONV_3x3):
     PROFILE.end("wgrad_tile", flops, t0, (sum(it["x"].C for it in items) if n > 1 else x0.C, g0.C, g0.H, mode + 100 * (n - 1)))
 
 
+def wgrad_thin(big, small4, dw, db, flip, alpha=1.0, beta=1.0):
+    """Weight gradient of a 3x3 layer with <= 3 channels on one side on the vector ALUs (tnr_wgrad_thin): flip=False
+    for a 3 -> C layer (big = gradient of its output, small4 = NHWC4 input image), flip=True for a C -> 3 layer
+    (big = its input, small4 = NHWC4 gradient of its output)."""
+    lib = hip.load()
+    cs = dw.shape[0] if flip else dw.shape[1]
+    need = lib.tnr_wgrad_thin_workspace_bytes(big.N, big.H, big.C)
+    ws = WS.get("wgrad_thin@%x" % hip.stream(), need, big.buf.device)
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_wgrad_thin(big.c(), small4.c(), big.N, big.H, big.W, big.C, cs, int(flip), dw.data_ptr(), hip.ptr(db),
+                                 alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "wgrad_thin")
+    if PROFILE is not None:
+        PROFILE.end("wgrad_thin", 2.0 * big.pixels * 9 * big.C * cs, t0, (big.C, cs, big.H, int(flip)))
+
+
 # ----------------------------------------------------------------------------------------------
 # layout / resampling / elementwise
 # ----------------------------------------------------------------------------------------------
