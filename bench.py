@@ -201,6 +201,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     log = model.get_current_log()
+    if ops.chain_error_flag():
+        raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
 
     roof = None
     if not args.no_roofline:
