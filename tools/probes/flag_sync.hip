@@ -20,6 +20,15 @@ __device__ __forceinline__ float4 load_sc(const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ float4 load_sc1(const float *p) {      // agent scope only
+    f4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_sc1(float *p, float4 q) {
+    f4v v = {q.x, q.y, q.z, q.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void store_sc(float *p, float4 q) {
     f4v v = {q.x, q.y, q.z, q.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
@@ -33,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) ring(float *buf0, float *buf1, unsigne
     for (int it = 0; it < iters; ++it) {
         float *src = (it & 1) ? buf1 : buf0;
         float *dst = (it & 1) ? buf0 : buf1;
-        if (MODE != 2 && it > 0) {
+        if (MODE != 2 && it > 0) {   // modes: 0 fences, 1 none, 3 sc0 sc1, 4 sc1, 5 wbl2
             if (tid < NB) {
                 // spread neighbours over the grid: other CUs and other XCDs
                 const int nb = nbr(t, tid, ntiles);
@@ -52,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) ring(float *buf0, float *buf1, unsigne
             for (int k = 0; k < NB; ++k) {
                 const int nb = nbr(t, k, ntiles);
                 const float *ap = src + (size_t)nb * TILE_F + ((tid + it * 7 + k * 13) & 511) * 4 * 8;
-                const float4 v = (MODE == 3) ? load_sc(ap) : *reinterpret_cast<const float4 *>(ap);
+                const float4 v = (MODE == 3) ? load_sc(ap) : (MODE == 4 || MODE == 5) ? load_sc1(ap) : *reinterpret_cast<const float4 *>(ap);
                 if (v.x != (float)it || v.w != (float)it) ++bad;
                 acc += v.x;
             }
@@ -62,11 +71,14 @@ __global__ void __launch_bounds__(256, 2) ring(float *buf0, float *buf1, unsigne
         for (int k = 0; k < 16; ++k) {
             const float f = (float)(it + 1);
             float *sp = dst + (size_t)t * TILE_F + (k * 256 + tid) * 4;
-            if (MODE == 3) store_sc(sp, make_float4(f, f, f, f)); else *reinterpret_cast<float4 *>(sp) = make_float4(f, f, f, f);
+            if (MODE == 3) store_sc(sp, make_float4(f, f, f, f));
+            else if (MODE == 4) store_sc1(sp, make_float4(f, f, f, f));
+            else *reinterpret_cast<float4 *>(sp) = make_float4(f, f, f, f);
         }
         if (MODE != 2) {
             if (MODE == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            if (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (MODE == 3 || MODE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (MODE == 5) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");   // plain stores + L2 write-back
             __syncthreads();
             if (tid == 0) __hip_atomic_store(&flags[t], (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -107,6 +119,8 @@ int main() {
         run<1>("flags, no fences", 200);
         run<0>("flags + release/acquire", 200);
         run<3>("flags + sc0 sc1 ld/st", 200);
+        run<4>("flags + sc1 ld/st (agent)", 200);
+        run<5>("plain st + wbl2 sc1, sc1 ld", 200);
     }
     return 0;
 }

@@ -23,11 +23,18 @@ struct ConvK {
     size_t split_stride;
 };
 
-#ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps */
-__device__ unsigned long long tnr_timeline[8 * 8192];
-#define TNR_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_timeline[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps, 8 per body call */
+__device__ unsigned long long tnr_timeline[8192 * 8 * 8];
+__device__ int tnr_timeline_call[8192];      /* which body call of the workgroup is running (chain kernel: stage pass) */
+#define TNR_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 8192)                                                           \
+            tnr_timeline[(blockIdx.x * 8 + (tnr_timeline_call[blockIdx.x] & 7)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define TNR_STAMP_CALL(c) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_timeline_call[blockIdx.x] = (c); } while (0)
 #else
 #define TNR_STAMP(i) do { } while (0)
+#define TNR_STAMP_CALL(c) do { } while (0)
 #endif
 
 // One output tile of one convolution: (MT*128 pixels at tile (n, ty, tx), parity class `par` for the
@@ -43,6 +50,7 @@ template <int MODE, int TW, int NT, int MT, bool COH, class WaitFn>
 __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, const int tx, const int ty, const int n,
                                                const int par, float *smem, const int wait_chunk, WaitFn &&wait,
                                                const int ksplit = 1, const int split = 0) {
+    TNR_STAMP(0);
     constexpr int TH = 128 * MT / TW;   // 4 waves x MT M-tiles of 32 pixels
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
@@ -286,10 +294,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // 64 % C4 == 0: a lane keeps the same channel quad for all its units
     const int c4 = lane % C4, co = cb * NC + c4 * 4;
     const bool co_ok = co < a.Cout;
-    const bool full = co + 4 <= a.Cout;                // false only for the 3-channel image output
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (a.bias != nullptr && co_ok) {
-        if (full) {
+        if (co + 4 <= a.Cout) {
             bv = *reinterpret_cast<const f32x4 *>(a.bias + co);
         } else {
 #pragma unroll
@@ -297,9 +304,16 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 if (co + k < a.Cout) bv[k] = a.bias[co + k];
         }
     }
-    const bool use_r1 = a.r1 != nullptr && co < a.r1_ch;
-    const bool use_r2 = a.r2 != nullptr;
-    const bool use_m = a.m != nullptr && co >= a.m_lo && co < a.m_hi;
+    // Everything below is written branch-light: an earlier version (per-element activation switch, per-unit
+    // residual / mask / partial-store branches) spent ~1000 cycles per float4 unit on control flow -- 17k cycles
+    // per tile, as much as one input chunk's MFMA phase.  Uniform switches are hoisted, lane conditions are selects.
+    const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.m != nullptr;     // wave-uniform
+    const bool all_full = (a.Cout & 3) == 0;                                                  // wave-uniform
+    const bool use_r1 = has_r1 && co < a.r1_ch;                                               // per lane
+    const bool use_m = has_m && co >= a.m_lo && co < a.m_hi;
+    const float ns = a.act == TNR_ACT_LRELU ? a.slope : (a.act == TNR_ACT_RELU ? 0.f : 1.f);  // act(v) = max(v,0) + ns*min(v,0)
+    const float b1 = use_r1 ? a.beta1 : 0.f;
+    const float ms = use_m ? a.m_slope : 1.f;          // factor for masked-off elements (1 outside the mask range)
     // Residual / mask loads of group g+1 are issued BEFORE the stores of group g (two register sets): on
     // gfx9 stores count in vmcnt like loads, so a load placed after a store in program order makes its
     // consumer wait for that store's acknowledgement -- serialising the whole tail on write latency.
@@ -318,37 +332,47 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             const int ox = DG2 ? 2 * sx + px : sx;
             const size_t pix = ((size_t)n * a.Ho + oy) * a.Wo + ox;
             pixi[set][k] = pix;
-            if (ok[set][k]) {
-                if (use_r1) q1[set][k] = *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
-                if (use_r2) q2[set][k] = *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
-                if (use_m) qm[set][k] = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+            if (has_r1) {
+                q1[set][k] = zero;
+                if (ok[set][k] && use_r1) q1[set][k] = *reinterpret_cast<const f32x4 *>(a.r1 + pix * a.r1_ct + a.r1_co + co);
+            }
+            if (has_r2) {
+                q2[set][k] = zero;
+                if (ok[set][k]) q2[set][k] = *reinterpret_cast<const f32x4 *>(a.r2 + pix * a.r2_ct + a.r2_co + co);
+            }
+            if (has_m) {
+                qm[set][k] = one;
+                if (ok[set][k] && use_m) qm[set][k] = *reinterpret_cast<const f32x4 *>(a.m + pix * a.m_ct + a.m_co + co);
             }
         }
     };
     auto finish = [&](int g, int set) {
 #pragma unroll
         for (int k = 0; k < G; ++k) {
-            if (!ok[set][k]) continue;
             const int pl = (g * G + k) * (64 / C4) + lane / C4;
             f32x4 v = *reinterpret_cast<const f32x4 *>(s_o + pl * NC + c4 * 4) + bv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tnr_act(v[e], a.act, a.slope) * a.alpha;
-            if (use_r1) v += a.beta1 * q1[set][k];
-            if (use_r2) v = v * a.alpha2 + q2[set][k];
-            if (use_m) {
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ns, __builtin_fminf(v[e], 0.f), __builtin_fmaxf(v[e], 0.f)) * a.alpha;
+            if (has_r1) v += b1 * q1[set][k];
+            if (has_r2) v = v * a.alpha2 + q2[set][k];
+            if (has_m) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= (qm[set][k][e] > 0.f ? 1.f : a.m_slope);
+                for (int e = 0; e < 4; ++e) v[e] *= (qm[set][k][e] > 0.f ? 1.f : ms);
             }
-            float *yp = a.y + pixi[set][k] * a.y_ct + a.y_co + co;
+            if (!ok[set][k]) continue;
             if (COH) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnr_u32x4, v), y_rs,
                                                        (int)((unsigned)(pixi[set][k] * a.y_ct + a.y_co + co) * 4u), 0, TNR_AUX_SC0_SC1);
-            } else if (full) {
-                *reinterpret_cast<f32x4 *>(yp) = v;
             } else {
+                float *yp = a.y + pixi[set][k] * a.y_ct + a.y_co + co;
+                if (all_full) {
+                    *reinterpret_cast<f32x4 *>(yp) = v;
+                } else {                               // 3-channel image outputs only
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (co + e < a.Cout) yp[e] = v[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout) yp[e] = v[e];
+                }
             }
         }
     };

@@ -92,6 +92,8 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int pend_tile = -1;          // wave-uniform
     unsigned pend_value = 0;
+    int calls = 0;               // (timeline probe only)
+    (void)calls;
     for (int s = 0; s < c.nstages; ++s) {
         int wait_chunk;
         const ConvK st = chain_stage(s, &wait_chunk);
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
                 // them it stays live across the whole kernel and spills)
                 int txo = tx, tyo = ty, no = n;
                 asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(no));
+                TNR_STAMP_CALL(calls++);
                 conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
             }
             // this tile's stage-s output is on its way to memory: published from inside the next tile body

@@ -24,7 +24,7 @@ namespace {
 
 template <int MODE, int TW, int NT, int MT>
 __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
-    TNR_STAMP(0);
+    TNR_STAMP_CALL(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
     const int split = bid % a.ksplit;   // innermost: the splits of a tile run side by side and share its input in L2
