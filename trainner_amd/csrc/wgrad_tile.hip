@@ -254,22 +254,20 @@ wgrad_tile_kernel(const WgK ga) {
         }
     }
 
-    // ---- write the partial slab
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        if (!t_ok[j]) continue;
-        const int tap = t_tap[j] >> 10, aa = (t_tap[j] >> 5) & 31, bb = t_tap[j] & 31;
-        const int blk = cib * B_T + bb;                // 32-wide virtual input-channel block
+    // ---- write the partial slab [tap][co][blk][split][32]: the split axis is contiguous (128-B granules), so the
+    // reducer streams each (tap, co, blk) row; one base pointer per tile, a constant stride per output row
+    {
         const int nblk = a.KinVP >> 5;
-        if (blk >= nblk) continue;
-        // slab layout [tap][co][blk][split][32]: the split axis is contiguous (128-B granules), so the
-        // reducer streams each (tap, co, blk) row; a wave store still writes 128 B per half-wave
+        const size_t row_stride = (size_t)nblk * a.nsplits * 32;       // floats between consecutive co
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = cob * COB + aa * 32 + i;
-            if (co < a.KoutP)
-                a.ws[((((size_t)tap * a.KoutP + co) * nblk + blk) * a.nsplits + split) * 32 + li] = acc[j][r];
+        for (int j = 0; j < J; ++j) {
+            const int tap = t_tap[j] >> 10, aa = (t_tap[j] >> 5) & 31, bb = t_tap[j] & 31;
+            const int blk = cib * B_T + bb;                // 32-wide virtual input-channel block
+            const int co0 = cob * COB + aa * 32;           // KoutP % 32 == 0: a 32-cout block is valid as a whole
+            if (!t_ok[j] || blk >= nblk || co0 >= a.KoutP) continue;
+            float *p = a.ws + (((size_t)tap * a.KoutP + co0 + 4 * half) * nblk + blk) * a.nsplits * 32 + (size_t)split * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[(size_t)((r & 3) + 8 * (r >> 2)) * row_stride] = acc[j][r];
         }
     }
     // every wave accumulated the sums of its cout half; the first wave of each half (bb == 0) publishes
