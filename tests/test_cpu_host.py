@@ -183,3 +183,16 @@ def test_patch_extraction_and_recomposition_match_reference():
         rec = recompose_tensor(sr, H, W, step=step, scale=scale)
         assert rec.shape == c["recomposed"].shape, name
         assert (rec - c["recomposed"]).abs().max().item() <= 1e-6, name
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No eager / CPU fallback: without the built C-ABI library every op raises HipEngineError naming the build step."""
+    import pytest
+    from trainner_amd import hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setenv("TNR_HIP_LIB", str(tmp_path / "nowhere" / "libtrainner_hip.so"))
+    with pytest.raises(hip.HipEngineError, match="trainner_amd.build"):
+        hip.load()
+    monkeypatch.delenv("TNR_HIP_LIB")
+    monkeypatch.setattr(hip, "_lib", None)
+    assert hip.load() is not None           # the in-tree build is found again
