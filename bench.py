@@ -1,7 +1,10 @@
 """bench.py -- HR images/sec of the full G+D step (SRModel.optimize_parameters), ESRGAN x4 128->512.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce.)
+N > 1: one rank per GPU, RCCL gradient all-reduce.  Under `torch.distributed.run` (RANK / WORLD_SIZE set) each
+process is one rank; a plain `python bench.py --gpus N` re-launches itself under torch.distributed.run on 127.0.0.1.
+`--dry-run-cpu` exercises the same launch + data-parallel host logic on CPU (gloo, the test suite's torch stand-in
+for the C ABI, tiny shapes): a plumbing check whose JSON line is marked invalid -- never a measurement.
 
 Workload = BASELINE.json configs[1]: RRDBNet-23 + Discriminator_VGG(512) + VGG19->conv5_4, batch 16
 per GPU (weak scaling), L1 + perceptual + relativistic GAN, clip + Adam -- fp32 on the matrix cores.
@@ -11,7 +14,11 @@ Synthetic HR in [0,1), LR = avg_pool(HR, 4), resident in HBM before the timed re
                  algorithmic FLOP of every launch / HIP-event time of that launch, both summed over a
                  separate instrumented pass of the same steps (events on the launch stream);
   cpu_baseline : the CPU oracle (a port of the reference step) on this host's cores, batch 1, same
-                 shapes (N=1 runs only).
+                 shapes (N=1 runs only); `reference` inside it = the reference's OWN SRModel timed in the build
+                 container (profiles/*_cpu_reference.json, oracle/time_reference.py) -- the GPU box has no
+                 /root/reference.
+The GPU result is also written to stderr as `BENCH_GPU_LINE {...}` before the CPU leg starts, so a timeout in the
+CPU leg cannot lose it; stdout carries exactly one JSON line.
 """
 import argparse
 import json
@@ -36,7 +43,7 @@ name: bench_esrgan
 use_tb_logger: false
 model: sr
 scale: 4
-gpu_ids: [0]
+gpu_ids: {gpu_ids}
 use_amp: false
 datasets:
   train:
@@ -66,6 +73,7 @@ train:
   pixel_weight: 1e-2
   feature_criterion: l1
   feature_weight: 1
+  perceptual_allow_random_init: true   # seeded VGG weights are loaded below (no network access for ImageNet weights)
   gan_type: vanilla
   gan_weight: 5e-3
   manual_seed: 0
@@ -79,14 +87,15 @@ logger:
 """
 
 
-def make_model(batch, crop, rank):
+def make_model(batch, crop, rank, world=1):
+    """batch = per-GPU batch; the YAML carries the reference's GLOBAL batch_size (options/README.md:31)."""
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     root = tempfile.mkdtemp(prefix="tnr_bench_r%d_" % rank)
     path = os.path.join(root, "bench.yml")
     with open(path, "w") as f:
-        f.write(YAML.format(batch=batch, crop=crop, root=root))
-    torch.manual_seed(1234)                       # identical replicas on every rank
+        f.write(YAML.format(batch=batch * world, crop=crop, root=root, gpu_ids=list(range(world))))
+    torch.manual_seed(1234 + rank)                # replicas are made identical by SRModel.sync_replicas (rank 0 wins)
     opt = options.parse(path, is_train=True)
     model = create_model(opt, verbose=False)
     # VGG19: seeded He-normal weights (ImageNet weights cannot be downloaded here)
@@ -110,6 +119,23 @@ def synthetic(batch, crop, seed, device):
     return lr.to(device), hr.to(device)
 
 
+def cpu_reference_record():
+    """The reference's own SRModel timed on CPU (N = 2, 1 warm-up + >= 3 steps) in the build container: newest
+    committed profiles/*_cpu_reference.json, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_reference.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            rec = json.load(fh)
+        rec["source"] = os.path.relpath(files[-1], ROOT)
+        rec.pop("last_log", None)
+        return rec
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(crop, steps=2):
     """The reference step as ported in oracle/sr_oracle.py, timed on this host's cores (batch 1)."""
     from oracle import detrand, sr_oracle as O
@@ -129,7 +155,8 @@ def cpu_baseline(crop, steps=2):
     dt = (time.time() - t0) / steps
     return {"value": round(1.0 / dt, 4), "unit": "HR img/s", "cores": cores, "kind": "port",
             "sample": "oracle/sr_oracle.py OracleSRStep (port of SRModel.optimize_parameters), ESRGAN RRDBNet-23 + "
-                      "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps)}
+                      "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps),
+            "reference": cpu_reference_record()}
 
 
 def pmc_traffic(family="conv_tile_3x3"):
@@ -138,16 +165,33 @@ def pmc_traffic(family="conv_tile_3x3"):
     FETCH_SIZE / WRITE_SIZE passes of this same command).  Counters cannot be read from inside the timed
     process, so this is the recorded figure for the same kernels and shapes; None if no summary exists."""
     import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as fh:
             e = json.load(fh)[family]
-            return round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None
+            src = "%s (rocprofv3 --pmc passes of this command, recorded; file mtime %s)" % (
+                os.path.relpath(files[-1], ROOT), time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(files[-1]))))
+            return (round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None), src
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -160,28 +204,43 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel table on stderr")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     from trainner_amd import hip, ops
-    hip.require_device()
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    dry = args.dry_run_cpu
+    if dry:
+        # TEST INFRASTRUCTURE: the C ABI replaced by its torch-CPU contract (no GPU in the build container)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emul_backend
+        emul_backend.install()
+        os.environ["LOCAL_RANK"] = "0"
+        args.crop, args.batch, args.no_roofline, args.no_cpu_baseline = 64, 2, True, True
+        device = torch.device("cpu")
+        torch.set_num_threads(4)
+    else:
+        hip.require_device()
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
 
-    model = make_model(args.batch, args.crop, rank)
-    LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)
+    model = make_model(args.batch, args.crop, rank, world)
+    assert model.dp.world_size == world and (world == 1 or model.dp.active)
+    LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)      # this rank's shard of the global batch
     data = {"LR": LR, "HR": HR}
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     step = 0
     for _ in range(args.warmup):
@@ -231,9 +290,10 @@ def main():
             per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
             kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
                      "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
+            traffic, traffic_src = pmc_traffic(fam)
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(fam),
+                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
@@ -245,17 +305,24 @@ def main():
             "metric": "HR images/sec (G+D step), ESRGAN x4 128->512",
             "value": round(imgs / dt, 3), "unit": "HR img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not dry else "DRY-RUN on CPU (emulated C ABI, tiny shapes): NOT a measurement",
             "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "world_size_observed": model.dp.world_size,
+                       "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},
             "step_tflops": round(FLOP_PER_IMG * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
             "roofline": roof,
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
+        if dry:
+            out["value"] = None
+            out["invalid"] = "dry run"
         if world == 1 and not args.no_cpu_baseline:
+            print("BENCH_GPU_LINE " + json.dumps(out), file=sys.stderr, flush=True)    # safe before the CPU leg
             out["cpu_baseline"] = cpu_baseline(args.crop)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

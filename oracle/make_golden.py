@@ -30,6 +30,11 @@ CASES = {
                                               upsample_mode="pixelshuffle"), steps=2, seed=31),
     # full RRDBNet-23 + Discriminator_VGG(128, nf 64) + VGG19, one step at batch 2
     "esrgan_nb23_crop128": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64), steps=1, seed=41),
+    # BASELINE.json configs[1] at its real resolution with batch 2: Discriminator_VGG(512)'s BatchNorm reduces over
+    # more than one image (the 4x4 layer: 32 positions), RRDBNet-23, all losses, one step
+    "esrgan_nb23_crop512_b2": dict(yaml=dict(nb=23, batch=2, crop=512, d_nf=64), steps=1, seed=51),
+    # SURVEY.md 8(d) parity metric K = 10: ten consecutive G+D steps at reduced size, batch 4
+    "esrgan_nb2_crop64_k10": dict(yaml=dict(nb=2, batch=4, crop=64, d_nf=16), steps=10, seed=61),
 }
 
 G_SEED, D_SEED, F_SEED = 101, 202, 77

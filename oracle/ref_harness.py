@@ -62,6 +62,8 @@ def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, m
     ]
     if feature:
         train += ["  feature_criterion: l1", "  feature_weight: 1"]
+        if gpu_ids != "[]":     # engine configs: the parity tests load their own seeded VGG weights (no ImageNet file here)
+            train += ["  perceptual_allow_random_init: true"]
     if gan:
         train += ["  gan_type: vanilla", "  gan_weight: 5e-3"]
     train += ["  manual_seed: 0", "  niter: 500000", "  val_freq: 5000"]

@@ -325,7 +325,48 @@ _NAMES = ["conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to
           "sumsq", "clip_by_norm", "adam_step"]
 
 
-def install(monkeypatch):
+class DirectPatcher:
+    """monkeypatch stand-in for worker processes (no pytest fixture there; the process exits afterwards)."""
+
+    @staticmethod
+    def setattr(obj, name, value):
+        setattr(obj, name, value)
+
+
+def chunked_bn(chunks):
+    """(bn_train_fwd, bn_train_bwd) that take BatchNorm statistics per contiguous chunk of the batch: ONE process
+    reproducing what `chunks` data-parallel replicas do (per-replica statistics; replica 0's running stats are the
+    ones kept: SURVEY.md 8(e))."""
+    View = ops.View
+
+    def _split(v, i):
+        n = v.N // chunks
+        return View(v.buf[i * n:(i + 1) * n], v.coff, v.C)
+
+    stats = {}      # the network allocates [C] statistics; the per-chunk ones live here, keyed by that tensor
+
+    def fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save_mean, save_invstd, **kw):
+        per = []
+        for i in range(chunks):
+            keep = i == 0
+            m, s = torch.empty_like(save_mean), torch.empty_like(save_invstd)
+            rm = running_mean if keep else (None if running_mean is None else running_mean.clone())
+            rv = running_var if keep else (None if running_var is None else running_var.clone())
+            bn_train_fwd(_split(z, i), _split(y, i), gamma, beta, rm, rv, num_batches if keep else None, m, s, **kw)
+            per.append((m, s))
+        stats[save_mean.data_ptr()] = (save_mean, per)      # holding save_mean keeps the key unique
+
+    def bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, **kw):
+        _, per = stats.pop(save_mean.data_ptr())
+        for i in range(chunks):
+            bn_train_bwd(_split(gy, i), _split(y, i), _split(z, i), _split(gz, i), gamma, per[i][0], per[i][1],
+                         dgamma=dgamma, dbeta=dbeta, acc_beta=acc_beta if i == 0 else 1.0, **kw)
+
+    return fwd, bwd
+
+
+def install(monkeypatch=None):
+    monkeypatch = monkeypatch or DirectPatcher
     g = globals()
     for n in _NAMES:
         monkeypatch.setattr(ops, n, g[n])

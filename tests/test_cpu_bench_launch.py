@@ -1,0 +1,23 @@
+"""`python bench.py --gpus 2` without a launcher must start its own two ranks (torch.distributed.run on 127.0.0.1),
+run the data-parallel step and print ONE JSON line from rank 0 (-m "not gpu": CPU dry run over gloo + the torch
+stand-in for the C ABI; the line is marked invalid because it is a plumbing check, not a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launches_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size_observed"] == 2 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["global_batch"] == 4 and j["scaling"] == "weak" and j["steps"] == 1
+    assert j["value"] is None and j["invalid"] == "dry run"          # never mistaken for a measurement
+    assert all(v == v for v in j["losses"].values())                 # finite

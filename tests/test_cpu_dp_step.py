@@ -1,0 +1,131 @@
+"""N-rank SRModel step == 1-rank step (-m "not gpu"): two gloo processes, each running the engine's real host logic
+(SRModel.optimize_parameters, the network kernel schedules, flat clip + Adam, dp.py's bucketed gradient averaging,
+the relativistic global-mean exchange with its xworld backward coupling, the rank-0 start-state broadcast and the
+global-batch sharding of feed_data) over the torch-CPU stand-in for the C ABI (tests/emul_backend.py), against ONE
+process stepping the whole batch.  BatchNorm statistics are per replica in the reference (nn.DataParallel, no
+SyncBN), so the single process takes them per half-batch (emul_backend.chunked_bn) -- everything else must agree
+to fp32 round-off: logs, this rank's slice of fake_H, and the post-step G / D weights.
+Reference: codes/models/losses.py:428-433,503-512 (global-batch relativistic means), sr_model.py:195-267.
+"""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import emul_backend
+from oracle import detrand, fixtures as FX, ref_harness
+
+KW = dict(nb=1, batch=4, crop=64, d_nf=16)
+STEPS = 2
+BN_BIAS = None
+
+
+def _build(tmp, seed_g, seed_d):
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    yml = ref_harness.esrgan_yaml(name="dp_case", out_root=tmp, gpu_ids="[0]", **KW)
+    opt = options.parse(yml, is_train=True)
+    model = create_model(opt, verbose=False)
+    if seed_g is not None:
+        model.netG.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netG.state_dict().items()}, seed_g))
+        model.netD.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netD.state_dict().items()}, seed_d))
+    netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+    sd = netF.state_dict()
+    sd.update(FX.vgg_state(77))
+    netF.load_state_dict(sd)
+    return model
+
+
+def _run(model, rank=None, world=1):
+    logs = []
+    for s in range(1, STEPS + 1):
+        LR, HR = detrand.synthetic_pair(KW["batch"], KW["crop"], 70 + s)     # every rank is fed the GLOBAL batch
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+        logs.append(model.get_current_log())
+    return dict(logs=logs, fake=model.fake_H.detach().clone(),
+                g={k: v.detach().clone() for k, v in model.netG.state_dict().items()},
+                d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
+
+
+def _worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    try:
+        torch.set_num_threads(4)
+        emul_backend.install()
+        from trainner_amd import dp as dpmod
+        dpmod.BUCKET_FLOATS = 100_000             # several buckets per network, fired from inside backward
+        # rank 1 holds DIFFERENT weights (as after a per-rank init RNG): sync_replicas must bring it to rank 0's
+        # (SRModel's constructor calls it as its last act; here the seeded load happens after construction)
+        model = _build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666)
+        assert model.dp.active and model.dp.world_size == world
+        model.sync_replicas()
+        out = _run(model, rank, world)
+        path = os.path.join(tmp, "rank%d.pt" % rank)
+        torch.save(out, path)                     # tensors travel by file (the worker exits before the parent reads)
+        q.put((rank, path))
+    except Exception as e:                           # pragma: no cover
+        import traceback
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process(tmp_path, monkeypatch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    # the single-process comparator runs meanwhile: full batch, per-half-batch BatchNorm statistics
+    emul_backend.install(monkeypatch)
+    from trainner_amd import ops
+    f, b = emul_backend.chunked_bn(2)
+    monkeypatch.setattr(ops, "bn_train_fwd", f)
+    monkeypatch.setattr(ops, "bn_train_bwd", b)
+    torch.set_num_threads(4)
+    one = _run(_build(str(tmp_path / "one"), 101, 202))
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert res[r].endswith(".pt"), res[r]
+        res[r] = torch.load(res[r], weights_only=False)
+    per = KW["batch"] // 2
+    lr_steps = 1e-4 * STEPS
+    shadow = FX.bn_shadowed_biases([(k, None) for k in one["d"]])
+    for r in (0, 1):
+        out = res[r]
+        for s in range(STEPS):
+            for k, v in one["logs"][s].items():
+                # every log entry is a global-batch quantity on every rank (G losses are all-reduced means)
+                assert abs(out["logs"][s][k] - v) <= 5e-5 * abs(v) + 1e-7, (r, s, k, out["logs"][s][k], v)
+        diff = (out["fake"] - one["fake"][r * per:(r + 1) * per]).abs().max().item()
+        assert diff <= 1e-5, ("fake_H", r, diff)
+        for name, mine, ref in (("G", out["g"], one["g"]), ("D", out["d"], one["d"])):
+            worst, tot, cnt = (0.0, None), 0.0, 0
+            for k, v in ref.items():
+                if k in shadow or not v.is_floating_point():
+                    continue
+                if ".running_" in k:
+                    if r == 0:               # replica 0's running statistics are the ones the reference keeps
+                        # (running means carry the +-lr walk of the BN-shadowed conv biases: atol = lr * steps)
+                        assert torch.allclose(mine[k], v, rtol=1e-4, atol=2.5e-4), (k,)
+                    continue
+                d = (mine[k] - v).abs() / lr_steps
+                tot, cnt = tot + d.sum().item(), cnt + d.numel()
+                if d.max().item() > worst[0]:
+                    worst = (d.max().item(), k)
+            # Adam's first steps are sign-like: an element whose gradient is at rounding-noise level can move
+            # +-lr either way, so the mean is bounded tightly and the worst element loosely
+            assert tot / cnt < 2e-3 and worst[0] < 1.0, (name, r, worst, tot / cnt)
+    # both replicas hold identical weights after the steps (same reduced gradients, same Adam)
+    for k, v in res[0]["g"].items():
+        assert torch.equal(v, res[1]["g"][k]), k
+    for k, v in res[0]["d"].items():
+        if ".running_" not in k and v.is_floating_point():
+            assert torch.equal(v, res[1]["d"][k]), k

@@ -36,10 +36,38 @@ def test_vgg_schedule():
     TN.test_vgg19_features()
 
 
-@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle"])
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb2_crop64_k10"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 
 
 def test_validation_forward_and_self_ensemble(tmp_path):
     TS.test_validation_forward_and_self_ensemble(tmp_path)
+
+
+def test_freezeD_layers_are_not_trained(tmp_path):
+    """train.freeze_loc (FreezeD, base_model.py:641-655 / sr_model.py:249-253): the first layers of the discriminator
+    have requires_grad False during the D step, so the reference's Adam never touches them; the engine's flat Adam
+    launch must leave them bit-identical too."""
+    from oracle import detrand, ref_harness
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    yml = ref_harness.esrgan_yaml(name="freezed", out_root=str(tmp_path), gpu_ids="[0]", nb=1, batch=2, crop=64, d_nf=16)
+    txt = open(yml).read().replace("  gan_type: vanilla", "  gan_type: vanilla\n  freeze_loc: 2")
+    open(yml, "w").write(txt)
+    opt = options.parse(yml, is_train=True)
+    model = create_model(opt, verbose=False)
+    assert model.feature_loc == 4                       # (loc * 3) - 2: features.0 .. features.3 are frozen
+    before = {k: v.detach().clone() for k, v in model.netD.state_dict().items()}
+    for s in (1, 2):
+        LR, HR = detrand.synthetic_pair(2, 64, 90 + s)
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+    after = model.netD.state_dict()
+    frozen = [k for k in before if k.split(".")[0] == "features" and int(k.split(".")[1]) < 4
+              and (k.endswith("weight") or k.endswith("bias"))]
+    assert len(frozen) == 6                             # conv0 w/b, conv1 (features.2) w/b, its BatchNorm (features.3) w/b
+    for k in frozen:
+        assert torch.equal(before[k], after[k]), k
+    moved = [k for k in before if k.endswith("weight") and k not in frozen and not torch.equal(before[k], after[k])]
+    assert "features.5.weight" in moved and "classifier.2.weight" in moved

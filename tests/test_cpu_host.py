@@ -38,7 +38,8 @@ def test_no_device_fails_loudly():
         net(torch.zeros(1, 3, 8, 8))          # no CPU / eager fallback exists
 
 
-@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"])
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
+                                  "esrgan_nb2_crop64_k10", "esrgan_nb23_crop512_b2"])
 def test_options_and_state_dict_contract(case, tmp_path):
     """options.parse expands to the dicts the REAL reference produced (stored in the fixtures) and the
     engine's networks carry exactly the reference's state_dict keys and shapes."""
@@ -196,3 +197,48 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.delenv("TNR_HIP_LIB")
     monkeypatch.setattr(hip, "_lib", None)
     assert hip.load() is not None           # the in-tree build is found again
+
+
+def test_perceptual_net_refuses_silent_random_init(tmp_path):
+    """without perceptual_opt.pretrained_path and without torchvision's ImageNet weights the reference
+    would download them (perceptual.py:139-144); the engine must raise instead of training against random features,
+    unless the config opts in (benchmarks / parity tests load their own weights)."""
+    from trainner_amd import hip
+    from trainner_amd.models import networks
+    from trainner_amd.options import options
+    try:
+        import torchvision  # noqa: F401
+        pytest.skip("torchvision present: pretrained weights may load")
+    except ImportError:
+        pass
+    yml = ref_harness.esrgan_yaml(name="noinit", out_root=str(tmp_path), gpu_ids="[0]", nb=1, batch=2, crop=64, d_nf=16)
+    opt = options.parse(yml, is_train=True)
+    assert opt["train"]["perceptual_allow_random_init"] is True
+    net = networks.define_F(opt)
+    assert net.weights_source == "random-init"
+    opt["train"]["perceptual_allow_random_init"] = None
+    with pytest.raises(hip.HipEngineError, match="pretrained_path"):
+        networks.define_F(opt)
+    # a torchvision-layout state_dict on disk is honoured
+    sd = {}
+    for i, n in enumerate(net.names):
+        if n.startswith("conv"):
+            sd["features.%d.weight" % i] = torch.full_like(net.feature_net[n].weight, 0.5)
+            sd["features.%d.bias" % i] = torch.zeros_like(net.feature_net[n].bias)
+    p = tmp_path / "vgg19.pth"
+    torch.save(sd, str(p))
+    opt["train"]["perceptual_opt"] = {"pretrained_path": str(p)}
+    net2 = networks.define_F(opt)
+    assert net2.weights_source == str(p) and float(net2.feature_net["conv5_4"].weight.mean()) == 0.5
+
+
+def test_optimizer_options_keep_falsy_values():
+    """beta1_G: 0 / lr_D: 0 are legitimate: only a missing key takes the default (optimizers.py:74-134)."""
+    from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
+    from trainner_amd.models.optimizers import config_optimizer
+    from trainner_amd.options.options import dict_to_nonedict
+    net = SRResNet(3, 3, 16, 1)
+    o = config_optimizer(dict_to_nonedict({"beta1_G": 0, "lr_G": 0.0, "optim_G": "adam"}), "G", [net])
+    assert o.param_groups[0]["betas"] == (0, 0.999) and o.param_groups[0]["lr"] == 0.0
+    o = config_optimizer(dict_to_nonedict({}), "D", [net])
+    assert o.param_groups[0]["betas"] == (0.9, 0.999) and o.param_groups[0]["lr"] == 1e-4

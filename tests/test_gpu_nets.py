@@ -1,12 +1,20 @@
 """Network-level parity (-m gpu): each HIP-engine network (one autograd node) against the CPU
 oracle's functional restatement driven by torch autograd, on identical seeded weights/inputs:
 outputs, input gradients, every parameter gradient, BatchNorm running statistics.
+
+Gradients that pass through ReLU / LeakyReLU / max-pool gates are arbitrated by fp64 (oracle/gated.py): the
+oracle is re-evaluated in double precision with every gate pinned to the branch the HIP engine actually took
+(read from the engine's own saved activations).  With the gates pinned the function is smooth, so EVERY gradient
+element must agree to fp32 round-off (max norm, 2e-4) -- this replaces the former "relative L2 < 0.05 / 0.1"
+bounds, which could have hidden a real kernel bug behind the gate-flip argument.  The ungated fp32-vs-fp32
+comparison is kept as a secondary statistic (`three_way`: no further from the free fp64 run than 20x the CPU
+fp32 oracle's own distance).
 """
 import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import detrand, sr_oracle as O
+from oracle import detrand, gated, sr_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -24,6 +32,21 @@ def robust_err(got, ref):
     d = (got.detach().cpu() - ref.detach()).double()
     r = ref.detach().double()
     return (d.norm() / (r.norm() + 1e-30)).item(), (d.abs().median() / (r.abs().max() + 1e-30)).item()
+
+
+def to64(sd):
+    return {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
+
+
+def three_way(got, ref32, ref64, factor=20.0, floor=2e-6):
+    """relative L2 distance to the fp64 evaluation: HIP <= factor * (fp32 CPU oracle's own distance) + floor.
+    `floor` covers the case where the CPU fp32 run happens to sit exactly on the fp64 gates (its distance is then
+    pure round-off, ~1e-7) while a different, equally valid fp32 summation order flips one."""
+    r = ref64.detach().double()
+    n = r.norm().item() + 1e-300
+    e_hip = (got.detach().cpu().double() - r).norm().item() / n
+    e_cpu = (ref32.detach().double() - r).norm().item() / n
+    return e_hip <= factor * e_cpu + floor, e_hip, e_cpu
 
 
 def seeded(net, seed, **kw):
@@ -95,21 +118,41 @@ def test_discriminator_vgg(size, nf):
     gout = detrand.uniform((3, 1), 11, -1.0, 1.0)
     xd = x.clone().to(DEV).requires_grad_(True)
     out = net(xd)
+    gates, hid_gate = gated.gates_of_discriminator(out.grad_fn.saved)      # the branches the engine took
     out.backward(gout.to(DEV))
     osd = oracle_params(sd)
     xr = x.detach().clone().requires_grad_(True)
     ref = O.disc_vgg_forward(xr, osd, size, nf, training=True)
     ref.backward(gout)
     assert rel_err(out, ref) < 5e-5
-    l2, med = robust_err(xd.grad, xr.grad)            # LeakyReLU gates near zero may flip (see robust_err)
-    assert l2 < 0.05 and med < 2e-4, (l2, med)
+    # fp64 arbitration (see three_way): LeakyReLU gates within round-off of zero and batch-3 BatchNorm statistics make
+    # two fp32 evaluations differ by far more than 1 ulp; neither may be further from fp64 than the other by > 4x
+    osd64 = oracle_params(to64(sd))
+    x64 = x.detach().double().requires_grad_(True)
+    ref64 = O.disc_vgg_forward(x64, osd64, size, nf, training=True)
+    ref64.backward(gout.double())
+    ok, e_hip, e_cpu = three_way(xd.grad, xr.grad, x64.grad, floor=1e-5)
+    assert ok, ("input grad", e_hip, e_cpu)
     from oracle.fixtures import bn_shadowed_biases
     shadow = bn_shadowed_biases([(k, None) for k in sd])
+    worst = 0.0
     for k, p in net.named_parameters():
         if k in shadow:
             continue                                   # true gradient is exactly zero: noise on both sides
-        l2, med = robust_err(p.grad, osd[k].grad)       # batch-3 BatchNorm amplifies gate flips (robust_err)
-        assert l2 < 0.05 and med < 5e-3, (k, l2, med)
+        ok, e_hip, e_cpu = three_way(p.grad, osd[k].grad, osd64[k].grad, floor=1e-5)
+        assert ok, (k, e_hip, e_cpu)
+        worst = max(worst, e_hip)
+    assert worst < 2e-3, worst                         # and in absolute terms every parameter gradient is close
+    # the strong check: fp64 with the engine's own gates -> every element of every gradient, max norm
+    gsd64 = oracle_params(to64(sd))
+    xg64 = x.detach().double().requires_grad_(True)
+    out64 = gated.disc_vgg_forward_gated(xg64, gsd64, size, nf, gates, hid_gate)
+    out64.backward(gout.double())
+    assert rel_err(out, out64) < 2e-5
+    assert rel_err(xd.grad, xg64.grad) < 2e-4, rel_err(xd.grad, xg64.grad)
+    for k, p in net.named_parameters():
+        if k not in shadow:
+            assert rel_err(p.grad, gsd64[k].grad) < 2e-4, (k, rel_err(p.grad, gsd64[k].grad))
     new = net.state_dict()
     for k in sd:
         if "running_" in k:
@@ -130,13 +173,14 @@ def test_discriminator_vgg(size, nf):
 def test_vgg19_features():
     from trainner_amd.models.modules.architectures.perceptual import FeatureExtractor
     from oracle import fixtures as FX
-    net = FeatureExtractor(["conv5_4"])
+    net = FeatureExtractor(["conv5_4"], allow_random_init=True)
     vsd = FX.vgg_state(77)
     net.load_state_dict({**{k: v for k, v in net.state_dict().items() if k in ("mean", "std")}, **vsd})
     net = net.to(DEV)
     x = detrand.uniform((2, 3, 64, 96), 12, 0.0, 1.0)
     xd = x.clone().to(DEV).requires_grad_(True)
     feat = net(xd)["conv5_4"]
+    relu_gates, pool_idx = gated.gates_of_vgg(feat.grad_fn.saved)
     xr = x.detach().clone().requires_grad_(True)
     ref = O.vgg19_conv54(xr, vsd)
     assert feat.shape == ref.shape
@@ -144,8 +188,19 @@ def test_vgg19_features():
     g = detrand.uniform(tuple(ref.shape), 13, -1.0, 1.0)
     feat.backward(g.to(DEV).contiguous(memory_format=torch.channels_last))
     ref.backward(g)
+    vsd64 = to64(vsd)
+    x64 = x.detach().double().requires_grad_(True)
+    O.vgg19_conv54(x64, vsd64).backward(g.double())
+    ok, e_hip, e_cpu = three_way(xd.grad, xr.grad, x64.grad, floor=1e-5)     # ReLU / max-pool gates: fp64 arbitrates
+    assert ok, (e_hip, e_cpu)
     l2, med = robust_err(xd.grad, xr.grad)
-    assert l2 < 0.1 and med < 2e-5, (l2, med)
+    assert med < 2e-5, (l2, med)
+    # the strong check: fp64 with the engine's own ReLU gates and max-pool winners, max norm over every pixel
+    xg64 = x.detach().double().requires_grad_(True)
+    f64 = gated.vgg19_conv54_gated(xg64, vsd64, relu_gates, pool_idx)
+    f64.backward(g.double())
+    assert rel_err(feat, f64) < 2e-5
+    assert rel_err(xd.grad, xg64.grad) < 2e-4, rel_err(xd.grad, xg64.grad)
     # the perceptual criterion end to end
     from trainner_amd.models.losses import L1Loss
     y = detrand.uniform((2, 3, 64, 96), 14, 0.0, 1.0)
@@ -162,5 +217,9 @@ def test_vgg19_features():
     # under a different (equally valid) fp32 summation order -- the split-K GEMM of the 4x6 / 8x12 layers here --
     # and conv5_4's receptive field spans this whole image, so a handful of flips moves every input-gradient
     # element a little: bound the median at 5e-4 (measured 8e-5 with flips, 2e-7 without) and the L2 as before
+    x64 = x.detach().double().requires_grad_(True)
+    F.l1_loss(O.vgg19_conv54(x64, vsd64), O.vgg19_conv54(y.double(), vsd64)).backward()
+    ok, e_hip, e_cpu = three_way(xd2.grad, xr2.grad, x64.grad, floor=1e-5)
+    assert ok, (e_hip, e_cpu)
     l2, med = robust_err(xd2.grad, xr2.grad)
-    assert l2 < 0.1 and med < 5e-4, (l2, med)
+    assert med < 5e-4, (l2, med)

@@ -39,6 +39,14 @@ def load_initial(model, g, d, f):
 
 D_SIDE = ("l_g_gan", "l_d_real", "l_d_fake", "D_real", "D_fake")
 
+# Per-case bounds of test_step_matches_reference_golden: (log tol, fake_H mean, fake_H max, state mean, state worst).
+# Default = 1-3 steps: round-off only.  K = 10: trajectories of two correct fp32 implementations drift (Adam's early
+# steps are sign-like; elements with rounding-noise gradients move +-lr either way -- the CPU restatement in oracle/
+# drifts from the reference by up to 2e-4 on the logs and 7e-5 on fake_H over the same 10 steps), so the bounds are
+# wider there, while PSNR must still agree within 0.05 dB (north star).
+CASE_TOL = {"esrgan_nb2_crop64_k10": dict(log=3e-3, fake_mean=5e-4, fake_max=4e-3, st_mean=0.15, st_worst=2.0, bn=2e-2)}
+DEFAULT_TOL = dict(log=2e-4, fake_mean=2e-5, fake_max=5e-4, st_mean=0.02, st_worst=1.5, bn=2e-3)
+
 
 def check_logs(log, ref_log, tol=2e-4, d_tol=None):
     for k, v in ref_log.items():
@@ -51,9 +59,12 @@ def check_logs(log, ref_log, tol=2e-4, d_tol=None):
         assert abs(log[k] - v) <= t * max(1.0, abs(v)) + 5e-6, (k, log[k], v)
 
 
-@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128"])
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
+                                  "esrgan_nb2_crop64_k10",       # K = 10 consecutive G+D steps
+                                  "esrgan_nb23_crop512_b2"])     # BASELINE configs[1] resolution, batch 2: BN over > 1 image
 def test_step_matches_reference_golden(case, tmp_path):
     fx = FX.load(case)
+    T = CASE_TOL.get(case, DEFAULT_TOL)
     opt, model = build_engine_model(fx["spec"]["yaml"], tmp_path)
     assert dict(opt["network_G"]) == fx["network_G"]
     if fx["network_D"]:
@@ -63,25 +74,26 @@ def test_step_matches_reference_golden(case, tmp_path):
     for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
         model.feed_data({"LR": LR, "HR": HR})
         model.optimize_parameters(s)
-        check_logs(model.get_current_log(), ref_log)
+        check_logs(model.get_current_log(), ref_log, tol=T["log"] if s > 2 else DEFAULT_TOL["log"],
+                   d_tol=T["log"] if s > 1 else None)
     ref = fx["fake_H"]
     got = model.fake_H.detach().cpu()
     scale = max(1.0, ref.abs().max().item())
     diff = (got - ref).abs()
-    assert diff.mean().item() <= 2e-5 * scale and diff.max().item() <= 5e-4 * scale, (diff.mean().item(), diff.max().item())
+    assert diff.mean().item() <= T["fake_mean"] * scale and diff.max().item() <= T["fake_max"] * scale, (diff.mean().item(), diff.max().item())
     _, HR = detrand.synthetic_pair(fx["spec"]["yaml"]["batch"], fx["spec"]["yaml"]["crop"],
                                    fx["seeds"]["data"] + fx["spec"]["steps"])
     assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
     lr_steps = 1e-4 * fx["spec"]["steps"]
     gs = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
     worst, mean, k = FX.state_error(gs, fx["g_state"], lr_steps=lr_steps)
-    assert mean < 0.02 and worst < 1.5, ("G state", k, worst, mean)
+    assert mean < T["st_mean"] and worst < T["st_worst"], ("G state", k, worst, mean)
     if fx["d_keys"]:
         ds = {k: v.detach().cpu() for k, v in model.netD.state_dict().items()}
         worst, mean, k = FX.state_error(ds, fx["d_state"], FX.bn_shadowed_biases(fx["d_keys"]), lr_steps=lr_steps)
-        assert mean < 0.02 and worst < 1.5, ("D state", k, worst, mean)
+        assert mean < T["st_mean"] and worst < T["st_worst"], ("D state", k, worst, mean)
         e, k = FX.buffers_error(ds, fx["d_state"])
-        assert e < 2e-3, ("D running stats", k, e)
+        assert e < T["bn"], ("D running stats", k, e)
 
 
 @pytest.mark.timeout(420)

@@ -39,6 +39,24 @@ class DPGroup:
         if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
+    def mean_scalar(self, t):
+        """Global-batch mean of a per-rank mean (equal shards): what nn.DataParallel's gather-then-loss reports."""
+        if not self.active:
+            return t
+        t = t.detach().clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t / self.world_size
+
+    # ---------------------------------------------------------------- replica start state
+    def broadcast_from_rank0(self, tensors):
+        """Make every replica start from rank 0's values (parameters, BatchNorm buffers, optimiser moments).
+        nn.DataParallel re-broadcasts GPU 0's module every forward (networks.py:252-255); persistent replicas
+        need it exactly once, after construction / load / resume."""
+        if not self.active:
+            return
+        for t in tensors:
+            dist.broadcast(t, src=0, group=self.group)
+
     # ---------------------------------------------------------------- gradient buckets
     def _stream(self, device):
         if device.type != "cuda":
@@ -91,13 +109,21 @@ class BucketSchedule:
     """Tracks which prefix of a network's (reverse-order) gradients is complete during backward and
     fires bucket all-reduces as soon as a bucket is fully written."""
 
-    def __init__(self, dp, holder):
+    def __init__(self, dp, holder, passes=1):
         self.dp, self.holder = dp, holder
         self.hi = holder.total          # everything >= hi has been handed to the communicator
         self.low_water = holder.total   # everything >= low_water is final
+        # number of backward passes that accumulate into this gradient buffer before it is final (the D step
+        # back-propagates D(fake) and D(real): two autograd nodes, one buffer): buckets only go out in the last
+        self.passes, self.pass_no = passes, 0
+
+    def begin_pass(self):
+        self.pass_no += 1
 
     def mark_done(self, param):
         """All gradient kernels of `param` (and of every parameter after it in the flat buffer) are enqueued."""
+        if self.pass_no < self.passes:
+            return
         _, off = param._tnr_flat
         if off < self.low_water:
             self.low_water = off

@@ -119,6 +119,9 @@ class _NetFn(torch.autograd.Function):
         if saved is None:
             raise RuntimeError("HIP engine: backward through a forward that saved no activations")
         ctx.saved = None
+        sched = getattr(ctx.net, "_bucket_schedule", None)
+        if sched is not None and ctx.need_param_grad:
+            sched.begin_pass()                      # dp.BucketSchedule: buckets leave in the last accumulating pass
         gx = ctx.net.engine_backward(saved, gout, need_input_grad=ctx.needs_input_grad[1],
                                      need_param_grad=ctx.need_param_grad)
         return (None, gx) + (None,) * (len(ctx.needs_input_grad) - 2)

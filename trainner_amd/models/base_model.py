@@ -89,8 +89,18 @@ class BaseModel:
     def get_network_description(self, network):
         return str(network), sum(p.numel() for p in network.parameters())
 
+    def check_engine_errors(self):
+        """Cheap host-side check at points that synchronise anyway (log read-out, checkpoint): a tnr_conv_chain
+        dependency wait that timed out computed with unpublished neighbour tiles -- the step is invalid, so a
+        training run stops here instead of continuing on corrupted activations."""
+        if ops.chain_error_flag():
+            raise hip.HipEngineError("a tnr_conv_chain dependency wait timed out (another tenant on the GPU kept the "
+                                     "grid from being co-resident?): results since the last check are invalid; set "
+                                     "TNR_CONV_CHAIN=0 to run one launch per layer")
+
     # ------------------------------------------------------------------ checkpoints
     def save(self, iter_step, latest=None, loader=None):
+        self.check_engine_errors()
         if self.dp.rank != 0:
             return
         for name in self.model_names:
@@ -151,6 +161,7 @@ class BaseModel:
             if hasattr(s, "milestones") and isinstance(s.milestones, Counter) and isinstance(st.get("milestones"), list):
                 st["milestones"] = Counter(st["milestones"])
             s.load_state_dict(st)
+        self.sync_replicas()
 
     def update_schedulers(self, train_opt):
         for s in self.schedulers:
@@ -282,12 +293,45 @@ class BaseModel:
     def calc_gradients(self, loss):
         loss.backward()
 
-    def _arm_bucket_schedule(self, nets):
-        """Let the next backward pass of `nets` hand finished gradient buckets to RCCL while it is still
-        running (only when this backward completes the virtual batch: partial sums must not be reduced)."""
+    def _arm_bucket_schedule(self, nets, passes=1):
+        """Let the next backward pass(es) of `nets` hand finished gradient buckets to RCCL while backward is still
+        running (only when this backward completes the virtual batch: partial sums must not be reduced).
+        `passes`: autograd nodes of the net in the loss (D step: D(fake) and D(real) = 2)."""
         if self.dp.active and self.accumulations == 1:
             for net in nets:
-                net._bucket_schedule = dpmod.BucketSchedule(self.dp, net.flat_params())
+                net._bucket_schedule = dpmod.BucketSchedule(self.dp, net.flat_params(), passes=passes)
+
+    def sync_replicas(self):
+        """Data-parallel start state: every rank takes rank 0's parameters, BatchNorm buffers and Adam moments
+        (each rank ran its own init RNG / load).  Called at the end of construction and after resume_training."""
+        if not self.dp.active:
+            return
+        tensors = []
+        for name in self.model_names:
+            net = getattr(self, "net" + name)
+            tensors.append(net.flat_params().flat)
+            tensors += [b for b in net.buffers() if b.is_floating_point() or b.dtype == torch.int64]
+        for o in self.optimizers:
+            for mv in getattr(o, "_moments", {}).values():
+                tensors += list(mv)
+        self.dp.broadcast_from_rank0(tensors)
+        for name in self.model_names:
+            getattr(self, "net" + name).flat_params().touch()
+
+    def _zero_frozen_grads(self, opt_flag):
+        """Parameters with requires_grad False at step time (FreezeD: base_model.py:641-655, sr_model.py:249-253) get
+        no gradient in the reference and Adam skips them.  The engine's flat Adam launch covers the whole buffer, so
+        their gradient slices are cleared: with zero gradient history Adam's update is exactly 0 (weight decay on a
+        frozen tensor would not be, hence the check)."""
+        for net in self._opt_nets[opt_flag]:
+            frozen = [p for p in net.parameters() if not p.requires_grad]
+            if not frozen:
+                continue
+            opt = self.optimizer_G if opt_flag == "G" else self.optimizer_D
+            if any(g["weight_decay"] for g in opt.param_groups):
+                raise NotImplementedError("frozen parameters with weight decay are not implemented by the HIP engine")
+            for p in frozen:
+                ops.fill(p.grad, 0.0)
 
     def _sync_gradients(self, opt_flag):
         """Data-parallel exchange of the gradients the backward pass just produced."""
@@ -307,6 +351,7 @@ class BaseModel:
         """base_model.py:815-850: step only when the virtual batch is complete; G gets the clip."""
         if step % self.accumulations != 0:
             return
+        self._zero_frozen_grads(opt_flag)
         self._sync_gradients(opt_flag)
         if opt_flag == "G":
             self.apply_gradclip()

@@ -228,6 +228,7 @@ class GeneratorLoss(nn.Module):
         else:
             self.cri_fea = None
         self.precise_loss_list = []
+        self.dp_group = None        # set by SRModel when running data-parallel
 
     def forward(self, sr, hr, log_dict, fsfilter=None, selector=None, precise=False):
         if fsfilter is not None or selector:
@@ -242,5 +243,7 @@ class GeneratorLoss(nn.Module):
             else:
                 effective = l["weight"] * l["function"](sr, hr)
             results.append(effective)
-            log_dict[l["name"]] = effective.detach()
+            # under data parallelism the logged value is the global-batch mean, as the reference computes it on the
+            # gathered batch (the gradient uses the local mean: averaging over ranks makes it the global one)
+            log_dict[l["name"]] = self.dp_group.mean_scalar(effective) if self.dp_group is not None else effective.detach()
         return results, log_dict

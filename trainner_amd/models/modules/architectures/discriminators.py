@@ -103,6 +103,9 @@ class Discriminator_VGG(HipNet):
                        db=l0.bias.grad if W else None, mslope=0.2)
         gy = View(new_act(N, last.H, last.W, last.C, dev))
         ops.nchw_to_nhwc(gfeat, gy, Cpad=last.C)
+        sched = getattr(self, "_bucket_schedule", None) if W else None      # data-parallel gradient buckets (dp.py)
+        if sched is not None:
+            sched.mark_done(l0.weight)
         for li in range(len(self._ops) - 1, -1, -1):
             conv, bn = self._ops[li]
             xin, z, y, mean, invstd = acts[li]
@@ -114,6 +117,8 @@ class Discriminator_VGG(HipNet):
                 gz = gy                                         # already masked by the consumer's dgrad epilogue
             if W:
                 conv.wgrad(View(xin.buf, 0, conv.mod.in_channels) if li == 0 else xin, gz)
+                if sched is not None:
+                    sched.mark_done(conv.mod.weight)      # this layer's conv + BN and everything after it are final
             if li == 0:
                 if not need_input_grad:
                     return None

@@ -6,11 +6,14 @@ features taken BEFORE the ReLU when a 'convX_Y' name is listened (the `x.clone()
 happens before the in-place ReLU that follows).  Parameters are frozen (requires_grad False,
 :185-188): only the data-gradient schedule exists.
 
-torchvision is not a dependency: the layer table is the public VGG configuration.  Pretrained
-ImageNet weights, when available, are loaded with `load_path` (a torchvision `vgg19` state_dict,
-keys `features.N.*`); otherwise the caller fills the weights (the benchmarks use seeded weights,
-there is no network access).
+torchvision is not a dependency of the kernels: the layer table is the public VGG configuration.
+Weights: `load_path` (a torchvision `vggNN` state_dict, keys `features.N.*`) when given, else
+torchvision's pretrained ImageNet weights exactly like the reference (:139-144).  If neither is
+available the constructor RAISES -- a perceptual loss against random features is never entered
+silently; benchmarks and parity tests (no network access: they load their own seeded weights right
+after construction) opt in with `allow_random_init=True` (option `train.perceptual_allow_random_init`).
 """
+import logging
 import os
 
 import torch
@@ -20,6 +23,8 @@ from .... import ops
 from ....engine import ConvOp, HipNet
 from ....ops import View, new_act
 from . import block as B
+
+logger = logging.getLogger("base")
 
 VGG_CFG = {
     "vgg16": [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"],
@@ -41,7 +46,7 @@ def vgg_layer_names(net):
 
 class FeatureExtractor(HipNet):
     def __init__(self, listen_list=None, net="vgg19", use_input_norm=True, z_norm=False, requires_grad=False,
-                 remove_pooling=False, pooling_stride=2, change_padding=False, load_path=None):
+                 remove_pooling=False, pooling_stride=2, change_padding=False, load_path=None, allow_random_init=False):
         super().__init__()
         if net not in VGG_CFG or remove_pooling or pooling_stride != 2 or change_padding or requires_grad or z_norm:
             raise NotImplementedError("FeatureExtractor option outside the ESRGAN recipe is not implemented by the HIP engine")
@@ -67,13 +72,34 @@ class FeatureExtractor(HipNet):
         if use_input_norm:
             self.register_buffer("mean", torch.tensor([[[0.485]], [[0.456]], [[0.406]]]))
             self.register_buffer("std", torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
-        if load_path and os.path.exists(load_path):
-            self.load_torchvision_state(torch.load(load_path, map_location="cpu"))
+        self.weights_source = self._load_pretrained(net, load_path, allow_random_init)
         for p in self.parameters():
             p.requires_grad = False
         self.eval()
         self._init_engine()
         self._norm = None
+
+    def _load_pretrained(self, net, load_path, allow_random_init):
+        """perceptual.py:134-144: a local torchvision state_dict, else torchvision's ImageNet weights; never a
+        silent random init."""
+        if load_path and os.path.exists(load_path):
+            self.load_torchvision_state(torch.load(load_path, map_location="cpu", weights_only=False))
+            return load_path
+        why = "pretrained_path %r does not exist" % load_path if load_path else "no perceptual_opt.pretrained_path given"
+        try:
+            from torchvision.models import vgg as tv_vgg          # optional: not installed on the build image
+            self.load_torchvision_state(getattr(tv_vgg, net)(pretrained=True).state_dict())
+            return "torchvision:%s" % net
+        except Exception as e:                                    # no torchvision / no network / no cached weights
+            why += "; torchvision pretrained weights unavailable (%s: %s)" % (type(e).__name__, e)
+        if not allow_random_init:
+            from ....hip import HipEngineError
+            raise HipEngineError("FeatureExtractor(%s): %s. A perceptual loss on randomly initialised features is refused; "
+                                 "set train.perceptual_opt.pretrained_path to a torchvision %s state_dict, or opt in with "
+                                 "train.perceptual_allow_random_init: true (benchmarks / parity tests that load their own "
+                                 "weights)" % (net, why, net))
+        logger.warning("FeatureExtractor(%s): %s -- weights left at their random init (allow_random_init)", net, why)
+        return "random-init"
 
     def load_torchvision_state(self, sd):
         """Accept a torchvision vggNN state_dict (features.<i>.weight/bias): torchvision's `features`

@@ -101,6 +101,7 @@ def define_F(opt):
         net = opt["train"].get("feature_network", "vgg19") or "vgg19"
         w_l_p, w_l_s = {"conv5_4": 1}, {}
         kw = dict(remove_pooling=False, use_input_norm=True, requires_grad=False, change_padding=False, load_path=None)
+    kw["allow_random_init"] = bool(opt["train"].get("perceptual_allow_random_init"))
     w_l = dict(w_l_p)
     w_l.update(w_l_s)
     if "resnet" in net:

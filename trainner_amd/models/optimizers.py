@@ -106,11 +106,16 @@ def config_optimizer(train_opt, name, net=None, optim_params=None):
             n.flat_params()              # parameters become views of the network's flat buffer
     if not optim_params:
         optim_params, _ = get_optim_params(net, True)
-    optim = train_opt.get("optim_" + name, "adam") or "adam"
-    lr = train_opt.get("lr_" + name, 1e-4) or 1e-4
-    wd = train_opt.get("weight_decay_" + name, 0) or 0
-    beta1 = train_opt.get("beta1_" + name, 0.9) or 0.9
-    beta2 = train_opt.get("beta2_" + name, 0.999) or 0.999
+    def opt_or(key, default):
+        # missing keys read as None (NoneDict); legitimate falsy values (beta1_G: 0, lr_D: 0) are kept
+        v = train_opt.get(key, None)
+        return default if v is None else v
+
+    optim = opt_or("optim_" + name, "adam")
+    lr = opt_or("lr_" + name, 1e-4)
+    wd = opt_or("weight_decay_" + name, 0)
+    beta1 = opt_or("beta1_" + name, 0.9)
+    beta2 = opt_or("beta2_" + name, 0.999)
     if optim != "adam":
         raise NotImplementedError("optimizer [{}] is outside the SR hot path of the HIP engine".format(optim))
     return FusedAdam(optim_params, lr=lr, weight_decay=wd, betas=(beta1, beta2))

@@ -39,6 +39,7 @@ class SRModel(BaseModel):
             self.setup_batchaug()
             self.setup_fs()
             self.generatorlosses = losses.GeneratorLoss(opt, self.device)
+            self.generatorlosses.dp_group = self.dp if self.dp.active else None
             self.setup_gan()
             if self.cri_gan:
                 self.setup_freezeD()
@@ -54,13 +55,33 @@ class SRModel(BaseModel):
             self.setup_cem()
             self.setup_unshuffle()
             self.setup_gradclip(opt_G_nets)
+        if self.is_train:
+            self.sync_replicas()
         self.print_network(verbose=False)
 
+    def _shard(self, t):
+        """Reference semantics of `batch_size` (options/README.md:31: the GLOBAL batch, split over gpu_ids by
+        nn.DataParallel's scatter): a fed tensor that carries the global batch is cut to this rank's contiguous
+        shard; a tensor that already holds batch_size / world samples (a per-rank loader) is taken as is."""
+        world = self.dp.world_size
+        if world == 1 or not self.is_train:
+            return t
+        gb = self.opt["datasets"]["train"]["batch_size"]
+        if gb % world:
+            raise ValueError("batch_size %d is not divisible by the %d data-parallel ranks" % (gb, world))
+        per = gb // world
+        if t.shape[0] == gb:
+            return t[self.dp.rank * per:(self.dp.rank + 1) * per]
+        if t.shape[0] == per:
+            return t
+        raise ValueError("fed batch of %d samples is neither the global batch (%d) nor this rank's shard (%d)"
+                         % (t.shape[0], gb, per))
+
     def feed_data(self, data, need_HR=True):
-        self.var_L = data["LR"].to(self.device, non_blocking=True)
+        self.var_L = self._shard(data["LR"]).to(self.device, non_blocking=True)
         if need_HR:
-            self.real_H = data["HR"].to(self.device, non_blocking=True)
-            self.var_ref = data.get("ref", data["HR"]).to(self.device, non_blocking=True)
+            self.real_H = self._shard(data["HR"]).to(self.device, non_blocking=True)
+            self.var_ref = self._shard(data.get("ref", data["HR"])).to(self.device, non_blocking=True)
 
     def forward(self, data=None, CEM_net=None):
         if isinstance(data, torch.Tensor):
@@ -80,6 +101,7 @@ class SRModel(BaseModel):
         self.calc_gradients(l_g_total)
 
     def backward_D(self):
+        self._arm_bucket_schedule([self.netD], passes=2)   # D(fake) and D(real) both accumulate: buckets leave in the 2nd
         self.log_dict = self.backward_D_Basic(self.netD, self.var_ref, self.fake_H, self.log_dict)
 
     def optimize_parameters(self, step):
@@ -149,7 +171,9 @@ class SRModel(BaseModel):
         self.netG.train()
 
     def get_current_log(self):
-        return self.log_dict.materialize()
+        log = self.log_dict.materialize()           # the step's one host sync
+        self.check_engine_errors()
+        return log
 
     def get_current_visuals(self, need_HR=True):
         out = OrderedDict()

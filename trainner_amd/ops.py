@@ -316,7 +316,10 @@ def conv_chain(stages):
         ws = torch.zeros(need // 4, dtype=torch.int32, device=dev)     # progress counters start at 0; last word = error flag
         WS.bufs[key] = ws
         _chain_epoch[key] = 0
-    _chain_epoch[key] = (_chain_epoch[key] + 1) & 0x0FFFFFFF
+    _chain_epoch[key] += 1
+    if _chain_epoch[key] > 0x0FFFFFF0:                 # epoch wrap: stale counters would compare as already satisfied
+        fill(ws[:-1].view(torch.float32), 0.0)         # (stream-ordered after every earlier launch on this stream)
+        _chain_epoch[key] = 1
     t0 = PROFILE.begin() if PROFILE is not None else None
     hip.check(lib.tnr_conv_chain(descs, fresh, n, ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_chain")
     if PROFILE is not None:
