@@ -237,7 +237,7 @@ def test_optimizer_options_keep_falsy_values():
     from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
     from trainner_amd.models.optimizers import config_optimizer
     from trainner_amd.options.options import dict_to_nonedict
-    net = SRResNet(3, 3, 16, 1)
+    net = SRResNet(3, 3, 32, 1)
     o = config_optimizer(dict_to_nonedict({"beta1_G": 0, "lr_G": 0.0, "optim_G": "adam"}), "G", [net])
     assert o.param_groups[0]["betas"] == (0, 0.999) and o.param_groups[0]["lr"] == 0.0
     o = config_optimizer(dict_to_nonedict({}), "D", [net])
