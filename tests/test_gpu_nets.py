@@ -6,9 +6,10 @@ Gradients that pass through ReLU / LeakyReLU / max-pool gates are arbitrated by 
 oracle is re-evaluated in double precision with every gate pinned to the branch the HIP engine actually took
 (read from the engine's own saved activations).  With the gates pinned the function is smooth, so EVERY gradient
 element must agree to fp32 round-off (max norm, 2e-4) -- this replaces the former "relative L2 < 0.05 / 0.1"
-bounds, which could have hidden a real kernel bug behind the gate-flip argument.  The ungated fp32-vs-fp32
-comparison is kept as a secondary statistic (`three_way`: no further from the free fp64 run than 20x the CPU
-fp32 oracle's own distance).
+bounds, which could have hidden a real kernel bug behind the gate-flip argument.  The ungated comparison against
+the free-running fp64 oracle is kept as a secondary statistic with an absolute bound (`dist64`; a flip is a
+discrete event, so the CPU fp32 oracle may sit at 2e-6 from fp64 while an equally valid run sits at 4e-4 --
+measured on MI355X for features.17.weight -- which is why no ratio between the two is asserted).
 """
 import pytest
 import torch
@@ -38,15 +39,11 @@ def to64(sd):
     return {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
 
 
-def three_way(got, ref32, ref64, factor=20.0, floor=2e-6):
-    """relative L2 distance to the fp64 evaluation: HIP <= factor * (fp32 CPU oracle's own distance) + floor.
-    `floor` covers the case where the CPU fp32 run happens to sit exactly on the fp64 gates (its distance is then
-    pure round-off, ~1e-7) while a different, equally valid fp32 summation order flips one."""
+def dist64(got, ref32, ref64):
+    """relative L2 distances to the free-running fp64 evaluation: (engine, fp32 CPU oracle)."""
     r = ref64.detach().double()
     n = r.norm().item() + 1e-300
-    e_hip = (got.detach().cpu().double() - r).norm().item() / n
-    e_cpu = (ref32.detach().double() - r).norm().item() / n
-    return e_hip <= factor * e_cpu + floor, e_hip, e_cpu
+    return (got.detach().cpu().double() - r).norm().item() / n, (ref32.detach().double() - r).norm().item() / n
 
 
 def seeded(net, seed, **kw):
@@ -131,18 +128,15 @@ def test_discriminator_vgg(size, nf):
     x64 = x.detach().double().requires_grad_(True)
     ref64 = O.disc_vgg_forward(x64, osd64, size, nf, training=True)
     ref64.backward(gout.double())
-    ok, e_hip, e_cpu = three_way(xd.grad, xr.grad, x64.grad, floor=1e-5)
-    assert ok, ("input grad", e_hip, e_cpu)
+    e_hip, e_cpu = dist64(xd.grad, xr.grad, x64.grad)
+    assert e_hip < 2e-2, ("input grad", e_hip, e_cpu)   # (MI355X: 5.9e-3; the CPU fp32 oracle itself: 7.3e-3)
     from oracle.fixtures import bn_shadowed_biases
     shadow = bn_shadowed_biases([(k, None) for k in sd])
-    worst = 0.0
     for k, p in net.named_parameters():
         if k in shadow:
             continue                                   # true gradient is exactly zero: noise on both sides
-        ok, e_hip, e_cpu = three_way(p.grad, osd[k].grad, osd64[k].grad, floor=1e-5)
-        assert ok, (k, e_hip, e_cpu)
-        worst = max(worst, e_hip)
-    assert worst < 2e-3, worst                         # and in absolute terms every parameter gradient is close
+        e_hip, e_cpu = dist64(p.grad, osd[k].grad, osd64[k].grad)
+        assert e_hip < 2e-3, (k, e_hip, e_cpu)          # ungated: a few flipped gates at most (was: L2 < 0.05)
     # the strong check: fp64 with the engine's own gates -> every element of every gradient, max norm
     gsd64 = oracle_params(to64(sd))
     xg64 = x.detach().double().requires_grad_(True)
@@ -191,8 +185,8 @@ def test_vgg19_features():
     vsd64 = to64(vsd)
     x64 = x.detach().double().requires_grad_(True)
     O.vgg19_conv54(x64, vsd64).backward(g.double())
-    ok, e_hip, e_cpu = three_way(xd.grad, xr.grad, x64.grad, floor=1e-5)     # ReLU / max-pool gates: fp64 arbitrates
-    assert ok, (e_hip, e_cpu)
+    e_hip, e_cpu = dist64(xd.grad, xr.grad, x64.grad)     # ungated: a few flipped ReLU / max-pool gates (was: L2 < 0.1)
+    assert e_hip < 2e-2, (e_hip, e_cpu)
     l2, med = robust_err(xd.grad, xr.grad)
     assert med < 2e-5, (l2, med)
     # the strong check: fp64 with the engine's own ReLU gates and max-pool winners, max norm over every pixel
@@ -219,7 +213,7 @@ def test_vgg19_features():
     # element a little: bound the median at 5e-4 (measured 8e-5 with flips, 2e-7 without) and the L2 as before
     x64 = x.detach().double().requires_grad_(True)
     F.l1_loss(O.vgg19_conv54(x64, vsd64), O.vgg19_conv54(y.double(), vsd64)).backward()
-    ok, e_hip, e_cpu = three_way(xd2.grad, xr2.grad, x64.grad, floor=1e-5)
-    assert ok, (e_hip, e_cpu)
+    e_hip, e_cpu = dist64(xd2.grad, xr2.grad, x64.grad)
+    assert e_hip < 5e-2, (e_hip, e_cpu)               # + sign(f - fy) flips of the L1 criterion (see below)
     l2, med = robust_err(xd2.grad, xr2.grad)
     assert med < 5e-4, (l2, med)

@@ -44,8 +44,11 @@ D_SIDE = ("l_g_gan", "l_d_real", "l_d_fake", "D_real", "D_fake")
 # steps are sign-like; elements with rounding-noise gradients move +-lr either way -- the CPU restatement in oracle/
 # drifts from the reference by up to 2e-4 on the logs and 7e-5 on fake_H over the same 10 steps), so the bounds are
 # wider there, while PSNR must still agree within 0.05 dB (north star).
-CASE_TOL = {"esrgan_nb2_crop64_k10": dict(log=3e-3, fake_mean=5e-4, fake_max=4e-3, st_mean=0.15, st_worst=2.0, bn=2e-2)}
-DEFAULT_TOL = dict(log=2e-4, fake_mean=2e-5, fake_max=5e-4, st_mean=0.02, st_worst=1.5, bn=2e-3)
+# st_worst: Adam's first step moves every element by exactly +-lr; an element whose gradient is rounding noise may take
+# the other sign (|dp| = 2 lr, seen for 0.25 % of the sampled Discriminator_VGG(512) weights) -- bounded by 2 lr, while
+# the MEAN displacement error stays below 2 % of lr.
+CASE_TOL = {"esrgan_nb2_crop64_k10": dict(log=3e-3, fake_mean=5e-4, fake_max=4e-3, st_mean=0.15, st_worst=2.05, bn=2e-2)}
+DEFAULT_TOL = dict(log=2e-4, fake_mean=2e-5, fake_max=5e-4, st_mean=0.02, st_worst=2.05, bn=2e-3)
 
 
 def check_logs(log, ref_log, tol=2e-4, d_tol=None):
