@@ -136,7 +136,7 @@ def test_discriminator_vgg(size, nf):
         if k in shadow:
             continue                                   # true gradient is exactly zero: noise on both sides
         e_hip, e_cpu = dist64(p.grad, osd[k].grad, osd64[k].grad)
-        assert e_hip < 2e-3, (k, e_hip, e_cpu)          # ungated: a few flipped gates at most (was: L2 < 0.05)
+        assert e_hip < 2e-2, (k, e_hip, e_cpu)          # ungated: flipped gates (MI355X 5.5e-3, CPU fp32 oracle 6.8e-3; was: L2 < 0.05)
     # the strong check: fp64 with the engine's own gates -> every element of every gradient, max norm
     gsd64 = oracle_params(to64(sd))
     xg64 = x.detach().double().requires_grad_(True)

@@ -36,9 +36,18 @@ struct WgK {
 //   J >= 9 : 144 accumulator VGPRs, ONE workgroup per CU with the whole 512-entry register file: the
 //            global loads of tile i+1 are all issued before the MFMA phase of tile i and written to LDS
 //            after it (issue-early / write-late), and the k-loop is unrolled 4 k-steps deep.
+//
+// Pixel split inside the workgroup (KS): with AB = A_T*B_T < 4 channel blocks the 9*AB tiles do not divide by the
+// 4 waves (18 tiles -> 5 slots per wave, 10 % of the issued MFMAs were padding).  For the 3x3 modes the waves are
+// therefore grouped: WPG = AB waves per group, KS = 4 / AB groups; each group owns ALL tiles (one (aa, bb) block
+// per wave, its 9 taps: J = 9, no padding) over its own 1/KS of the tile's pixel rows; after the last tile the
+// groups' accumulators are added in a fixed order through LDS, so the workgroup still writes ONE partial slab.
 template <int A_T, int B_T, int NTAPS_>
 struct WgCfg {
-    static constexpr int J = (A_T * B_T * NTAPS_ + 3) / 4;
+    static constexpr int AB = A_T * B_T;
+    static constexpr int KS = (NTAPS_ == 9 && (AB == 1 || AB == 2)) ? 4 / AB : 1;
+    static constexpr int WPG = 4 / KS;                       // waves per pixel group
+    static constexpr int J = (AB * NTAPS_ + WPG - 1) / WPG;
     static constexpr bool PIPE = true;
     static constexpr int WAVES_PER_SIMD = (J >= 9) ? 1 : 2;
 };
@@ -54,7 +63,10 @@ wgrad_tile_kernel(const WgK ga) {
     constexpr int HT = THG + KH - 1, WT = TWG + KH - 1;
     constexpr int COB = 32 * A_T, CIB = 32 * B_T;
     constexpr int AB = A_T * B_T;
-    constexpr int T = AB * NTAPS, J = (T + 3) / 4;
+    constexpr int KS = WgCfg<A_T, B_T, NTAPS>::KS, WPG = WgCfg<A_T, B_T, NTAPS>::WPG;
+    constexpr int T = AB * NTAPS, J = WgCfg<A_T, B_T, NTAPS>::J;
+    constexpr int ROWS = THG / KS;                           // pixel rows of the tile one wave group reduces over
+    static_assert(THG % KS == 0, "tile rows must split evenly over the pixel groups");
     constexpr bool PIPE = WgCfg<A_T, B_T, NTAPS>::PIPE;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -65,6 +77,7 @@ wgrad_tile_kernel(const WgK ga) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> SGPR
     const int lane = tid & 63, li = lane & 31, half = lane >> 5;
     const int split = blockIdx.x;
+    const int pg = wave / WPG, wq = wave - pg * WPG;            // pixel group, position inside the group (SGPRs)
     int ji = 0;
 #pragma unroll
     for (int q = 1; q < TNR_WGRAD_GROUP_MAX; ++q)
@@ -92,12 +105,12 @@ wgrad_tile_kernel(const WgK ga) {
     // t = wave + 4 j  ->  (tap, aa, bb) = (t / AB, (t % AB) / B_T, (t % AB) % B_T).  With A_T == 2 the
     // block count AB is 2 or 4, so t % AB == wave % AB: every tile of a wave uses the SAME cout half
     // aa_w, and the wave reads a single A fragment per k-step.
-    static_assert(A_T == 1 || (4 % AB) == 0, "A_T == 2 needs AB in {2, 4}");
-    const int aa_w = (A_T == 1) ? 0 : (wave % AB) / B_T;
+    static_assert(A_T == 1 || (WPG % AB) == 0, "A_T == 2 needs AB to divide the waves of a group");
+    const int aa_w = (A_T == 1) ? 0 : (wq % AB) / B_T;
     int t_ok[J], t_tap[J], t_boff[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wq + WPG * j;
         t_ok[j] = t < T;
         const int tt = t_ok[j] ? t : 0;
         const int tap = tt / AB, ab = tt - tap * AB;
@@ -221,16 +234,16 @@ wgrad_tile_kernel(const WgK ga) {
         // is row base + compile-time offset, including the first step of the next row.
         {
             // integer float-offsets into smem[] (keeps the accesses provably LDS: ds_read with immediates)
-            int go = half * COB + li + aa_w * 32;
+            int go = half * COB + li + aa_w * 32 + pg * ROWS * TWG * COB;
             int xo[J];
 #pragma unroll
-            for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j];
+            for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
             float fa[2], fb[2][J];
             fa[0] = smem[go];
 #pragma unroll
             for (int j = 0; j < J; ++j) fb[0][j] = smem[xo[j]];
 #pragma unroll 1
-            for (int r = 0; r < THG; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
                 for (int k = 0; k < TWG / 2; ++k) {
                     const int cur = k & 1, nxt = cur ^ 1;
@@ -254,27 +267,54 @@ wgrad_tile_kernel(const WgK ga) {
         }
     }
 
+    // ---- pixel groups: group p = 1 .. KS-1 hands its accumulators (and bias sums) to group 0 through LDS, in order
+    float btot = bsum + __shfl_xor(bsum, 32);
+    if constexpr (KS > 1) {
+        constexpr int ACC_FLOATS = WPG * J * 16 * 64;
+        static_assert((ACC_FLOATS + WPG * 64) <= PX * COB + (HT + 1) * WT * CIB, "pixel-group reduction does not fit the tile LDS");
+#pragma unroll 1
+        for (int p = 1; p < KS; ++p) {
+            __syncthreads();                       // the tiles (p == 1) / the previous round's values are consumed
+            if (pg == p) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) smem[((wq * J + j) * 16 + r) * 64 + lane] = acc[j][r];
+                smem[ACC_FLOATS + wq * 64 + lane] = btot;
+            }
+            __syncthreads();
+            if (pg == 0) {
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][r] += smem[((wq * J + j) * 16 + r) * 64 + lane];
+                btot += smem[ACC_FLOATS + wq * 64 + lane];
+            }
+        }
+        if (pg != 0) return;                       // (no barrier follows)
+    }
+
     // ---- write the partial slab [tap][co][blk][split][32]: the split axis is contiguous (128-B granules), so the
     // reducer streams each (tap, co, blk) row; one base pointer per tile, a constant stride per output row
     {
         const int nblk = a.KinVP >> 5;
-        const size_t row_stride = (size_t)nblk * a.nsplits * 32;       // floats between consecutive co
+        const int nsl = a.nsplits, sl = split;
+        const size_t row_stride = (size_t)nblk * nsl * 32;             // floats between consecutive co
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int tap = t_tap[j] >> 10, aa = (t_tap[j] >> 5) & 31, bb = t_tap[j] & 31;
             const int blk = cib * B_T + bb;                // 32-wide virtual input-channel block
             const int co0 = cob * COB + aa * 32;           // KoutP % 32 == 0: a 32-cout block is valid as a whole
             if (!t_ok[j] || blk >= nblk || co0 >= a.KoutP) continue;
-            float *p = a.ws + (((size_t)tap * a.KoutP + co0 + 4 * half) * nblk + blk) * a.nsplits * 32 + (size_t)split * 32 + li;
+            float *p = a.ws + (((size_t)tap * a.KoutP + co0 + 4 * half) * nblk + blk) * nsl * 32 + (size_t)sl * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[(size_t)((r & 3) + 8 * (r >> 2)) * row_stride] = acc[j][r];
         }
     }
     // every wave accumulated the sums of its cout half; the first wave of each half (bb == 0) publishes
-    if (want_bias && wave < AB && (wave % B_T) == 0) {
-        const float tot = bsum + __shfl_xor(bsum, 32);
+    if (want_bias && wq < AB && (wq % B_T) == 0) {
         const int co = cob * COB + aa_w * 32 + li;
-        if (half == 0 && co < a.KoutP) a.dbp[(size_t)co * a.nsplits + split] = tot;   // [co][split]
+        if (half == 0 && co < a.KoutP) a.dbp[(size_t)co * a.nsplits + split] = btot;   // [co][split]
     }
 }
 
@@ -362,7 +402,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
 }
 
 struct WgPlan {
-    int a_t, b_t, thg;
+    int a_t, b_t, thg, ks;
     int ncib, ncob;
     int KoutP, KinVP, cinp32;
     int tiles_x, tiles_y, tiles_total, splits, tiles_per_split;
@@ -385,6 +425,9 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     }
     // LDS budget: two workgroups per CU (<= 80 KiB each) except the 1-workgroup regime (J >= 9, <= 160 KiB)
     p.thg = (p.a_t == 2 || p.b_t <= 2 || (p.b_t == 4 && d->mode != TNR_CONV_4x4_S2)) ? 8 : 4;
+    const int ab = p.a_t * p.b_t;
+    p.ks = (!s2d && (ab == 1 || ab == 2)) ? 4 / ab : 1;      // WgCfg::KS
+    if (p.ks > 1) p.thg = 16;                                // each pixel group keeps >= 4 rows (J = 9: one workgroup per CU)
     p.cinp32 = tnr_round_up(d->Cin, 32);
     p.KinVP = vch;
     p.KoutP = tnr_round_up(d->Cout, 32);
@@ -394,7 +437,8 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     p.tiles_x = tnr_cdiv(d->Wo, 16);
     p.tiles_y = tnr_cdiv(d->Ho, p.thg);
     p.tiles_total = p.tiles_x * p.tiles_y * d->N;
-    const int J = (p.a_t * p.b_t * p.ntaps + 3) / 4;
+    const int wpg = 4 / p.ks;
+    const int J = (p.a_t * p.b_t * p.ntaps + wpg - 1) / wpg;
     p.resident = (J >= 9) ? 256 : 512;           // workgroups that fit the chip at once in this regime
     const int jobs = group_jobs > 0 ? group_jobs : p.ncib * p.ncob;
     int want = p.resident / jobs;                // one full wave of workgroups, never a straggler
@@ -433,13 +477,14 @@ int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
 
 template <int MODE>
 int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
+    constexpr int THS = (MODE == TNR_CONV_4x4_S2) ? 8 : 16;   // tile rows of the pixel-split classes (plan_wgrad: ks > 1)
     if (p.a_t == 2) {
         if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, jobs, s);
-        return launch_wgrad<MODE, 2, 1, 8>(k, jobs, s);
+        return launch_wgrad<MODE, 2, 1, THS>(k, jobs, s);
     }
     switch (p.b_t) {
-        case 1: return launch_wgrad<MODE, 1, 1, 8>(k, jobs, s);
-        case 2: return launch_wgrad<MODE, 1, 2, 8>(k, jobs, s);
+        case 1: return launch_wgrad<MODE, 1, 1, THS>(k, jobs, s);
+        case 2: return launch_wgrad<MODE, 1, 2, THS>(k, jobs, s);
         case 3: return launch_wgrad<MODE, 1, 3, 4>(k, jobs, s);
         default:
             if constexpr (MODE != TNR_CONV_4x4_S2) {
@@ -485,7 +530,7 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
         const tnr_wgrad_desc &d0 = descs[0], &di = descs[i];
         TNR_REQUIRE(di.mode == d0.mode && di.N == d0.N && di.H == d0.H && di.W == d0.W && di.Ho == d0.Ho && di.Wo == d0.Wo,
                     "wgrad_group: layer %d does not share the pixel geometry of layer 0", i);
-        TNR_REQUIRE(plans[i].a_t == plans[0].a_t && plans[i].b_t == plans[0].b_t && plans[i].thg == plans[0].thg,
+        TNR_REQUIRE(plans[i].a_t == plans[0].a_t && plans[i].b_t == plans[0].b_t && plans[i].thg == plans[0].thg && plans[i].ks == plans[0].ks,
                     "wgrad_group: layer %d (%d->%d channels) is not in the tile class of layer 0 (%d->%d)", i, di.Cin,
                     di.Cout, d0.Cin, d0.Cout);
     }

@@ -167,7 +167,7 @@ class RRDBNet(HipNet):
             saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w))
         return out, saved
 
-    def _rdb_backward(self, convs, dense, buf, GP, s, gnext, extra, want_w):
+    def _rdb_backward(self, convs, dense, buf, GP, s, gnext, extra, want_w, pend):
         """Backward of one dense block as a 'gradient dense block' (mirror of the forward).
         GP: 192-ch gradient buffer whose [0:nf) holds the incoming gradient g (unscaled; the block's
         residual scale s and conv5's 0.2 are folded into the packed weights).  Fills GP[nf:] with the
@@ -186,21 +186,26 @@ class RRDBNet(HipNet):
         st.append(dict(x=View(GP), wp=dp.get(dense[4]), y=gnext, fresh_from=nf + 3 * gc, r1=g, beta1=s, **kw))
         ops.conv_chain(st)                       # one launch for the block's data-gradient (conv_chain.hip)
         if want_w:
-            convs[4].wgrad(View(buf), g, alpha=0.2 * s)
-            # conv1..conv4 (32 couts; g_k lives at GP[nf + (3-k)*gc : +gc)) as 32 x 64 and 32 x 96 channel
-            # workgroup tiles (wgrad_tile.hip): 128 inputs = 64 + 64, 160 inputs = 96 + 64.  Pieces of one
-            # tile class share a launch, so a block costs 3 weight-gradient launches instead of 7.
-            groups = {}
+            # Weight gradients are only COLLECTED here and launched per RRDB (_flush_wgrads): conv5 as 64 x 64 channel
+            # workgroup tiles; conv1..conv4 (32 couts; g_k lives at GP[nf + (3-k)*gc : +gc)) as 32 x 128 / 32 x 64 /
+            # 32 x 32 pieces (96 inputs = 64 + 32, 160 = 128 + 32) -- every class has 9 accumulator tiles per wave and
+            # no padded MFMA slot (wgrad_tile.hip), and the pieces of one class over the RRDB's three dense blocks
+            # share a launch: 4 weight-gradient launches per RRDB instead of 9.
+            pend.setdefault("c5", []).append(convs[4].wgrad_item(View(buf), g, alpha=0.2 * s))
             for k in (3, 2, 1, 0):
                 cin = nf + gc * k
                 gk = View(GP, nf + (3 - k) * gc, gc)
-                first = cin if cin <= 96 else (96 if cin > 128 else 64)
-                pieces = [(0, first)] + ([(first, cin - first)] if cin > first else [])
+                big = 4 * gc if cin >= 4 * gc else 2 * gc
+                pieces = [(0, big)] + ([(big, cin - big)] if cin > big else [])
                 for lo, n in pieces:
-                    groups.setdefault(n, []).append(convs[k].wgrad_item(View(buf, lo, n), gk, cin_begin=lo))
-            for items in groups.values():
-                for i in range(0, len(items), ops.WGRAD_GROUP_MAX):
-                    ops.wgrad_group(items[i:i + ops.WGRAD_GROUP_MAX])
+                    pend.setdefault(n, []).append(convs[k].wgrad_item(View(buf, lo, n), gk, cin_begin=lo))
+
+    @staticmethod
+    def _flush_wgrads(pend):
+        for items in pend.values():
+            for i in range(0, len(items), ops.WGRAD_GROUP_MAX):
+                ops.wgrad_group(items[i:i + ops.WGRAD_GROUP_MAX])
+        pend.clear()
 
     def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
         o, nf, gc, sl = self._ops, self.nf, self.gc, self.slope
@@ -254,20 +259,24 @@ class RRDBNet(HipNet):
         gy0 = gcur                                     # grad w.r.t. fea + trunk
         nrdb = 3 * self.nb
         cb = nf + 4 * gc
-        G = [new_act(N, h, w, cb, dev) for _ in range(3 if nrdb else 1)]
+        # four rotating gradient buffers: the three dense blocks of an RRDB keep theirs until the RRDB's grouped
+        # weight-gradient launches are enqueued; the fourth receives the gradient leaving the RRDB
+        G = [new_act(N, h, w, cb, dev) for _ in range(4 if nrdb else 1)]
         if W:
             o["lr"].wgrad(View(sv["trunk"]), gy0)
             done(o["lr"])
         o["lr"].dgrad(gy0, View(G[0], 0, nf))
         pin = 0                                        # buffer whose [0:nf) holds the incoming gradient
+        pend = {}
         for b in range(self.nb - 1, -1, -1):
-            q, r = [i for i in range(3) if i != pin]
+            q, r, t = (pin + 1) % 4, (pin + 2) % 4, (pin + 3) % 4
             bufs, convs, dense = sv["bufs"], o["rdb"], o["rdb_dense"]
-            self._rdb_backward(convs[3 * b + 2], dense[3 * b + 2], bufs[3 * b + 2], G[pin], 0.2, View(G[q], 0, nf), None, W)
-            self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W)
-            self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, View(G[q], 0, nf), View(G[pin], 0, nf), W)
-            pin = q
+            self._rdb_backward(convs[3 * b + 2], dense[3 * b + 2], bufs[3 * b + 2], G[pin], 0.2, View(G[q], 0, nf), None, W, pend)
+            self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W, pend)
+            self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, View(G[t], 0, nf), View(G[pin], 0, nf), W, pend)
+            pin = t
             if W:
+                self._flush_wgrads(pend)
                 done(convs[3 * b][0])                  # everything from this RRDB's first conv onwards is final
         gfea = View(G[pin], 0, nf)
         ops.axpby(gfea, gy0, 1.0, 1.0)                 # ShortcutBlock: both branches reach fea
