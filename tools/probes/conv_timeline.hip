@@ -93,7 +93,18 @@ static void run_chain(int N, int H, int W) {
     hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(8 * 8 * 8192);
     hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(tnr_timeline), h.size() * 8);
+    std::vector<unsigned long long> ph(8 * 8 * 8192);
+    hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(tnr_phase), ph.size() * 8);
     const int tiles = (int)(px / 512);
+    {
+        const char *pn[7] = {"barriers A + B", "load wait (vmcnt)", "LDS refill", "drain (store acks)", "neighbour wait", "next-chunk load issue", "MFMA phase"};
+        double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < tiles; ++b)
+            for (int cc = 0; cc < 6; ++cc)
+                for (int i = 0; i < 8; ++i) tot[i] += (double)ph[((size_t)b * 8 + cc) * 8 + i];
+        printf("chain chunk-loop phases, wave 0, mean cycles per chunk over %.0f chunks/workgroup (4 launches accumulated):\n", tot[7] / tiles);
+        for (int i = 0; i < 7; ++i) printf("   %-24s %9.0f\n", pn[i], tot[i] / tot[7]);
+    }
     printf("chain 5 stages N=%d %dx%d tiles=%d event time %.1f us (ticks/us from workgroup 0: %.0f)\n", N, H, W, tiles, ms * 1e3,
            (double)(h[5 * 8 + 3] - h[0]) / (ms * 1e3));
     const char *names[6] = {"conv1 64->32", "conv2 96->32", "conv3 128->32", "conv4 160->32", "conv5 cb0", "conv5 cb1"};

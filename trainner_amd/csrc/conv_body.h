@@ -7,6 +7,12 @@ namespace {
 
 typedef unsigned tnr_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | sc1 (bit 4) = system-coherent
+#ifndef TNR_COH_LOAD_AUX
+#define TNR_COH_LOAD_AUX TNR_AUX_SC0_SC1
+#endif
+#ifndef TNR_COH_STORE_AUX
+#define TNR_COH_STORE_AUX TNR_AUX_SC0_SC1
+#endif
 
 struct ConvK {
     const float *x; int x_ct, x_co;
@@ -32,7 +38,18 @@ __device__ int tnr_timeline_call[8192];      /* which body call of the workgroup
             tnr_timeline[(blockIdx.x * 8 + (tnr_timeline_call[blockIdx.x] & 7)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #define TNR_STAMP_CALL(c) do { if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_timeline_call[blockIdx.x] = (c); } while (0)
+/* per body call: cycles wave 0 spent per chunk-loop phase, summed over the chunks:
+ * 0 barriers A + B, 1 wait for the chunk's global loads (vmcnt), 2 LDS refill, 3 drain (store acknowledgements of the previous
+ * pass), 4 neighbour wait, 5 next-chunk load issue, 6 MFMA phase, 7 chunks */
+__device__ unsigned long long tnr_phase[8192 * 8 * 8];
+#define TNR_PH_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define TNR_PH_ADD(i, d)                                                                                     \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) tnr_phase[(blockIdx.x * 8 + (tnr_timeline_call[blockIdx.x] & 7)) * 8 + (i)] += (d); \
+    } while (0)
 #else
+#define TNR_PH_T(v) do { } while (0)
+#define TNR_PH_ADD(i, d) do { } while (0)
 #define TNR_STAMP(i) do { } while (0)
 #define TNR_STAMP_CALL(c) do { } while (0)
 #endif
@@ -172,7 +189,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 if (off != -1) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)(off + c0));
             } else if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
                 const unsigned bo = (off >= 0 && c0 + q * 4 < a.Cin) ? (unsigned)(off + c0) * 4u : 0xfffffff0u;
-                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_AUX_SC0_SC1));
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
             } else if (off >= 0 && c0 + q * 4 < a.Cin) {
                 v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
             }
@@ -206,16 +223,28 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     load_chunk(c_begin);
     TNR_STAMP(4);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        TNR_PH_T(ph0);
         __syncthreads();  // previous chunk's fragments are consumed
+        TNR_PH_T(ph1);
+#ifdef TNR_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        TNR_PH_T(ph2);
         store_chunk();
+#ifdef TNR_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        TNR_PH_T(ph2b);
         if (chunk == c_begin + 1) wait.drain();
+        TNR_PH_T(ph3);
         __syncthreads();
+        TNR_PH_T(ph4);
         if (chunk == c_begin + 1) wait.publish();
         if (chunk == c_begin) TNR_STAMP(1);
-        if (chunk + 1 < c_end) {
-            if (chunk + 1 == wait_chunk) wait();
-            load_chunk(chunk + 1);                       // in flight during the MFMA phase below
-        }
+        if (chunk + 1 < c_end && chunk + 1 == wait_chunk) wait();
+        TNR_PH_T(ph4b);
+        if (chunk + 1 < c_end) load_chunk(chunk + 1);    // in flight during the MFMA phase below
+        TNR_PH_T(ph5);
         // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
         // 8-channel group: MT + NT ds_read_b128 feeding 4*MT*NT MFMAs (>= 1024 matrix-core cycles).  The
         // fragments of step s+1 are read into the other register set BEFORE the MFMAs of step s issue, so
@@ -264,6 +293,13 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             mma(s_ & 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef TNR_TIMELINE
+        {
+            TNR_PH_T(ph6);
+            TNR_PH_ADD(0, (ph1 - ph0) + (ph4 - ph3)); TNR_PH_ADD(1, ph2 - ph1); TNR_PH_ADD(2, ph2b - ph2); TNR_PH_ADD(3, ph3 - ph2b);
+            TNR_PH_ADD(4, ph4b - ph4); TNR_PH_ADD(5, ph5 - ph4b); TNR_PH_ADD(6, ph6 - ph5); TNR_PH_ADD(7, 1ull);
+        }
+#endif
     }
 
 #ifdef TNR_EPI_LDS
@@ -364,7 +400,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             if (!ok[set][k]) continue;
             if (COH) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnr_u32x4, v), y_rs,
-                                                       (int)((unsigned)(pixi[set][k] * a.y_ct + a.y_co + co) * 4u), 0, TNR_AUX_SC0_SC1);
+                                                       (int)((unsigned)(pixi[set][k] * a.y_ct + a.y_co + co) * 4u), 0, TNR_COH_STORE_AUX);
             } else {
                 float *yp = a.y + pixi[set][k] * a.y_ct + a.y_co + co;
                 if (all_full) {
@@ -498,7 +534,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             const int co = co_n[nn];
             if (COH) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnr_u32x4, v), y_rs,
-                                                       (int)((unsigned)(pixi[set] * a.y_ct + a.y_co + co) * 4u), 0, TNR_AUX_SC0_SC1);
+                                                       (int)((unsigned)(pixi[set] * a.y_ct + a.y_co + co) * 4u), 0, TNR_COH_STORE_AUX);
             } else {
                 float *yp = a.y + pixi[set] * a.y_ct + a.y_co + co;
                 if (all_full) {
