@@ -193,6 +193,17 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* Bilinear x2 up-sampling, align_corners = False, and its adjoint -- F.interpolate(x, scale_factor=2, mode='bilinear',
+ * align_corners=False) between the decoder convolutions of UNetDiscriminator (discriminators.py:745-769).
+ * fwd: x [N,H,W,C] -> y [N,2H,2W,C].  bwd: gy [N,2H,2W,C] -> gx (plain, may be null) and / or
+ * gz = gx * LeakyReLU'(mask) (may be null; mask is the activation whose sign gates: > 0 -> 1, else mslope).   */
+int tnr_bilinear2x_fwd(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, void *stream);
+int tnr_bilinear2x_bwd(tnr_view gy, tnr_view gx, tnr_view gz, tnr_view mask, float mslope, int32_t N, int32_t H, int32_t W,
+                       int32_t C, void *stream);
+/* dst = a + b over `pixels` x C (the U-Net skip connections x4 + x2, x5 + x1, x6 + x0: discriminators.py:755,762,769);
+ * dst = src * LeakyReLU'(y) out of place (src stays intact for the skip path of the backward pass).          */
+int tnr_add2(tnr_view dst, tnr_view a, tnr_view b, int64_t pixels, int32_t C, void *stream);
+int tnr_mask_copy(tnr_view dst, tnr_view src, tnr_view y, int64_t pixels, int32_t C, float mslope, void *stream);
 /* --- layout / resampling (block.py:326-371 Upsample, :374-387,434-460 PixelShuffle; nn.MaxPool2d) */
 int tnr_nchw_to_nhwc(const float *src, int32_t N, int32_t C, int32_t H, int32_t W, tnr_view dst,
                      int32_t Cpad, const float *scale, const float *shift, void *stream);

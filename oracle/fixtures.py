@@ -49,9 +49,11 @@ def oracle_for(fx):
     g, d, f = initial_states(fx)
     ng = fx["network_G"]
     nd = fx["network_D"]
+    unet = bool(nd) and nd["type"] == "unet"
     return sr_oracle.OracleSRStep(
-        g, d, f, arch=ng["type"], nb=ng["nb"], d_size=(nd["size"] if nd else 0),
-        d_nf=(nd["base_nf"] if nd else 0), pixel_weight=y.get("pixel_weight", 1e-2),
+        g, d, f, arch=ng["type"], nb=ng["nb"], d_size=(nd["size"] if nd and not unet else 0),
+        d_nf=((nd["nf"] if unet else nd["base_nf"]) if nd else 0), d_arch=("unet" if unet else "discriminator_vgg"),
+        pixel_weight=y.get("pixel_weight", 1e-2),
         feature_weight=1.0 if y.get("feature", True) else 0.0,
         gan_weight=5e-3 if y.get("gan", True) else 0.0,
         upsample_mode=ng.get("upsample_mode", "upconv"))

@@ -58,6 +58,40 @@ def vgg19_conv54_gated(x, sd, relu_gates, pool_indices):
     return x
 
 
+def unet_disc_forward_gated(x, sd, gates, skip_connection=True):
+    """sr_oracle.unet_disc_forward with every LeakyReLU branch taken from `gates` (9 bool NCHW tensors: the outputs of
+    conv0 .. conv8 before any skip add, > 0)."""
+    def c(t, i, stride=1):
+        return F.conv2d(t, sd["conv%d.weight" % i], sd.get("conv%d.bias" % i), stride=stride, padding=1)
+
+    def up(t):
+        return F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+
+    x0 = _gate(c(x, 0), gates[0], O.LRELU)
+    x1 = _gate(c(x0, 1, 2), gates[1], O.LRELU)
+    x2 = _gate(c(x1, 2, 2), gates[2], O.LRELU)
+    x3 = _gate(c(x2, 3, 2), gates[3], O.LRELU)
+    x4 = _gate(c(up(x3), 4), gates[4], O.LRELU)
+    if skip_connection:
+        x4 = x4 + x2
+    x5 = _gate(c(up(x4), 5), gates[5], O.LRELU)
+    if skip_connection:
+        x5 = x5 + x1
+    x6 = _gate(c(up(x5), 6), gates[6], O.LRELU)
+    if skip_connection:
+        x6 = x6 + x0
+    out = _gate(c(x6, 7), gates[7], O.LRELU)
+    out = _gate(c(out, 8), gates[8], O.LRELU)
+    return c(out, 9)
+
+
+def gates_of_unet(saved):
+    """LeakyReLU gates of trainner_amd's UNetDiscriminator from its saved activations (enc = x0..x3, ys = the decoder
+    activations BEFORE the skip add, o7, o8)."""
+    acts = list(saved["enc"]) + list(saved["ys"]) + [saved["o7"], saved["o8"]]
+    return [a.dense().permute(0, 3, 1, 2).detach().cpu() > 0 for a in acts]
+
+
 def gates_of_discriminator(saved):
     """LeakyReLU gates of trainner_amd's Discriminator_VGG from the activations its forward saved (engine `saved`
     dict: acts = [(input view, pre-BN view or None, activation view, mean, invstd)], hid = classifier hidden)."""

@@ -35,6 +35,8 @@ CASES = {
     "esrgan_nb23_crop512_b2": dict(yaml=dict(nb=23, batch=2, crop=512, d_nf=64), steps=1, seed=51),
     # SURVEY.md 8(d) parity metric K = 10: ten consecutive G+D steps at reduced size, batch 4
     "esrgan_nb2_crop64_k10": dict(yaml=dict(nb=2, batch=4, crop=64, d_nf=16), steps=10, seed=61),
+    # Real-ESRGAN's discriminator: network_D: unet -> UNetDiscriminator, per-pixel logits, 2 steps
+    "esrgan_nb1_unet": dict(yaml=dict(nb=1, batch=2, crop=64, d_nf=16, d_type="unet"), steps=2, seed=71),
 }
 
 G_SEED, D_SEED, F_SEED = 101, 202, 77

@@ -44,7 +44,7 @@ def reference_env():
 
 def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, model_G="esrgan",
                 gan=True, feature=True, pixel_weight=1e-2, grad_clip=True, upsample_mode=None,
-                out_root=None, gpu_ids="[]"):
+                out_root=None, gpu_ids="[]", d_type="discriminator_vgg"):
     """A train_sr.yml-shaped config (codes/options/sr/train_sr.yml:1-195) for CPU."""
     out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
     os.makedirs(out_root, exist_ok=True)
@@ -54,7 +54,7 @@ def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, m
             netg += "  upsample_mode: %s\n" % upsample_mode
     else:
         netg = "network_G:\n  type: sr_resnet\n  nb: %d\n  nf: %d\n" % (nb, nf)
-    netd = "network_D:\n  type: discriminator_vgg\n  nf: %d\n" % d_nf if gan else ""
+    netd = "network_D:\n  type: %s\n  nf: %d\n" % (d_type, d_nf) if gan else ""
     train = [
         "  optim_G: adam", "  optim_D: adam", "  lr_scheme: MultiStepLR",
         "  lr_steps: [50000, 100000]", "  lr_gamma: 0.5",

@@ -125,6 +125,34 @@ def disc_vgg_forward(x, sd, size, base_nf, training=True, momentum=0.1, eps=1e-5
     return F.linear(x, sd["classifier.2.weight"], sd["classifier.2.bias"])
 
 
+def unet_disc_forward(x, sd, skip_connection=True):
+    """UNetDiscriminator.forward (models/modules/architectures/discriminators.py:736-779): conv0 (bias) + LReLU; conv1..3
+    k4 s2 without bias + LReLU; three times bilinear x2 (align_corners=False) -> conv k3 without bias + LReLU -> + skip;
+    conv7, conv8 + LReLU; conv9 (bias).  Keys conv<i>.weight (+ conv0.bias, conv9.bias).  Per-pixel logits [N,1,H,W]."""
+    def c(t, i, stride=1):
+        return F.conv2d(t, sd["conv%d.weight" % i], sd.get("conv%d.bias" % i), stride=stride, padding=1)
+
+    def up(t):
+        return F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False)
+
+    x0 = F.leaky_relu(c(x, 0), LRELU)
+    x1 = F.leaky_relu(c(x0, 1, 2), LRELU)
+    x2 = F.leaky_relu(c(x1, 2, 2), LRELU)
+    x3 = F.leaky_relu(c(x2, 3, 2), LRELU)
+    x4 = F.leaky_relu(c(up(x3), 4), LRELU)
+    if skip_connection:
+        x4 = x4 + x2
+    x5 = F.leaky_relu(c(up(x4), 5), LRELU)
+    if skip_connection:
+        x5 = x5 + x1
+    x6 = F.leaky_relu(c(up(x5), 6), LRELU)
+    if skip_connection:
+        x6 = x6 + x0
+    out = F.leaky_relu(c(x6, 7), LRELU)
+    out = F.leaky_relu(c(out, 8), LRELU)
+    return c(out, 9)
+
+
 # --------------------------------------------------------------------------------------
 # VGG19 feature extractor  (models/modules/architectures/perceptual.py:103-214)
 # --------------------------------------------------------------------------------------
@@ -242,8 +270,8 @@ class OracleSRStep:
 
     def __init__(self, g_state, d_state=None, vgg_state=None, *, arch="rrdb_net", nb=23, d_size=128,
                  d_nf=64, pixel_weight=1e-2, feature_weight=1.0, gan_weight=5e-3, lr=1e-4,
-                 grad_clip=0.1, upsample_mode="upconv"):
-        self.arch, self.nb, self.d_size, self.d_nf = arch, nb, d_size, d_nf
+                 grad_clip=0.1, upsample_mode="upconv", d_arch="discriminator_vgg"):
+        self.arch, self.nb, self.d_size, self.d_nf, self.d_arch = arch, nb, d_size, d_nf, d_arch
         self.upsample_mode = upsample_mode
         self.pw, self.fw, self.gw, self.clip = pixel_weight, feature_weight, gan_weight, grad_clip
         self.g = OrderedDict((k, v.clone().float()) for k, v in g_state.items())
@@ -267,6 +295,8 @@ class OracleSRStep:
         return srresnet_forward(lr_img, self.g, self.nb, 4)
 
     def netD(self, x):
+        if self.d_arch == "unet":
+            return unet_disc_forward(x, self.d)
         return disc_vgg_forward(x, self.d, self.d_size, self.d_nf, training=True)
 
     def step(self, LR, HR):

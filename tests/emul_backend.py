@@ -189,6 +189,29 @@ def maxpool2_bwd(gy, x, gx):
     gx.dense().copy_((g * (xin.detach() > 0)).permute(0, 2, 3, 1))
 
 
+def bilinear2x_fwd(x, y):
+    y.dense().copy_(F.interpolate(_nchw(x), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1))
+
+
+def bilinear2x_bwd(gy, gx=None, gz=None, mask=None, mslope=0.2):
+    ref = gx if gx is not None else gz
+    with torch.enable_grad():
+        xin = torch.zeros(ref.N, ref.C, ref.H, ref.W, requires_grad=True)
+        (g,) = torch.autograd.grad(F.interpolate(xin, scale_factor=2, mode="bilinear", align_corners=False), xin, _nchw(gy))
+    if gx is not None:
+        gx.dense().copy_(g.permute(0, 2, 3, 1))
+    if gz is not None:
+        gz.dense().copy_((g * _mask(_nchw(mask), mslope)).permute(0, 2, 3, 1))
+
+
+def add2(dst, a, b):
+    dst.dense().copy_(a.dense() + b.dense())
+
+
+def mask_copy(dst, src, y, mslope=0.2):
+    dst.dense().copy_(src.dense() * _mask(y.dense(), mslope))
+
+
 def axpby(dst, src, a=1.0, b=1.0):
     d = dst.dense()
     d.copy_(a * src.dense() + (b * d if b != 0 else 0))
@@ -319,7 +342,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
 
 
-_NAMES = ["conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

@@ -32,11 +32,17 @@ def test_discriminator_schedule():
     TN.test_discriminator_vgg(64, 16)
 
 
+@pytest.mark.parametrize("skip", [True, False])
+def test_unet_discriminator_schedule(skip):
+    TN.test_unet_discriminator(16, skip)
+
+
 def test_vgg_schedule():
     TN.test_vgg19_features()
 
 
-@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb2_crop64_k10"])
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb2_crop64_k10",
+                                  "esrgan_nb1_unet"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 

@@ -620,3 +620,43 @@ def test_dense_block_gradient_pack(t):
     yb = torch.zeros((N, H, W, ntar), device=DEV)
     ops.conv(ops.View(gb, 0, nf + t * gc), dp.get(idx[t]), ops.View(yb))
     close(to_nchw(yb, 0, ntar), ref, what="dense-block gradient step %d" % t)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8), (1, 1, 1, 4), (2, 16, 24, 32), (1, 1, 9, 12)])
+def test_bilinear2x_and_skip_kernels(shape):
+    """tnr_bilinear2x_fwd / _bwd against F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) and its
+    autograd adjoint (UNetDiscriminator's decoder, discriminators.py:745-769), inside channel windows of wider buffers;
+    tnr_add2 / tnr_mask_copy (skip sums and the out-of-place LeakyReLU backward) are exact."""
+    ops = _ops()
+    N, H, W, C = shape
+    x = rnd(N, C, H, W, seed=301)
+    xb = nhwc_buf(x, C + 8, 4)
+    yb = torch.full((N, 2 * H, 2 * W, C + 4), 7.0, device=DEV)
+    ops.bilinear2x_fwd(ops.View(xb, 4, C), ops.View(yb, 0, C))
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    close(to_nchw(yb, 0, C), ref, tol=2e-6, what="bilinear fwd")
+    assert float(yb[..., C:].min()) == 7.0                              # channels outside the view are untouched
+    g = rnd(N, C, 2 * H, 2 * W, seed=302)
+    xr = x.clone().requires_grad_(True)
+    (gref,) = torch.autograd.grad(F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False), xr, g)
+    gb = nhwc_buf(g, C, 0)
+    m = rnd(N, C, H, W, seed=303)
+    mb = nhwc_buf(m, C, 0)
+    gx = torch.zeros(N, H, W, C, device=DEV)
+    gz = torch.zeros(N, H, W, C + 4, device=DEV)
+    ops.bilinear2x_bwd(ops.View(gb), gx=ops.View(gx), gz=ops.View(gz, 4, C), mask=ops.View(mb), mslope=0.2)
+    close(to_nchw(gx, 0, C), gref, tol=5e-6, what="bilinear bwd")
+    gate = torch.where(m > 0, torch.ones_like(m), torch.full_like(m, 0.2))
+    close(to_nchw(gz, 4, C), gref * gate, tol=5e-6, what="bilinear bwd gated")
+    gz2 = torch.zeros(N, H, W, C, device=DEV)
+    ops.bilinear2x_bwd(ops.View(gb), gx=None, gz=ops.View(gz2), mask=ops.View(mb), mslope=0.2)
+    assert torch.equal(gz2, gz[..., 4:].contiguous())
+    # skip sum and out-of-place gate
+    a, b = rnd(N, C, H, W, seed=304), rnd(N, C, H, W, seed=305)
+    ab, bb = nhwc_buf(a, C, 0), nhwc_buf(b, C + 4, 4)
+    d = torch.zeros(N, H, W, C, device=DEV)
+    ops.add2(ops.View(d), ops.View(ab), ops.View(bb, 4, C))
+    assert torch.equal(to_nchw(d, 0, C), a + b)
+    ops.mask_copy(ops.View(d), ops.View(ab), ops.View(mb), 0.2)
+    assert torch.equal(to_nchw(d, 0, C), a * gate)
+    assert torch.equal(to_nchw(ab, 0, C), a)                            # the source stays intact

@@ -164,6 +164,48 @@ def test_discriminator_vgg(size, nf):
     assert int(net.state_dict()["features.3.num_batches_tracked"]) == 2
 
 
+@pytest.mark.parametrize("nf,skip", [(16, True), (64, True), (16, False)])
+def test_unet_discriminator(nf, skip):
+    """UNetDiscriminator (Real-ESRGAN's D, discriminators.py:686-779): per-pixel logits, input gradient and every
+    parameter gradient against the oracle; LeakyReLU gates arbitrated by the gate-pinned fp64 run (oracle/gated.py)."""
+    from trainner_amd.models.modules.architectures.discriminators import UNetDiscriminator
+    net = UNetDiscriminator(3, nf, skip_connection=skip)
+    sd = seeded(net, 21)
+    assert list(sd) == ["conv0.weight", "conv0.bias"] + ["conv%d.weight" % i for i in range(1, 10)] + ["conv9.bias"]
+    net = net.to(DEV).train()
+    x = detrand.uniform((2, 3, 48, 64), 22, 0.0, 1.0)
+    gout = detrand.uniform((2, 1, 48, 64), 23, -1.0, 1.0)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = net(xd)
+    gates = gated.gates_of_unet(out.grad_fn.saved)
+    out.backward(gout.to(DEV))
+    osd = oracle_params(sd)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = O.unet_disc_forward(xr, osd, skip)
+    ref.backward(gout)
+    assert out.shape == ref.shape == (2, 1, 48, 64)
+    assert rel_err(out, ref) < 5e-5
+    e_hip, e_cpu = dist64(xd.grad, xr.grad, xr.grad)         # ungated fp32 vs fp32: bounded loosely (flips), see below
+    assert e_hip < 2e-2, e_hip
+    gsd64 = oracle_params(to64(sd))
+    xg64 = x.detach().double().requires_grad_(True)
+    out64 = gated.unet_disc_forward_gated(xg64, gsd64, gates, skip)
+    out64.backward(gout.double())
+    assert rel_err(out, out64) < 2e-5
+    assert rel_err(xd.grad, xg64.grad) < 2e-4, rel_err(xd.grad, xg64.grad)
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, gsd64[k].grad) < 2e-4, (k, rel_err(p.grad, gsd64[k].grad))
+    # gradients accumulate; frozen parameters (G step) give the data gradient only
+    for p in net.parameters():
+        p.requires_grad_(False)
+    before = [p.grad.clone() for p in net.parameters()]
+    xd2 = x.detach().clone().to(DEV).requires_grad_(True)
+    net(xd2).backward(gout.to(DEV))
+    for b, p in zip(before, net.parameters()):
+        assert torch.equal(b, p.grad)
+    assert rel_err(xd2.grad, xg64.grad) < 2e-4
+
+
 def test_vgg19_features():
     from trainner_amd.models.modules.architectures.perceptual import FeatureExtractor
     from oracle import fixtures as FX

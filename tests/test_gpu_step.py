@@ -64,7 +64,8 @@ def check_logs(log, ref_log, tol=2e-4, d_tol=None):
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
                                   "esrgan_nb2_crop64_k10",       # K = 10 consecutive G+D steps
-                                  "esrgan_nb23_crop512_b2"])     # BASELINE configs[1] resolution, batch 2: BN over > 1 image
+                                  "esrgan_nb23_crop512_b2",      # BASELINE configs[1] resolution, batch 2: BN over > 1 image
+                                  "esrgan_nb1_unet"])            # network_D: unet (Real-ESRGAN's U-Net discriminator)
 def test_step_matches_reference_golden(case, tmp_path):
     fx = FX.load(case)
     T = CASE_TOL.get(case, DEFAULT_TOL)

@@ -12,7 +12,8 @@ from oracle import fixtures as FX
 
 CASES = ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
          "esrgan_nb2_crop64_k10",        # K = 10 consecutive steps
-         "esrgan_nb23_crop512_b2"]       # BASELINE configs[1] resolution, batch 2 through Discriminator_VGG(512)
+         "esrgan_nb23_crop512_b2",       # BASELINE configs[1] resolution, batch 2 through Discriminator_VGG(512)
+         "esrgan_nb1_unet"]              # network_D: unet (UNetDiscriminator)
 LOG_RTOL = 2e-5
 STATE_MEAN = 0.01     # mean |dp| in units of lr*steps (the largest possible Adam displacement)
 STATE_WORST = 0.6     # a noise-gradient element may flip sign once: bounded, not tight

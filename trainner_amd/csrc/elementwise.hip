@@ -244,6 +244,126 @@ __global__ void mask_mul_kernel(float *g, int g_ct, int g_co, const float *y, in
     }
 }
 
+// ---- bilinear x2, align_corners = False (F.interpolate(scale_factor=2, mode='bilinear'): UNetDiscriminator,
+// discriminators.py:745-769).  Source coordinate of output index o: max((o + 0.5) / 2 - 0.5, 0): even o = 2i blends
+// 0.25 x[i-1] + 0.75 x[i], odd o = 2i+1 blends 0.75 x[i] + 0.25 x[i+1], indices clamped at the border (where the
+// clamped source makes the blend collapse onto the border sample).
+__device__ __forceinline__ void bil_taps(int o, int n, int &i0, int &i1, float &w0, float &w1) {
+    const int i = o >> 1;
+    if (o & 1) {
+        i0 = i;
+        i1 = i + 1 < n ? i + 1 : n - 1;
+        w0 = 0.75f;
+        w1 = 0.25f;
+    } else {
+        i0 = i > 0 ? i - 1 : 0;
+        i1 = i;
+        w0 = 0.25f;
+        w1 = 0.75f;
+    }
+}
+
+__global__ void bilinear2x_fwd_kernel(const float *x, int x_ct, int x_co, float *y, int y_ct, int y_co, int N, int H, int W, int C) {
+    const int c4n = C / 4;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const int64_t total = (int64_t)N * H2 * W2 * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const int64_t pix = e / c4n;
+        const int ox = (int)(pix % W2);
+        const int64_t q = pix / W2;
+        const int oy = (int)(q % H2);
+        const int64_t n = q / H2;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        bil_taps(oy, H, y0, y1, wy0, wy1);
+        bil_taps(ox, W, x0, x1, wx0, wx1);
+        const float *b = x + x_co + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4 *>(b + ((n * H + y0) * W + x0) * x_ct);
+        const f32x4 v01 = *reinterpret_cast<const f32x4 *>(b + ((n * H + y0) * W + x1) * x_ct);
+        const f32x4 v10 = *reinterpret_cast<const f32x4 *>(b + ((n * H + y1) * W + x0) * x_ct);
+        const f32x4 v11 = *reinterpret_cast<const f32x4 *>(b + ((n * H + y1) * W + x1) * x_ct);
+        // PyTorch's order: horizontal blend inside each row, then the vertical blend of the two rows
+        const f32x4 r = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+        *reinterpret_cast<f32x4 *>(y + pix * y_ct + y_co + c4 * 4) = r;
+    }
+}
+
+// adjoint of bilinear2x_fwd: gx[i] gathers, per axis, 0.75 (g[2i] + g[2i+1]) + 0.25 (g[2i-1] + g[2i+2]) with the
+// out-of-range neighbours folded back onto the border sample (g[-1] -> the clamped tap of g[0], i.e. + 0.25 g[0]).
+// Writes the plain gradient (gx, may be null) and/or the gradient times LeakyReLU'(mask) (gz, may be null).
+__device__ __forceinline__ void bil_adj(int i, int n, int o[4], float w[4]) {
+    o[0] = 2 * i - 1; o[1] = 2 * i; o[2] = 2 * i + 1; o[3] = 2 * i + 2;
+    w[0] = 0.25f; w[1] = 0.75f; w[2] = 0.75f; w[3] = 0.25f;
+    if (i == 0) { o[0] = 0; }                       // output 0 puts its clamped 0.25 tap on x[0] as well
+    if (i == n - 1) { o[3] = 2 * n - 1; }           // output 2n-1 likewise on x[n-1]
+}
+
+__global__ void bilinear2x_bwd_kernel(const float *gy, int g_ct, int g_co, float *gx, int x_ct, int x_co, float *gz, int z_ct,
+                                      int z_co, const float *mask, int m_ct, int m_co, float mslope, int N, int H, int W, int C) {
+    const int c4n = C / 4;
+    const int W2 = 2 * W;
+    const int64_t total = (int64_t)N * H * W * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const int64_t pix = e / c4n;
+        const int x = (int)(pix % W);
+        const int64_t q = pix / W;
+        const int y = (int)(q % H);
+        const int64_t n = q / H;
+        int oy[4], ox[4];
+        float wy[4], wx[4];
+        bil_adj(y, H, oy, wy);
+        bil_adj(x, W, ox, wx);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                r += wx[b] * *reinterpret_cast<const f32x4 *>(gy + ((n * 2 * H + oy[a]) * W2 + ox[b]) * g_ct + g_co + c4 * 4);
+            s += wy[a] * r;
+        }
+        if (gx) *reinterpret_cast<f32x4 *>(gx + pix * x_ct + x_co + c4 * 4) = s;
+        if (gz) {
+            const f32x4 mv = *reinterpret_cast<const f32x4 *>(mask + pix * m_ct + m_co + c4 * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] *= (mv[k] > 0.f ? 1.f : mslope);
+            *reinterpret_cast<f32x4 *>(gz + pix * z_ct + z_co + c4 * 4) = s;
+        }
+    }
+}
+
+// dst = a + b   (skip connections of the U-Net discriminator; dst may alias neither)
+__global__ void add2_kernel(float *dst, int d_ct, int d_co, const float *a, int a_ct, int a_co, const float *b, int b_ct, int b_co,
+                            int64_t pixels, int C) {
+    const int c4n = C / 4;
+    const int64_t total = pixels * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const int64_t pix = e / c4n;
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(a + pix * a_ct + a_co + c4 * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(b + pix * b_ct + b_co + c4 * 4);
+        *reinterpret_cast<f32x4 *>(dst + pix * d_ct + d_co + c4 * 4) = av + bv;
+    }
+}
+
+// dst = src * (y > 0 ? 1 : slope)   (out-of-place LeakyReLU backward: src stays intact for a skip path)
+__global__ void mask_copy_kernel(float *dst, int d_ct, int d_co, const float *src, int s_ct, int s_co, const float *y, int y_ct,
+                                 int y_co, int64_t pixels, int C, float mslope) {
+    const int c4n = C / 4;
+    const int64_t total = pixels * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const int64_t pix = e / c4n;
+        f32x4 gv = *reinterpret_cast<const f32x4 *>(src + pix * s_ct + s_co + c4 * 4);
+        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + pix * y_ct + y_co + c4 * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k] *= (yv[k] > 0.f ? 1.f : mslope);
+        *reinterpret_cast<f32x4 *>(dst + pix * d_ct + d_co + c4 * 4) = gv;
+    }
+}
+
 __global__ void fill_kernel(float *p, int64_t n, float v) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
 }
@@ -336,6 +456,39 @@ extern "C" int tnr_mask_mul(tnr_view g, tnr_view y, int64_t pixels, int32_t C, f
     hipLaunchKernelGGL(mask_mul_kernel, dim3(ew_grid(pixels * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)stream, g.ptr, g.ctot,
                        g.coff, y.ptr, y.ctot, y.coff, pixels, C, mslope);
     return tnr_check_launch("mask_mul");
+}
+
+extern "C" int tnr_bilinear2x_fwd(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, void *stream) {
+    TNR_REQUIRE(view_ok(x) && view_ok(y) && (C % 4) == 0 && H >= 1 && W >= 1, "bilinear2x_fwd: bad arguments");
+    const int64_t total = (int64_t)N * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(bilinear2x_fwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x.ptr, x.ctot, x.coff,
+                       y.ptr, y.ctot, y.coff, N, H, W, C);
+    return tnr_check_launch("bilinear2x_fwd");
+}
+
+extern "C" int tnr_bilinear2x_bwd(tnr_view gy, tnr_view gx, tnr_view gz, tnr_view mask, float mslope, int32_t N, int32_t H,
+                                  int32_t W, int32_t C, void *stream) {
+    TNR_REQUIRE(view_ok(gy) && (gx.ptr == nullptr || view_ok(gx)) && (gz.ptr == nullptr || (view_ok(gz) && view_ok(mask))) &&
+                    (gx.ptr != nullptr || gz.ptr != nullptr) && (C % 4) == 0,
+                "bilinear2x_bwd: bad arguments");
+    const int64_t total = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bilinear2x_bwd_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, gy.ptr, gy.ctot, gy.coff,
+                       gx.ptr, gx.ctot, gx.coff, gz.ptr, gz.ctot, gz.coff, mask.ptr, mask.ctot, mask.coff, mslope, N, H, W, C);
+    return tnr_check_launch("bilinear2x_bwd");
+}
+
+extern "C" int tnr_add2(tnr_view dst, tnr_view a, tnr_view b, int64_t pixels, int32_t C, void *stream) {
+    TNR_REQUIRE(view_ok(dst) && view_ok(a) && view_ok(b) && (C % 4) == 0, "add2: bad arguments");
+    hipLaunchKernelGGL(add2_kernel, dim3(ew_grid(pixels * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)stream, dst.ptr, dst.ctot,
+                       dst.coff, a.ptr, a.ctot, a.coff, b.ptr, b.ctot, b.coff, pixels, C);
+    return tnr_check_launch("add2");
+}
+
+extern "C" int tnr_mask_copy(tnr_view dst, tnr_view src, tnr_view y, int64_t pixels, int32_t C, float mslope, void *stream) {
+    TNR_REQUIRE(view_ok(dst) && view_ok(src) && view_ok(y) && (C % 4) == 0, "mask_copy: bad arguments");
+    hipLaunchKernelGGL(mask_copy_kernel, dim3(ew_grid(pixels * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)stream, dst.ptr, dst.ctot,
+                       dst.coff, src.ptr, src.ctot, src.coff, y.ptr, y.ctot, y.coff, pixels, C, mslope);
+    return tnr_check_launch("mask_copy");
 }
 
 extern "C" int tnr_fill(float *p, int64_t n, float v, void *stream) {

@@ -88,6 +88,10 @@ _SIGS = {
     "tnr_space_to_depth_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
     "tnr_maxpool2_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
     "tnr_maxpool2_bwd": (c_i, [CView, CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_bilinear2x_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_bilinear2x_bwd": (c_i, [CView, CView, CView, CView, c_f, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_add2": (c_i, [CView, CView, CView, c_l, c_i, c_p]),
+    "tnr_mask_copy": (c_i, [CView, CView, CView, c_l, c_i, c_f, c_p]),
     "tnr_axpby": (c_i, [CView, CView, c_l, c_i, c_f, c_f, c_p]),
     "tnr_mask_mul": (c_i, [CView, CView, c_l, c_i, c_f, c_p]),
     "tnr_fill": (c_i, [c_p, c_l, c_f, c_p]),

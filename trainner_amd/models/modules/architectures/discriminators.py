@@ -135,3 +135,164 @@ class Discriminator_VGG(HipNet):
                 conv.dgrad(gz, gprev)                           # bn_train_bwd applies LeakyReLU' itself
             gy = gprev
         return None
+
+
+class UNetDiscriminator(HipNet):
+    """U-Net discriminator with per-pixel logits (Real-ESRGAN) on the MI355X engine.
+
+    Constructor, state_dict keys (conv0 .. conv9; only conv0 and conv9 carry a bias) and arithmetic follow
+    codes/models/modules/architectures/discriminators.py:686-779: conv3(in->nf)+LReLU; three conv4s2 (no bias)+LReLU
+    down to H/8; three times [bilinear x2 (align_corners=False) -> conv3 (no bias) + LReLU -> + skip]; two more
+    conv3 + LReLU; conv3(nf->1) with bias.  `spectral_norm` cannot be enabled from the options
+    (options/defaults.py:378-382 forwards only input_nc / nf / skip_connection) and is refused here.
+
+    Kernels: the k3 / k4s2 implicit-GEMM tiles (conv_tile.hip) with the image-side layers on the vector ALUs;
+    bilinear x2 and its adjoint as one HBM pass each (elementwise.hip).  The decoder activations are kept BEFORE the
+    skip add as well (y4, y5, y6): LeakyReLU' is gated by their sign, which the sum x_k = y_k + skip no longer shows.
+    """
+
+    def __init__(self, input_nc, nf=64, skip_connection=True, spectral_norm=False):
+        super().__init__()
+        if spectral_norm:
+            raise NotImplementedError("spectral norm in UNetDiscriminator is not implemented by the HIP engine")
+        if input_nc > 4 or nf % 4:
+            raise NotImplementedError("HIP UNetDiscriminator needs <= 4 image channels and nf %% 4 == 0")
+        self.input_nc, self.nf, self.skip_connection = input_nc, nf, bool(skip_connection)
+        self.slope = 0.2
+        C = B.Conv2dHIP
+        self.conv0 = C(input_nc, nf, 3, 1)
+        self.conv1 = C(nf, nf * 2, 4, 2, bias=False)
+        self.conv2 = C(nf * 2, nf * 4, 4, 2, bias=False)
+        self.conv3 = C(nf * 4, nf * 8, 4, 2, bias=False)
+        self.conv4 = C(nf * 8, nf * 4, 3, 1, bias=False)
+        self.conv5 = C(nf * 4, nf * 2, 3, 1, bias=False)
+        self.conv6 = C(nf * 2, nf, 3, 1, bias=False)
+        self.conv7 = C(nf, nf, 3, 1, bias=False)
+        self.conv8 = C(nf, nf, 3, 1, bias=False)
+        self.conv9 = C(nf, 1, 3, 1)
+        self._init_engine()
+
+    def _build_ops(self, packer):
+        self._ops = [ConvOp(getattr(self, "conv%d" % i), packer, need_dgrad=True) for i in range(10)]
+
+    def engine_forward(self, x, save):
+        N, Cc, H, W = x.shape
+        if H % 8 or W % 8:
+            raise ValueError("UNetDiscriminator needs input sizes divisible by 8, got %s" % (tuple(x.shape),))
+        dev, sl, o, nf = x.device, self.slope, self._ops, self.nf
+        act = dict(act=ops.ACT_LRELU, slope=sl)
+        x4 = View(new_act(N, H, W, 4, dev))
+        ops.nchw_to_nhwc(x, x4, Cpad=4)
+        x0 = View(new_act(N, H, W, nf, dev))
+        o[0].fwd(x4, x0, **act)
+        x1 = View(new_act(N, H // 2, W // 2, nf * 2, dev))
+        o[1].fwd(x0, x1, **act)
+        x2 = View(new_act(N, H // 4, W // 4, nf * 4, dev))
+        o[2].fwd(x1, x2, **act)
+        x3 = View(new_act(N, H // 8, W // 8, nf * 8, dev))
+        o[3].fwd(x2, x3, **act)
+        # decoder: up(prev) -> conv + LReLU = y_k;  x_k = y_k + skip
+        ups, ys, xs = [], [], []
+        prev = x3
+        for conv, skip in ((o[4], x2), (o[5], x1), (o[6], x0)):
+            up = View(new_act(N, prev.H * 2, prev.W * 2, prev.C, dev))
+            ops.bilinear2x_fwd(prev, up)
+            y = View(new_act(N, up.H, up.W, conv.mod.out_channels, dev))
+            conv.fwd(up, y, **act)
+            if self.skip_connection:
+                xk = View(new_act(N, up.H, up.W, y.C, dev))
+                ops.add2(xk, y, skip)
+            else:
+                xk = y
+            ups.append(up)
+            ys.append(y)
+            xs.append(xk)
+            prev = xk
+        o7 = View(new_act(N, H, W, nf, dev))
+        o[7].fwd(prev, o7, **act)
+        o8 = View(new_act(N, H, W, nf, dev))
+        o[8].fwd(o7, o8, **act)
+        l4 = new_act(N, H, W, 4, dev)
+        o[9].fwd(o8, View(l4, 0, 1))
+        out = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(l4, 0, 1), out)
+        saved = dict(x4=x4, enc=(x0, x1, x2, x3), ups=ups, ys=ys, xs=xs, o7=o7, o8=o8) if save else None
+        return out, saved
+
+    def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
+        Wg, sl, o, nf = need_param_grad, self.slope, self._ops, self.nf
+        gout = gout.contiguous()
+        dev = gout.device
+        x4 = sv["x4"]
+        x0, x1, x2, x3 = sv["enc"]
+        ups, ys, xs, o7, o8 = sv["ups"], sv["ys"], sv["xs"], sv["o7"], sv["o8"]
+        N, H, W = x4.N, x4.H, x4.W
+        sched = getattr(self, "_bucket_schedule", None) if Wg else None      # data-parallel gradient buckets (dp.py)
+
+        def done(i):
+            if sched is not None:
+                sched.mark_done(o[i].mod.weight)
+
+        g4 = new_act(N, H, W, 4, dev)
+        ops.nchw_to_nhwc(gout, View(g4), Cpad=4)
+        g9 = View(g4, 0, 1)
+        if Wg:
+            o[9].wgrad(o8, g9)
+            done(9)
+        g8 = View(new_act(N, H, W, nf, dev))
+        o[9].dgrad(g9, g8, mask=o8, m_slope=sl)
+        if Wg:
+            o[8].wgrad(o7, g8)
+            done(8)
+        g7 = View(new_act(N, H, W, nf, dev))
+        o[8].dgrad(g8, g7, mask=o7, m_slope=sl)
+        if Wg:
+            o[7].wgrad(xs[2], g7)
+            done(7)
+        gx = View(new_act(N, H, W, nf, dev))                 # gradient w.r.t. x6 = y6 + x0: feeds y6 (gated) and the skip
+        o[7].dgrad(g7, gx)
+        skips = []                                           # skip gradients for x0, x1, x2 (in that order)
+        enc_in = (x2, x1, x0)
+        for lvl in (2, 1, 0):                                # conv6, conv5, conv4
+            conv, up, y = o[4 + lvl], ups[lvl], ys[lvl]
+            if lvl == 2:
+                gz = View(new_act(N, y.H, y.W, y.C, dev))
+                ops.mask_copy(gz, gx, y, sl)                 # gz = gx * LeakyReLU'(y6)
+            else:
+                gz = gnext_z                                 # produced by the bilinear adjoint below
+            skips.append(gx if self.skip_connection else None)
+            if Wg:
+                conv.wgrad(up, gz)
+                done(4 + lvl)
+            gup = View(new_act(N, up.H, up.W, up.C, dev))
+            conv.dgrad(gz, gup)
+            # adjoint of the up-sampling: plain gradient of the tensor that was up-sampled (x5 / x4: a skip sum; x3: an
+            # encoder activation) and its LeakyReLU'-gated copy for the producing convolution
+            src_y = ys[lvl - 1] if lvl > 0 else x3
+            gnext_z = View(new_act(N, up.H // 2, up.W // 2, up.C, dev))
+            if lvl > 0 and self.skip_connection:
+                gx = View(new_act(N, up.H // 2, up.W // 2, up.C, dev))
+                ops.bilinear2x_bwd(gup, gx=gx, gz=gnext_z, mask=src_y, mslope=sl)
+            else:
+                gx = None
+                ops.bilinear2x_bwd(gup, gx=None, gz=gnext_z, mask=src_y, mslope=sl)
+        # encoder: conv3 <- gz3; each data-gradient adds the skip gradient of its input and gates by its LeakyReLU'
+        gz = gnext_z                                         # gradient w.r.t. conv3's pre-activation
+        s_x0, s_x1, s_x2 = skips[0], skips[1], skips[2]
+        for i, xin, skip in ((3, x2, s_x2), (2, x1, s_x1), (1, x0, s_x0)):
+            if Wg:
+                o[i].wgrad(xin, gz)
+                done(i)
+            gprev = View(new_act(N, xin.H, xin.W, xin.C, dev))
+            kw = dict(r1=skip, beta1=1.0) if skip is not None else {}
+            o[i].dgrad(gz, gprev, mask=xin, m_slope=sl, **kw)
+            gz = gprev
+        if Wg:
+            o[0].wgrad(View(x4.buf, 0, self.input_nc), gz)
+        if not need_input_grad:
+            return None
+        gx4 = View(new_act(N, H, W, 4, dev))
+        o[0].dgrad(gz, gx4)
+        gin = torch.empty((N, self.input_nc, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(gx4.buf, 0, self.input_nc), gin)
+        return gin

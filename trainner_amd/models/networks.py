@@ -62,6 +62,9 @@ def get_network(opt, step=0, selector=None):
     elif kind == "discriminator_vgg":
         from .modules.architectures import discriminators
         net = discriminators.Discriminator_VGG
+    elif kind == "unet":
+        from .modules.architectures import discriminators
+        net = discriminators.UNetDiscriminator
     else:
         raise NotImplementedError("Model [{:s}] not recognized by the HIP engine".format(kind))
 

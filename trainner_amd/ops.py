@@ -471,6 +471,26 @@ def maxpool2_bwd(gy, x, gx):
     hip.check(hip.load().tnr_maxpool2_bwd(gy.c(), x.c(), gx.c(), x.N, x.H, x.W, x.C, hip.stream()), "maxpool2_bwd")
 
 
+def bilinear2x_fwd(x, y):
+    """y [N,2H,2W,C] = bilinear x2 of x [N,H,W,C], align_corners=False."""
+    hip.check(hip.load().tnr_bilinear2x_fwd(x.c(), y.c(), x.N, x.H, x.W, x.C, hip.stream()), "bilinear2x_fwd")
+
+
+def bilinear2x_bwd(gy, gx=None, gz=None, mask=None, mslope=0.2):
+    """adjoint of bilinear2x_fwd: gx = plain gradient and / or gz = gradient * LeakyReLU'(mask)."""
+    ref = gx if gx is not None else gz
+    hip.check(hip.load().tnr_bilinear2x_bwd(gy.c(), cv(gx), cv(gz), cv(mask), mslope, ref.N, ref.H, ref.W, ref.C, hip.stream()),
+              "bilinear2x_bwd")
+
+
+def add2(dst, a, b):
+    hip.check(hip.load().tnr_add2(dst.c(), a.c(), b.c(), dst.pixels, dst.C, hip.stream()), "add2")
+
+
+def mask_copy(dst, src, y, mslope=0.2):
+    hip.check(hip.load().tnr_mask_copy(dst.c(), src.c(), y.c(), dst.pixels, dst.C, mslope, hip.stream()), "mask_copy")
+
+
 def axpby(dst, src, a=1.0, b=1.0):
     """dst = a*src + b*dst"""
     hip.check(hip.load().tnr_axpby(dst.c(), src.c(), dst.pixels, dst.C, a, b, hip.stream()), "axpby")

@@ -80,6 +80,13 @@ def get_network_D_config(network_D, scale, crop_size, model_G):
         full["convtype"] = src.pop("convtype", "Conv2D")
         full["arch"] = src.pop("G_arch", arch)
         full["size"] = src.pop("D_size", crop_size)
+    elif "unet" in kind:                               # Real-ESRGAN's U-Net discriminator (defaults.py:378-382)
+        src.pop("which_model_D", None)
+        src.pop("type", None)
+        full["type"] = "unet"
+        full["input_nc"] = src.pop("in_nc", 3)
+        full["nf"] = src.pop("nf", 64)
+        full["skip_connection"] = src.pop("skip_connection", True)
     else:
         raise NotImplementedError("Discriminator model [{}] is outside the SR hot path of the HIP engine".format(kind))
     if src:
