@@ -193,6 +193,19 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* Validation metrics on the device (the reference does these on the host: tensor2np dataops/common.py:502-566,
+ * calculate_psnr / calculate_ssim utils/metrics.py:110-126,180-223, driven by train.py:335-372).
+ * tnr_tensor2np_u8: NCHW float -> NHWC uint8 = round_half_even(clip(255 * x, 0, 255)), x -> (x + 1) / 2 first if
+ *   denormalize, channels RGB(A) -> BGR(A) if rgb2bgr (every image of the batch; the reference keeps image 0).
+ * tnr_psnr_ssim_u8: per image n, out[4n .. 4n+3] = {sum of squared differences, element count, sum of the SSIM map,
+ *   SSIM map element count} over the images cropped by `crop` border pixels (SSIM: 11x11 Gaussian window sigma 1.5,
+ *   'valid' region, fp64; count 0 if the cropped image is smaller than the window or want_ssim == 0).
+ *   PSNR = 20 log10(255 / sqrt(sum / count)); SSIM = sum / count.  ws: tnr_metrics_workspace_bytes(N).           */
+int tnr_tensor2np_u8(const float *src, int32_t N, int32_t C, int32_t H, int32_t W, uint8_t *dst, int32_t rgb2bgr,
+                     int32_t denormalize, void *stream);
+int64_t tnr_metrics_workspace_bytes(int32_t N);
+int tnr_psnr_ssim_u8(const uint8_t *a, const uint8_t *b, int32_t N, int32_t H, int32_t W, int32_t C, int32_t crop,
+                     int32_t want_ssim, double *out, double *ws, int64_t ws_bytes, void *stream);
 /* Bilinear x2 up-sampling, align_corners = False, and its adjoint -- F.interpolate(x, scale_factor=2, mode='bilinear',
  * align_corners=False) between the decoder convolutions of UNetDiscriminator (discriminators.py:745-769).
  * fwd: x [N,H,W,C] -> y [N,2H,2W,C].  bwd: gy [N,2H,2W,C] -> gx (plain, may be null) and / or

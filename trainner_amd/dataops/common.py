@@ -64,3 +64,41 @@ def recompose_tensor(patches, height, width, step=None, scale=1):
                 out[b, :, y0:y0 + P, x0:x0 + P] += patches[idx] * blend
                 idx += 1
     return out / weight
+
+
+def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=False, change_range=True, imtype=None):
+    """Network output -> uint8 image(s), on the device (reference: codes/dataops/common.py:502-566; used by
+    train.py:324-363 before the metrics and image saving).  Arithmetic is the reference's: optional (x + 1) / 2,
+    round_half_even(clip(255 x, 0, 255)), RGB -> BGR for 3 / 4-channel tensors, CHW -> HWC.
+    Returns a CUDA uint8 tensor: [H,W,C] for a 3-D input or `remove_batch` (image 0 of the batch, as the reference
+    keeps), else [N,H,W,C] (the reference builds a make_grid mosaic there; the engine keeps the batch so that
+    utils.metrics can score every image in one launch).  `.cpu().numpy()` gives the reference's array."""
+    from .. import hip
+    if not torch.is_tensor(img):
+        raise TypeError("Got unexpected object type, expected torch.Tensor")
+    if data_range != 255 or not change_range or imtype not in (None, "uint8"):
+        raise NotImplementedError("tensor2np on the HIP engine produces uint8 images in [0, 255]")
+    hip.require_device(img)
+    t = img.detach().float()
+    if t.dim() == 2:
+        t = t[None, None]
+        squeeze = "hw"
+    elif t.dim() == 3:
+        t = t[None]
+        squeeze = "hwc"
+    elif t.dim() == 4:
+        if remove_batch:
+            t = t[:1]
+        squeeze = "hwc" if remove_batch else None
+    else:
+        raise TypeError("Only support 4D, 3D and 2D tensor. But received with dimension: {:d}".format(t.dim()))
+    t = t.contiguous()
+    N, C, H, W = t.shape
+    out = torch.empty((N, H, W, C), dtype=torch.uint8, device=t.device)
+    hip.check(hip.load().tnr_tensor2np_u8(t.data_ptr(), N, C, H, W, out.data_ptr(), int(bool(rgb2bgr)), int(bool(denormalize)),
+                                         hip.stream()), "tensor2np_u8")
+    if squeeze == "hw":
+        return out[0, :, :, 0]
+    if squeeze == "hwc":
+        return out[0]
+    return out
