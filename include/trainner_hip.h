@@ -193,6 +193,13 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* Input feed (wire format: uint8 HWC BGR crop windows, as OpenCV hands the reference's datasets): one launch per batch
+ * does the paired flip / rot90 of dataops/augmentations.py:790-830 and np2tensor of dataops/common.py:470-499
+ * (x * data_range / 255, HWC -> CHW, BGR(A) -> RGB(A), optional norm()).  src [N,H,W,C] uint8 (device), dst
+ * [N,C,H,W] float; flags[n] (device int32, may be NULL): bit 0 flip (np.flip axis 1), bit 1 rot (np.rot90 k = 1),
+ * bit 2 vflip (np.flip axis 0 before the rotation; only with rot).  any_rot != 0 requires H == W.            */
+int tnr_feed_u8_to_tensor(const uint8_t *src, int32_t N, int32_t H, int32_t W, int32_t C, const int32_t *flags, int32_t any_rot,
+                          float *dst, int32_t bgr2rgb, float data_range, int32_t normalize, void *stream);
 /* Validation metrics on the device (the reference does these on the host: tensor2np dataops/common.py:502-566,
  * calculate_psnr / calculate_ssim utils/metrics.py:110-126,180-223, driven by train.py:335-372).
  * tnr_tensor2np_u8: NCHW float -> NHWC uint8 = round_half_even(clip(255 * x, 0, 255)), x -> (x + 1) / 2 first if

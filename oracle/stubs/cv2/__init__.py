@@ -7,6 +7,7 @@ SR training hot path, so upper-case names resolve to distinct ints and anything
 else raises.
 """
 _consts = {}
+__version__ = "4.5.5"     # extra_functional.py:23 compares the version at import time
 
 
 def __getattr__(name):

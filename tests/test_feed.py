@@ -1,0 +1,134 @@
+"""Input feed: wire format = uint8 HWC BGR crop windows; the paired flip / rot90 and np2tensor run
+on the device.  Fixtures come from the REFERENCE's own crop / flip / rotate90 / np2tensor / get_params
+(tests/golden/feed.pt, oracle/make_golden_feed.py).  Integer / layout work: bit-exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import feed_oracle as FO
+
+FX = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feed.pt"), weights_only=False)
+
+
+def test_feed_oracle_and_param_draws_match_reference():
+    for c in FX["cases"]:
+        x = FO.flip_rot(FO.crop(c["img"].numpy(), c["pos"], c["size"]), c["flip"], c["rot"], c["vflip"])
+        t = FO.np2tensor(np.ascontiguousarray(x), normalize=c["normalize"])
+        assert t.shape == tuple(c["out"].shape) and np.array_equal(t, c["out"].numpy())
+    from trainner_amd.data.aligned_dataset import paired_params
+    for p in FX["params"]:
+        random.seed(p["seed"])
+        np.random.seed(p["seed"])
+        got = paired_params(p["size_wh"], p["crop"])
+        assert got["crop_pos"] == p["crop_pos"] and (got["flip"], got["rot"], got["vflip"], got["hrrot"], got["angle"]) == (
+            p["flip"], p["rot"], p["vflip"], p["hrrot"], p["angle"]), (got, p)
+
+
+def test_aligned_window_dataset_windows_and_flags(tmp_path):
+    """dataset on .npy files: windows are slices of the decoded arrays at the reference's paired positions."""
+    from trainner_amd.data.aligned_dataset import AlignedWindowDataset
+    hr_dir, lr_dir = tmp_path / "hr", tmp_path / "lr"
+    hr_dir.mkdir()
+    lr_dir.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(3):
+        np.save(str(hr_dir / ("%d.npy" % i)), rng.randint(0, 256, (96, 128, 3), dtype=np.uint8))
+        np.save(str(lr_dir / ("%d.npy" % i)), rng.randint(0, 256, (24, 32, 3), dtype=np.uint8))
+    ds = AlignedWindowDataset({"dataroot_HR": str(hr_dir), "dataroot_LR": str(lr_dir), "crop_size": 32, "scale": 4,
+                               "use_flip": True, "use_rot": True, "mode": "aligned"})
+    assert len(ds) == 3
+    random.seed(5)
+    s = ds[1]
+    random.seed(5)
+    from trainner_amd.data.aligned_dataset import paired_params, read_image_bgr
+    p = paired_params((32, 24), 8)
+    x, y = p["crop_pos"]
+    assert s["LR"].shape == (8, 8, 3) and s["HR"].shape == (32, 32, 3) and s["LR"].dtype == np.uint8
+    assert np.array_equal(s["LR"], read_image_bgr(s["LR_path"])[y:y + 8, x:x + 8])
+    assert np.array_equal(s["HR"], read_image_bgr(s["HR_path"])[4 * y:4 * y + 32, 4 * x:4 * x + 32])
+    assert s["flags"] == FO.flags_of(p["flip"], p["rot"], p["vflip"])
+
+
+@pytest.mark.gpu
+def test_device_feed_kernel_matches_reference_fixtures():
+    from trainner_amd import hip
+    from trainner_amd.dataops.common import np2tensor
+    lib = hip.load()
+    for c in FX["cases"]:
+        win = np.ascontiguousarray(FO.crop(c["img"].numpy(), c["pos"], c["size"]))
+        src = torch.from_numpy(win)[None].cuda()
+        flags = torch.tensor([FO.flags_of(c["flip"], c["rot"], c["vflip"])], dtype=torch.int32, device="cuda")
+        N, H, W, C = src.shape
+        out = torch.empty((1, C, H, W), device="cuda")
+        hip.check(lib.tnr_feed_u8_to_tensor(src.data_ptr(), 1, H, W, C, flags.data_ptr(), int(c["rot"]), out.data_ptr(), 1, 1.0,
+                                            int(c["normalize"]), hip.stream()), "feed")
+        assert torch.equal(out[0].cpu(), c["out"]), (c["pos"], c["flip"], c["rot"], c["vflip"], c["normalize"])
+    c = FX["cases"][0]
+    t = np2tensor(c["img"].numpy())
+    assert tuple(t.shape) == (1, 3, 40, 52) and torch.equal(t[0].cpu(), torch.from_numpy(FO.np2tensor(c["img"].numpy())))
+
+
+@pytest.mark.gpu
+def test_device_feeder_double_buffering():
+    """Many uint8 batches through DeviceFeeder while the compute stream is kept busy: every delivered batch must be
+    the conversion of ITS host batch (no slot is overwritten before its consumer is done), in order, paths intact."""
+    from trainner_amd.data.feeder import DeviceFeeder
+    rng = np.random.RandomState(1)
+    batches = []
+    for k in range(9):
+        n = 4
+        flags = rng.randint(0, 8, n)
+        flags = np.where(flags & 2, flags, flags & 1)            # vflip only together with rot
+        batches.append({"LR": rng.randint(0, 256, (n, 16, 16, 3), dtype=np.uint8), "HR": rng.randint(0, 256, (n, 64, 64, 3), dtype=np.uint8),
+                        "flags": flags, "LR_path": ["lr%d_%d" % (k, i) for i in range(n)], "HR_path": ["hr%d_%d" % (k, i) for i in range(n)]})
+    feeder = DeviceFeeder(batches)
+    busy = torch.randn(4096, 4096, device="cuda")
+    seen = []
+    for k, d in enumerate(feeder):
+        lr, hr = d["LR"], d["HR"]                                   # consumer keeps them through its "step"
+        for _ in range(3):
+            busy = busy @ busy * 1e-4                               # compute-stream work after taking the batch
+        seen.append((lr.clone(), hr.clone(), d["LR_path"]))
+    torch.cuda.synchronize()
+    assert len(seen) == len(batches)
+    for k, (lr, hr, paths) in enumerate(seen):
+        b = batches[k]
+        for key, got in (("LR", lr), ("HR", hr)):
+            for i in range(got.shape[0]):
+                f = int(b["flags"][i])
+                want = FO.np2tensor(np.ascontiguousarray(FO.flip_rot(b[key][i], f & 1, f & 2, f & 4)))
+                assert torch.equal(got[i].cpu(), torch.from_numpy(want)), (k, key, i, f)
+        assert paths == b["LR_path"]
+    assert feeder.bytes_uploaded == sum(b["LR"].nbytes + b["HR"].nbytes for b in batches)
+
+
+@pytest.mark.gpu
+def test_training_step_through_the_feeder(tmp_path):
+    """create_dataset + create_dataloader (DeviceFeeder over a torch DataLoader) feeding SRModel.optimize_parameters."""
+    import test_gpu_step as TS
+    from trainner_amd.data import create_dataloader, create_dataset
+    hr_dir, lr_dir = tmp_path / "hr", tmp_path / "lr"
+    hr_dir.mkdir()
+    lr_dir.mkdir()
+    rng = np.random.RandomState(3)
+    for i in range(4):
+        hr = rng.randint(0, 256, (80, 96, 3), dtype=np.uint8)
+        np.save(str(hr_dir / ("%d.npy" % i)), hr)
+        np.save(str(lr_dir / ("%d.npy" % i)), hr[::4, ::4].copy())
+    opt, model = TS.build_engine_model(dict(nb=1, batch=2, crop=64, d_nf=16), tmp_path)
+    ds_opt = dict(opt["datasets"]["train"])
+    ds_opt.update(dataroot_HR=str(hr_dir), dataroot_LR=str(lr_dir), use_flip=True, use_rot=True, use_shuffle=True, phase="train",
+                  scale=4)
+    loader = create_dataloader(create_dataset(ds_opt), ds_opt)
+    assert len(loader) == 2
+    step = 0
+    for data in loader:
+        assert data["LR"].is_cuda and tuple(data["LR"].shape) == (2, 3, 16, 16) and tuple(data["HR"].shape) == (2, 3, 64, 64)
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    log = model.get_current_log()
+    assert step == 2 and all(np.isfinite(v) for v in log.values())

@@ -1,0 +1,56 @@
+"""create_dataset / create_dataloader of the engine (reference: codes/data/__init__.py:8-97).
+
+`mode: aligned` builds data.aligned_dataset.AlignedWindowDataset (uint8 crop windows); create_dataloader wraps the
+torch DataLoader (same parameters as the reference: batch_size, use_shuffle, n_workers, drop_last, pin_memory) in a
+DeviceFeeder, so iterating it yields the reference's batch dicts with device fp32 tensors.  `batch_size` keeps the
+reference's meaning -- the GLOBAL batch (options/README.md:31): with one process per GPU each rank loads
+batch_size / world_size samples of a rank-strided index shard.
+"""
+import torch.utils.data as tud
+
+from .feeder import DeviceFeeder
+
+
+def create_dataset(dataset_opt):
+    mode = str(dataset_opt["mode"]).lower()
+    if mode in ("aligned", "lrhr", "lrhrotf", "lrhrc"):
+        from .aligned_dataset import AlignedWindowDataset
+        return AlignedWindowDataset(dataset_opt)
+    raise NotImplementedError("Dataset [{:s}] is outside the SR hot path of the HIP engine".format(mode))
+
+
+class _RankShard(tud.Sampler):
+    """rank-strided subset of a (shuffled) index permutation; same permutation on every rank (seeded per epoch)."""
+
+    def __init__(self, n, rank, world, shuffle, seed=0):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __iter__(self):
+        import torch
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        idx = idx[:len(idx) - len(idx) % self.world]
+        return iter(idx[self.rank::self.world])
+
+    def __len__(self):
+        return self.n // self.world
+
+
+def create_dataloader(dataset, dataset_opt, gpu_ids=None, device=None, rank=0, world_size=1):
+    train = dataset_opt.get("phase", "test") == "train"
+    if train:
+        gb = int(dataset_opt["batch_size"])
+        if gb % world_size:
+            raise ValueError("batch_size %d is not divisible by the %d data-parallel ranks" % (gb, world_size))
+        sampler = _RankShard(len(dataset), rank, world_size, bool(dataset_opt.get("use_shuffle")))
+        loader = tud.DataLoader(dataset, batch_size=gb // world_size, sampler=sampler, drop_last=True, pin_memory=True,
+                                num_workers=int(dataset_opt.get("n_workers", 0) or 0))
+    else:
+        loader = tud.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, drop_last=False, pin_memory=True)
+    return DeviceFeeder(loader, device=device, znorm=bool(dataset_opt.get("znorm")))

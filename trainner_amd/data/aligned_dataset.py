@@ -1,0 +1,96 @@
+"""Paired LR / HR dataset that hands out uint8 crop WINDOWS (the engine's wire format) instead of fp32 tensors.
+
+Mirrors what codes/data/aligned_dataset.py does for `mode: aligned` with `preprocess: crop`: read the image pair,
+draw the paired transform parameters exactly like get_params (dataops/augmentations.py:457-511: crop position in LR
+coordinates, then flip, rot, vflip, hrrot, angle -- the same `random` draws in the same order), crop both images
+(crop(), :776-790; HR position = LR position x scale, scale_params :1025-1036) and return the batch-dict entries of
+aligned_dataset.py:166-175.  Differences, all deliberate: the crop is a zero-copy slice of the decoded uint8 array; the
+flip / rot90 and np2tensor are NOT done here but on the GPU (data/feeder.py), so a sample also carries its `flags`.
+Files: .npy arrays (uint8 HWC, BGR like cv2.imread) or anything PIL opens (converted RGB -> BGR).
+"""
+import os
+import random
+
+import numpy as np
+import torch.utils.data as data
+
+IMG_EXT = (".npy", ".png", ".jpg", ".jpeg", ".bmp", ".webp", ".tif", ".tiff")
+
+
+def _list_images(root):
+    roots = root if isinstance(root, (list, tuple)) else [root]
+    out = []
+    for r in roots:
+        for d, _, files in sorted(os.walk(r)):
+            out += [os.path.join(d, f) for f in sorted(files) if f.lower().endswith(IMG_EXT)]
+    if not out:
+        raise ValueError("no images found under %s" % (roots,))
+    return out
+
+
+def read_image_bgr(path):
+    """uint8 HWC, BGR channel order (what cv2.imread returns to the reference's datasets)."""
+    if path.lower().endswith(".npy"):
+        img = np.load(path)
+    else:
+        from PIL import Image
+        with Image.open(path) as im:
+            img = np.asarray(im.convert("RGB"))[:, :, ::-1]
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise ValueError("%s: expected a uint8 HWC image" % path)
+    return img
+
+
+def paired_params(lr_size_wh, crop_lr):
+    """get_params (dataops/augmentations.py:457-511) for preprocess 'crop': same draws, same order."""
+    w, h = lr_size_wh
+    x = random.randint(0, max(0, w - crop_lr))
+    y = random.randint(0, max(0, h - crop_lr))
+    flip = random.random() > 0.5
+    rot = random.random() > 0.5
+    vflip = random.random() > 0.5
+    hrrot = random.random() > 0.5
+    angle = int(random.uniform(-90, 90))
+    return {"crop_pos": (x, y), "flip": flip, "rot": rot, "vflip": vflip, "hrrot": hrrot, "angle": angle}
+
+
+def window(img, pos, size):
+    """crop() of dataops/augmentations.py:776-790: a slice when the image is larger than the window, else the image."""
+    x1, y1 = pos
+    oh, ow = img.shape[:2]
+    if ow > size or oh > size:
+        return img[y1:y1 + size, x1:x1 + size, ...]
+    return img
+
+
+class AlignedWindowDataset(data.Dataset):
+    def __init__(self, opt):
+        self.opt = opt
+        self.scale = int(opt.get("scale", 1) or 1)
+        self.crop = int(opt["crop_size"])
+        self.use_flip, self.use_rot = bool(opt.get("use_flip")), bool(opt.get("use_rot"))
+        if opt.get("use_hrrot"):
+            raise NotImplementedError("use_hrrot (free-angle rotation) is not implemented by the HIP engine feeder")
+        self.hr_paths = _list_images(opt["dataroot_HR"] if opt.get("dataroot_HR") else opt["dataroot_B"])
+        lr_root = opt.get("dataroot_LR") or opt.get("dataroot_A")
+        if not lr_root:
+            raise NotImplementedError("on-the-fly LR generation needs the degradation pipeline; give dataroot_LR")
+        self.lr_paths = _list_images(lr_root)
+        if len(self.lr_paths) != len(self.hr_paths):
+            raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_paths), len(self.hr_paths)))
+
+    def __len__(self):
+        return len(self.hr_paths)
+
+    def __getitem__(self, index):
+        lr, hr = read_image_bgr(self.lr_paths[index]), read_image_bgr(self.hr_paths[index])
+        crop_lr = self.crop // self.scale
+        p = paired_params((lr.shape[1], lr.shape[0]), crop_lr)
+        x, y = p["crop_pos"]
+        lr_w = window(lr, (x, y), crop_lr)
+        hr_w = window(hr, (int(x * self.scale), int(y * self.scale)), self.crop)
+        flags = (1 if (self.use_flip and p["flip"]) else 0) | (2 if (self.use_rot and p["rot"]) else 0)
+        if flags & 2 and p["vflip"]:
+            flags |= 4
+        return {"LR": np.ascontiguousarray(lr_w), "HR": np.ascontiguousarray(hr_w), "flags": flags,
+                "LR_path": self.lr_paths[index], "HR_path": self.hr_paths[index]}

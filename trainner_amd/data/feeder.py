@@ -1,0 +1,137 @@
+"""Double-buffered device feeder for the SR training step.
+
+The reference converts every sample to an fp32 CHW tensor on DataLoader worker CPUs (np2tensor, dataops/common.py:
+470-499) after the paired flip / rot90 (dataops/augmentations.py:790-830), collates, pins, and `feed_data` then blocks
+on the fp32 H2D copy (sr_model.py:115-128).  Here the wire format stays what OpenCV produced -- uint8 HWC BGR crop
+windows, 4x fewer bytes over PCIe -- and the flip / rot90 / np2tensor work runs as ONE kernel per batch
+(csrc/feed.hip) on a side HIP stream:
+
+    host batch k+1 --memcpy--> pinned staging --async H2D (copy stream)--> uint8 on device --tnr_feed_u8_to_tensor-->
+    fp32 NCHW batch, ready event                      ...while the compute stream runs step k
+
+`for data in DeviceFeeder(loader, device): model.feed_data(data); model.optimize_parameters(step)` keeps the
+reference's batch-dict contract ({'LR', 'HR', 'LR_path', 'HR_path'}, data/aligned_dataset.py:166-175): the values are
+device fp32 tensors, so SRModel.feed_data's `.to(device)` is a no-op.  Two slots of buffers rotate; a slot is refilled
+only after the compute stream passed the point where the consumer asked for the next batch (event-ordered, the host
+never blocks on the GPU).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from .. import hip
+
+IMAGE_KEYS = ("LR", "HR", "A", "B", "ref")
+
+
+class _Slot:
+    def __init__(self):
+        self.pinned, self.dev_u8, self.dev_flags, self.out = {}, {}, None, {}
+        self.ready = torch.cuda.Event()
+        self.free = None           # recorded on the compute stream when the consumer moved on
+        self.batch = None
+
+
+def _as_host_tensor(v):
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(np.ascontiguousarray(v))
+    return v
+
+
+class DeviceFeeder:
+    def __init__(self, loader, device=None, znorm=False, data_range=1.0, bgr2rgb=True, depth=2):
+        hip.require_device()
+        self.loader = loader
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.znorm, self.data_range, self.bgr2rgb = bool(znorm), float(data_range), bool(bgr2rgb)
+        self.depth = max(2, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.bytes_uploaded = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    # ------------------------------------------------------------------ one batch -> one slot
+    def _stage(self, slot, key, host):
+        """host uint8 [N,H,W,C] (or fp32 [N,C,H,W]) -> pinned staging -> device, on the copy stream."""
+        host = _as_host_tensor(host)
+        pin = slot.pinned.get(key)
+        if pin is None or pin.shape != host.shape or pin.dtype != host.dtype:
+            pin = torch.empty(host.shape, dtype=host.dtype).pin_memory()
+            slot.pinned[key] = pin
+            slot.dev_u8[key] = torch.empty(host.shape, dtype=host.dtype, device=self.device)
+        if host.is_pinned():
+            pin = host                                       # the loader pinned it already (DataLoader(pin_memory=True))
+        else:
+            pin.copy_(host)                                  # host memcpy into page-locked memory
+        dev = slot.dev_u8[key]
+        dev.copy_(pin, non_blocking=True)
+        self.bytes_uploaded += host.numel() * host.element_size()
+        return dev
+
+    def _upload(self, slot, batch):
+        lib = hip.load()
+        out = {}
+        with torch.cuda.stream(self.copy_stream):
+            if slot.free is not None:
+                self.copy_stream.wait_event(slot.free)       # the step that consumed this slot's tensors is past
+            flags = batch.get("flags")
+            any_rot = 0
+            dflags = None
+            if flags is not None:
+                f = _as_host_tensor(flags).to(torch.int32).contiguous()
+                any_rot = int(bool((f & 2).any()))
+                if slot.dev_flags is None or slot.dev_flags.numel() != f.numel():
+                    slot.dev_flags = torch.empty(f.numel(), dtype=torch.int32, device=self.device)
+                slot.dev_flags.copy_(f, non_blocking=False)  # a few bytes
+                dflags = slot.dev_flags
+            for key, val in batch.items():
+                if key not in IMAGE_KEYS:
+                    if key != "flags":
+                        out[key] = val
+                    continue
+                host = _as_host_tensor(val)
+                if host.dtype == torch.uint8:
+                    if host.dim() != 4:
+                        raise ValueError("feeder: uint8 image batches are [N,H,W,C], got %s for %r" % (tuple(host.shape), key))
+                    dev = self._stage(slot, key, host)
+                    N, H, W, C = dev.shape
+                    o = slot.out.get(key)
+                    if o is None or o.shape != (N, C, H, W):
+                        o = torch.empty((N, C, H, W), dtype=torch.float32, device=self.device)
+                        slot.out[key] = o
+                    hip.check(lib.tnr_feed_u8_to_tensor(dev.data_ptr(), N, H, W, C, hip.ptr(dflags), any_rot, o.data_ptr(),
+                                                        int(self.bgr2rgb), self.data_range, int(self.znorm), hip.stream()),
+                              "feed_u8_to_tensor")
+                    out[key] = o
+                elif host.dtype == torch.float32:            # a loader that already produced fp32 CHW tensors
+                    out[key] = self._stage(slot, key, host)
+                else:
+                    raise TypeError("feeder: %r batches must be uint8 HWC or float32 CHW, got %s" % (key, host.dtype))
+            slot.ready.record(self.copy_stream)
+        slot.batch = out
+
+    # ------------------------------------------------------------------ iteration
+    def __iter__(self):
+        it = iter(self.loader)
+        slots = [_Slot() for _ in range(self.depth)]
+        pending = collections.deque()
+        for s in slots:
+            b = next(it, None)
+            if b is None:
+                break
+            self._upload(s, b)
+            pending.append(s)
+        while pending:
+            s = pending.popleft()
+            torch.cuda.current_stream(self.device).wait_event(s.ready)
+            yield s.batch
+            # the consumer came back for the next batch: everything that reads this slot is enqueued by now
+            if s.free is None:
+                s.free = torch.cuda.Event()
+            s.free.record(torch.cuda.current_stream(self.device))
+            b = next(it, None)
+            if b is not None:
+                self._upload(s, b)
+                pending.append(s)

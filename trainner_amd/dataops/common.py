@@ -102,3 +102,23 @@ def tensor2np(img, rgb2bgr=True, remove_batch=True, data_range=255, denormalize=
     if squeeze == "hwc":
         return out[0]
     return out
+
+
+def np2tensor(img, bgr2rgb=True, data_range=1.0, normalize=False, change_range=True, add_batch=True):
+    """uint8 HWC image (numpy array, or uint8 tensor) -> fp32 tensor on the device (reference: codes/dataops/common.py:
+    470-499): x * data_range / 255, HWC -> CHW, BGR(A) -> RGB(A), optional norm(); [1,C,H,W] with add_batch."""
+    import numpy as np
+    from .. import hip
+    if isinstance(img, np.ndarray):
+        img = torch.from_numpy(np.ascontiguousarray(img))
+    if not torch.is_tensor(img) or img.dtype != torch.uint8 or not change_range:
+        raise TypeError("np2tensor on the HIP engine converts uint8 images")
+    if img.dim() == 2:
+        img = img[:, :, None]
+    hip.require_device()
+    src = img.to("cuda").contiguous()
+    H, W, C = src.shape
+    out = torch.empty((1, C, H, W), dtype=torch.float32, device=src.device)
+    hip.check(hip.load().tnr_feed_u8_to_tensor(src.data_ptr(), 1, H, W, C, None, 0, out.data_ptr(), int(bool(bgr2rgb)),
+                                              float(data_range), int(bool(normalize)), hip.stream()), "feed_u8_to_tensor")
+    return out if add_batch else out[0]
