@@ -62,7 +62,7 @@ path:
 network_G:
   type: esrgan
   gaussian: false
-network_D: discriminator_vgg
+network_D: {netd}
 train:
   optim_G: adam
   optim_D: adam
@@ -87,14 +87,14 @@ logger:
 """
 
 
-def make_model(batch, crop, rank, world=1):
+def make_model(batch, crop, rank, world=1, netd="discriminator_vgg"):
     """batch = per-GPU batch; the YAML carries the reference's GLOBAL batch_size (options/README.md:31)."""
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     root = tempfile.mkdtemp(prefix="tnr_bench_r%d_" % rank)
     path = os.path.join(root, "bench.yml")
     with open(path, "w") as f:
-        f.write(YAML.format(batch=batch * world, crop=crop, root=root, gpu_ids=list(range(world))))
+        f.write(YAML.format(batch=batch * world, crop=crop, root=root, gpu_ids=list(range(world)), netd=netd))
     torch.manual_seed(1234 + rank)                # replicas are made identical by SRModel.sync_replicas (rank 0 wins)
     opt = options.parse(path, is_train=True)
     model = create_model(opt, verbose=False)
@@ -110,6 +110,30 @@ def make_model(batch, crop, rank, world=1):
             sd[k] = torch.zeros_like(v)
     netF.load_state_dict(sd)
     return model
+
+
+class HostBatches:
+    """--feed: an endless supply of HOST batches in the engine's wire format (uint8 HWC BGR crop windows + paired-transform
+    flags), cycling over a small pre-generated pool -- what a DataLoader over AlignedWindowDataset yields."""
+
+    def __init__(self, n_batches, batch, crop, seed, paired):
+        import numpy as np
+        rs = np.random.RandomState(seed)
+        self.pool = []
+        for _ in range(4):
+            hr = rs.randint(0, 256, (batch, crop, crop, 3), dtype=np.uint8)
+            b = {"HR": torch.from_numpy(hr).pin_memory(), "flags": torch.from_numpy(rs.randint(0, 2, batch).astype("int32") * 1)}
+            if paired:
+                b["LR"] = torch.from_numpy(np.ascontiguousarray(hr[:, ::4, ::4])).pin_memory()
+            self.pool.append(b)
+        self.n = n_batches
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield self.pool[i % len(self.pool)]
 
 
 def synthetic(batch, crop, seed, device):
@@ -204,6 +228,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape kernel table on stderr")
+    ap.add_argument("--feed", choices=["none", "paired", "resrgan"], default="none",
+                    help="variant with the input pipeline in the loop: uint8 host batches through the double-buffered DeviceFeeder "
+                         "(paired: LR + HR windows; resrgan: HR windows only, LR synthesised by the GPU degradation pipeline)")
+    ap.add_argument("--netd", choices=["discriminator_vgg", "unet"], default="discriminator_vgg")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
@@ -231,7 +259,7 @@ def main():
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
 
-    model = make_model(args.batch, args.crop, rank, world)
+    model = make_model(args.batch, args.crop, rank, world, args.netd)
     assert model.dp.world_size == world and (world == 1 or model.dp.active)
     LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)      # this rank's shard of the global batch
     data = {"LR": LR, "HR": HR}
@@ -243,15 +271,29 @@ def main():
             torch.cuda.synchronize()
 
     step = 0
+    feeder = None
+    if args.feed != "none":
+        from trainner_amd.data.feeder import DeviceFeeder
+        degrade = None
+        if args.feed == "resrgan":
+            from trainner_amd.dataops.degradations import RealESRGANDegradation
+            degrade = RealESRGANDegradation(scale=4, seed=rank)
+        feeder = DeviceFeeder(HostBatches(args.warmup + args.steps, args.batch, args.crop, 1000 + rank, args.feed == "paired"),
+                              device=device, degrade=degrade)
+        batches = iter(feeder)
+
+    def next_batch():
+        return data if feeder is None else next(batches)
+
     for _ in range(args.warmup):
         step += 1
-        model.feed_data(data)
+        model.feed_data(next_batch())
         model.optimize_parameters(step)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step += 1
-        model.feed_data(data)
+        model.feed_data(next_batch())
         model.optimize_parameters(step)
     barrier()
     dt = time.perf_counter() - t0
@@ -264,7 +306,7 @@ def main():
         raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
 
     roof = None
-    if not args.no_roofline:
+    if not args.no_roofline and feeder is None:
         # separate instrumented pass: HIP events around every implicit-GEMM launch, on the launch stream
         prof = ops.ConvProfile()
         ops.PROFILE = prof
@@ -316,6 +358,13 @@ def main():
             "roofline": roof,
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
+        if feeder is not None:
+            out["config"]["workload"] += "; INPUT PIPELINE IN THE LOOP: uint8 HWC host batches -> pinned H2D -> device np2tensor/flip/rot" + (
+                " + Real-ESRGAN degradations (LR synthesised on the GPU)" if args.feed == "resrgan" else "") + " (DeviceFeeder, double-buffered)"
+            out["feed"] = {"mode": args.feed, "h2d_bytes_per_step": feeder.bytes_uploaded // max(args.warmup + args.steps, 1),
+                           "note": "variant run: the headline `value` is measured with inputs resident in HBM (default run)"}
+        if args.netd != "discriminator_vgg":
+            out["config"]["workload"] = out["config"]["workload"].replace("Discriminator_VGG(%d)" % args.crop, "UNetDiscriminator")
         if dry:
             out["value"] = None
             out["invalid"] = "dry run"

@@ -193,6 +193,24 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* Real-ESRGAN style degradations on fp32 NCHW images in [0, 1] (the LR synthesis the reference runs per sample with
+ * OpenCV on DataLoader workers: dataops/augmentations.py:1666-1801, options/presets/resrgan_*.yaml).
+ * tnr_filter2d: cv2.filter2D semantics (correlation, centred anchor, BORDER_REFLECT_101) with one 21 x 21 kernel slot per
+ *   image (smaller kernels centred, zeros around) -- iso / aniso Gaussian and sinc blurs of 7..21 taps.
+ * tnr_resize: cv2.resize semantics for mode 0 INTER_AREA, 1 INTER_LINEAR, 2 INTER_CUBIC on NC planes of H x W -> Ho x Wo.
+ * tnr_noise_gaussian: x += sigma255[n][c] / 255 * N(0, 1) (grey[n]: one draw per pixel for all channels, sigma255[n][0]).
+ * tnr_noise_poisson: x += scale[n] * (Poisson(x * vals[n]) / vals[n] - x), the difference reduced to luma when grey[n].
+ *   Both in place, counter-based RNG (Philox4x32-10 keyed by seed and sample): reproducible for a given seed.
+ * tnr_jpeg_sim: in place JPEG round trip of RGB images at quality[n] (JFIF YCbCr, 4:2:0, 8x8 DCT, Annex-K tables with
+ *   libjpeg's quality scaling, triangle chroma up-sampling); ws: tnr_jpeg_workspace_bytes(N, H, W).            */
+int tnr_filter2d(const float *src, float *dst, const float *kernels21, int32_t N, int32_t C, int32_t H, int32_t W, void *stream);
+int tnr_resize(const float *src, float *dst, int32_t NC, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t mode, void *stream);
+int tnr_noise_gaussian(float *img, int32_t N, int32_t C, int32_t H, int32_t W, const float *sigma255, const int32_t *grey,
+                       uint64_t seed, int32_t clip, void *stream);
+int tnr_noise_poisson(float *img, int32_t N, int32_t C, int32_t H, int32_t W, const float *vals, const float *scale,
+                      const int32_t *grey, uint64_t seed, int32_t clip, void *stream);
+int64_t tnr_jpeg_workspace_bytes(int32_t N, int32_t H, int32_t W);
+int tnr_jpeg_sim(float *img, int32_t N, int32_t H, int32_t W, const int32_t *quality, float *ws, int64_t ws_bytes, void *stream);
 /* Input feed (wire format: uint8 HWC BGR crop windows, as OpenCV hands the reference's datasets): one launch per batch
  * does the paired flip / rot90 of dataops/augmentations.py:790-830 and np2tensor of dataops/common.py:470-499
  * (x * data_range / 255, HWC -> CHW, BGR(A) -> RGB(A), optional norm()).  src [N,H,W,C] uint8 (device), dst

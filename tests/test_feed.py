@@ -132,3 +132,30 @@ def test_training_step_through_the_feeder(tmp_path):
         model.optimize_parameters(step)
     log = model.get_current_log()
     assert step == 2 and all(np.isfinite(v) for v in log.values())
+
+
+@pytest.mark.gpu
+def test_resrgan_strategy_synthesises_lr_on_device(tmp_path):
+    """augs_strategy: resrgan without dataroot_LR: the dataset ships HR windows only, the feeder converts them and runs
+    the degradation pipeline on the copy stream; network_D: unet consumes the pair (BASELINE configs[3] on one GPU)."""
+    import test_gpu_step as TS
+    from trainner_amd.data import create_dataloader, create_dataset
+    hr_dir = tmp_path / "hr"
+    hr_dir.mkdir()
+    rng = np.random.RandomState(4)
+    for i in range(4):
+        np.save(str(hr_dir / ("%d.npy" % i)), rng.randint(0, 256, (80, 96, 3), dtype=np.uint8))
+    opt, model = TS.build_engine_model(dict(nb=1, batch=2, crop=64, d_nf=16, d_type="unet"), tmp_path)
+    ds_opt = dict(opt["datasets"]["train"])
+    ds_opt.pop("dataroot_LR", None)
+    ds_opt.update(dataroot_HR=str(hr_dir), dataroot_LR=None, augs_strategy="resrgan", use_flip=True, use_rot=True, use_shuffle=False,
+                  phase="train", scale=4)
+    loader = create_dataloader(create_dataset(ds_opt), ds_opt)
+    step = 0
+    for data in loader:
+        assert tuple(data["LR"].shape) == (2, 3, 16, 16) and tuple(data["HR"].shape) == (2, 3, 64, 64)
+        assert float(data["LR"].min()) >= 0 and float(data["LR"].max()) <= 1 and data["LR_path"] == data["HR_path"]
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    assert step == 2 and all(np.isfinite(v) for v in model.get_current_log().values())

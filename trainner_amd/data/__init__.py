@@ -53,4 +53,8 @@ def create_dataloader(dataset, dataset_opt, gpu_ids=None, device=None, rank=0, w
                                 num_workers=int(dataset_opt.get("n_workers", 0) or 0))
     else:
         loader = tud.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, drop_last=False, pin_memory=True)
-    return DeviceFeeder(loader, device=device, znorm=bool(dataset_opt.get("znorm")))
+    degrade = None
+    if train and str(dataset_opt.get("augs_strategy", "")).lower() == "resrgan":       # options/presets/README.md:25-33
+        from ..dataops.degradations import RealESRGANDegradation
+        degrade = RealESRGANDegradation(scale=int(dataset_opt.get("scale", 4) or 4), seed=int(dataset_opt.get("seed", 0) or 0) + rank)
+    return DeviceFeeder(loader, device=device, znorm=bool(dataset_opt.get("znorm")), degrade=degrade)

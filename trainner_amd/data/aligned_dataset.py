@@ -73,17 +73,26 @@ class AlignedWindowDataset(data.Dataset):
             raise NotImplementedError("use_hrrot (free-angle rotation) is not implemented by the HIP engine feeder")
         self.hr_paths = _list_images(opt["dataroot_HR"] if opt.get("dataroot_HR") else opt["dataroot_B"])
         lr_root = opt.get("dataroot_LR") or opt.get("dataroot_A")
-        if not lr_root:
-            raise NotImplementedError("on-the-fly LR generation needs the degradation pipeline; give dataroot_LR")
-        self.lr_paths = _list_images(lr_root)
-        if len(self.lr_paths) != len(self.hr_paths):
-            raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_paths), len(self.hr_paths)))
+        self.lr_paths = None
+        if lr_root:
+            self.lr_paths = _list_images(lr_root)
+            if len(self.lr_paths) != len(self.hr_paths):
+                raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_paths), len(self.hr_paths)))
+        elif str(opt.get("augs_strategy", "")).lower() != "resrgan":
+            raise NotImplementedError("no dataroot_LR: on-the-fly LR needs `augs_strategy: resrgan` (GPU degradation pipeline)")
 
     def __len__(self):
         return len(self.hr_paths)
 
     def __getitem__(self, index):
-        lr, hr = read_image_bgr(self.lr_paths[index]), read_image_bgr(self.hr_paths[index])
+        hr = read_image_bgr(self.hr_paths[index])
+        if self.lr_paths is None:           # HR window only: the LR image is synthesised on the GPU (data/feeder.py)
+            p = paired_params((hr.shape[1], hr.shape[0]), self.crop)
+            flags = (1 if (self.use_flip and p["flip"]) else 0) | (2 if (self.use_rot and p["rot"]) else 0)
+            if flags & 2 and p["vflip"]:
+                flags |= 4
+            return {"HR": np.ascontiguousarray(window(hr, p["crop_pos"], self.crop)), "flags": flags, "HR_path": self.hr_paths[index]}
+        lr = read_image_bgr(self.lr_paths[index])
         crop_lr = self.crop // self.scale
         p = paired_params((lr.shape[1], lr.shape[0]), crop_lr)
         x, y = p["crop_pos"]

@@ -40,9 +40,12 @@ def _as_host_tensor(v):
 
 
 class DeviceFeeder:
-    def __init__(self, loader, device=None, znorm=False, data_range=1.0, bgr2rgb=True, depth=2):
+    def __init__(self, loader, device=None, znorm=False, data_range=1.0, bgr2rgb=True, depth=2, degrade=None):
+        """degrade: optional callable HR batch -> LR batch (dataops.degradations.RealESRGANDegradation): batches that
+        carry no 'LR' get it synthesised from 'HR' on the copy stream (augs_strategy: resrgan)."""
         hip.require_device()
         self.loader = loader
+        self.degrade = degrade
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.znorm, self.data_range, self.bgr2rgb = bool(znorm), float(data_range), bool(bgr2rgb)
         self.depth = max(2, int(depth))
@@ -109,6 +112,18 @@ class DeviceFeeder:
                     out[key] = self._stage(slot, key, host)
                 else:
                     raise TypeError("feeder: %r batches must be uint8 HWC or float32 CHW, got %s" % (key, host.dtype))
+            if self.degrade is not None and "LR" not in out and "HR" in out:
+                if self.znorm:
+                    raise NotImplementedError("on-device degradations expect images in [0, 1] (znorm: false)")
+                lr = self.degrade(out["HR"])
+                o = slot.out.get("LR")
+                if o is None or o.shape != lr.shape:
+                    o = torch.empty_like(lr)
+                    slot.out["LR"] = o
+                o.copy_(lr)                                   # persistent slot buffer: no allocator reuse across streams
+                out["LR"] = o
+                if "HR_path" in out and "LR_path" not in out:
+                    out["LR_path"] = out["HR_path"]
             slot.ready.record(self.copy_stream)
         slot.batch = out
 

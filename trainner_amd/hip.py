@@ -88,6 +88,12 @@ _SIGS = {
     "tnr_space_to_depth_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
     "tnr_maxpool2_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
     "tnr_maxpool2_bwd": (c_i, [CView, CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_filter2d": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_resize": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_noise_gaussian": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, C.c_uint64, c_i, c_p]),
+    "tnr_noise_poisson": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, C.c_uint64, c_i, c_p]),
+    "tnr_jpeg_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "tnr_jpeg_sim": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "tnr_feed_u8_to_tensor": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_i, c_f, c_i, c_p]),
     "tnr_tensor2np_u8": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p]),
     "tnr_metrics_workspace_bytes": (c_l, [c_i]),
