@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16, dense: 256 CU x 4 SIMD x 32768 FLOP / 32 cycles x 2.4 GHz
 FLOP_PER_IMG = 3.0327e12           # full optimize_parameters, fp32, 128->512
 BATCH_PER_GPU = 16
 CROP = 512
@@ -44,7 +45,7 @@ use_tb_logger: false
 model: sr
 scale: 4
 gpu_ids: {gpu_ids}
-use_amp: false
+use_amp: {amp}
 datasets:
   train:
     name: synthetic
@@ -87,14 +88,15 @@ logger:
 """
 
 
-def make_model(batch, crop, rank, world=1, netd="discriminator_vgg"):
+def make_model(batch, crop, rank, world=1, netd="discriminator_vgg", amp=False):
     """batch = per-GPU batch; the YAML carries the reference's GLOBAL batch_size (options/README.md:31)."""
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     root = tempfile.mkdtemp(prefix="tnr_bench_r%d_" % rank)
     path = os.path.join(root, "bench.yml")
     with open(path, "w") as f:
-        f.write(YAML.format(batch=batch * world, crop=crop, root=root, gpu_ids=list(range(world)), netd=netd))
+        f.write(YAML.format(batch=batch * world, crop=crop, root=root, gpu_ids=list(range(world)), netd=netd,
+                            amp="true" if amp else "false"))
     torch.manual_seed(1234 + rank)                # replicas are made identical by SRModel.sync_replicas (rank 0 wins)
     opt = options.parse(path, is_train=True)
     model = create_model(opt, verbose=False)
@@ -232,6 +234,9 @@ def main():
                     help="variant with the input pipeline in the loop: uint8 host batches through the double-buffered DeviceFeeder "
                          "(paired: LR + HR windows; resrgan: HR windows only, LR synthesised by the GPU degradation pipeline)")
     ap.add_argument("--netd", choices=["discriminator_vgg", "unet"], default="discriminator_vgg")
+    ap.add_argument("--amp", action="store_true",
+                    help="variant: `use_amp: true` = bf16 matrix-core operands, fp32 accumulate (reported as dtype bf16 with its own "
+                         "roofline; the headline run is fp32)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
@@ -259,7 +264,7 @@ def main():
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
 
-    model = make_model(args.batch, args.crop, rank, world, args.netd)
+    model = make_model(args.batch, args.crop, rank, world, args.netd, args.amp)
     assert model.dp.world_size == world and (world == 1 or model.dp.active)
     LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)      # this rank's shard of the global batch
     data = {"LR": LR, "HR": HR}
@@ -333,9 +338,12 @@ def main():
             kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
                      "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
             traffic, traffic_src = pmc_traffic(fam)
+            peak = PEAK_BF16_MFMA_TFLOPS if args.amp else PEAK_F32_MFMA_TFLOPS
+            if args.amp:
+                traffic, traffic_src = None, None        # (the recorded PMC passes are of the fp32 run)
             roof = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
@@ -347,7 +355,7 @@ def main():
             "metric": "HR images/sec (G+D step), ESRGAN x4 128->512",
             "value": round(imgs / dt, 3), "unit": "HR img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None, "dtype": "bf16" if args.amp else "f32",
             "data": "synthetic" if not dry else "DRY-RUN on CPU (emulated C ABI, tiny shapes): NOT a measurement",
             "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),

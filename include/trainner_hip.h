@@ -59,6 +59,9 @@ enum {
     TNR_PACK_C4_DGRAD3 = 7  /* [1][KoutP=ci][48]: column 4*t + co (Cout <= 4), taps flipped                     */
 };
 
+#define TNR_MMA_F32 0
+#define TNR_MMA_BF16 1
+
 typedef struct tnr_view {
     float *ptr;
     int32_t ctot; /* channels per pixel of the underlying buffer */
@@ -93,6 +96,11 @@ typedef struct tnr_conv_desc {
      * into partial sums in ws, reduced in a fixed order by a second launch that applies bias / act / alpha.
      * NULL: never split.                                                                               */
     float *ws; int64_t ws_bytes;
+    /* matrix-core operand precision: TNR_MMA_F32 = v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: the default, bit
+     * parity class of the CPU reference); TNR_MMA_BF16 = activations and weights rounded to bf16 (round-to-nearest-even) as
+     * they enter the matrix core, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 epilogue and storage -- the engine's
+     * `use_amp: true` policy (base_model.py:736-744 autocasts the convolutions to half precision).               */
+    int32_t mma;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -107,6 +115,7 @@ typedef struct tnr_wgrad_desc {
     float *db;                                     /* [Cout] or NULL (only with cin_begin == 0)        */
     float alpha, beta;
     float *ws; int64_t ws_bytes;                   /* >= tnr_wgrad_workspace_bytes()                  */
+    int32_t mma;                                   /* TNR_MMA_F32 | TNR_MMA_BF16 (see tnr_conv_desc)   */
 } tnr_wgrad_desc;
 
 typedef struct tnr_pack_item {

@@ -44,7 +44,7 @@ def reference_env():
 
 def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, model_G="esrgan",
                 gan=True, feature=True, pixel_weight=1e-2, grad_clip=True, upsample_mode=None,
-                out_root=None, gpu_ids="[]", d_type="discriminator_vgg"):
+                out_root=None, gpu_ids="[]", d_type="discriminator_vgg", amp=False):
     """A train_sr.yml-shaped config (codes/options/sr/train_sr.yml:1-195) for CPU."""
     out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
     os.makedirs(out_root, exist_ok=True)
@@ -71,7 +71,7 @@ def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, m
         train += ["  grad_clip: norm", "  grad_clip_value: 0.1"]
     txt = "\n".join([
         "name: %s" % name, "use_tb_logger: false", "model: sr", "scale: 4", "gpu_ids: %s" % gpu_ids,
-        "use_amp: false", "use_swa: false", "use_cem: false", "use_atg: false",
+        "use_amp: %s" % ("true" if amp else "false"), "use_swa: false", "use_cem: false", "use_atg: false",
         "datasets:", "  train:", "    name: synth", "    mode: aligned",
         "    dataroot_HR: /tmp/none_hr", "    dataroot_LR: /tmp/none_lr", "    znorm: false",
         "    n_workers: 0", "    batch_size: %d" % batch, "    virtual_batch_size: %d" % batch,

@@ -63,10 +63,10 @@ def _dense_dgrad(xin, wp, yC):
     """sum over the consumers of the target group of conv_transpose(g_k, W_k[:, target])."""
     nf, gc, t = wp.nf, wp.gc, wp.tt
     tlo, ntar = (0, nf) if t == 4 else (nf + (3 - t) * gc, gc)
-    w5 = wp.srcs[4].detach()[:, tlo:tlo + ntar]
-    out = wp.scale5 * F.conv_transpose2d(xin[:, :nf], w5, None, padding=1)
+    w5 = _mm(wp.scale5 * wp.srcs[4].detach()[:, tlo:tlo + ntar])       # conv5's scale is folded into the PACKED weight
+    out = F.conv_transpose2d(xin[:, :nf], w5, None, padding=1)
     for m in range(t):
-        wk = wp.srcs[3 - m].detach()[:, tlo:tlo + ntar]
+        wk = _mm(wp.srcs[3 - m].detach()[:, tlo:tlo + ntar])
         out = out + F.conv_transpose2d(xin[:, nf + m * gc: nf + (m + 1) * gc], wk, None, padding=1)
     return out
 
@@ -86,10 +86,15 @@ def _mask(m, slope):
     return torch.where(m > 0, torch.ones_like(m), torch.full_like(m, slope))
 
 
+def _mm(t):
+    """TNR_MMA_BF16 contract: operands rounded to bf16 in front of the matrix core (fp32 accumulate)."""
+    return t.to(torch.bfloat16).to(torch.float32) if (t is not None and ops.MMA == hip.MMA_BF16) else t
+
+
 def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
          beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
-    xin = _nchw(x)
-    w = None if wp.kind == ops.PACK_DENSE_DGRAD else wp.w.detach()
+    xin = _mm(_nchw(x))
+    w = None if wp.kind == ops.PACK_DENSE_DGRAD else _mm(wp.w.detach())
     if wp.kind == ops.PACK_DENSE_DGRAD:
         out = _dense_dgrad(xin, wp, y.C)
     elif wp.kind == ops.PACK_FWD:
@@ -125,7 +130,8 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
 
 def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
     k = 4 if mode == ops.CONV_4x4_S2 else 3
-    xin, gin = _nchw(x), _nchw(g)
+    xin, gin_raw = _mm(_nchw(x)), _nchw(g)
+    gin = _mm(gin_raw)
     with torch.enable_grad():
         w0 = torch.zeros(g.C, x.C, k, k, requires_grad=True)
         if mode == ops.CONV_3x3_UP2:
@@ -138,7 +144,7 @@ def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0
     tgt = dw[:, cin_begin:cin_begin + x.C]
     tgt.copy_(beta * tgt + alpha * gw)
     if db is not None:
-        db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
+        db.copy_(beta * db + alpha * gin_raw.sum(dim=(0, 2, 3)))
 
 
 def nchw_to_nhwc(src, dst, Cpad=None, scale=None, shift=None):

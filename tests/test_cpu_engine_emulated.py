@@ -47,6 +47,10 @@ def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 
 
+def test_amp_policy_step(tmp_path):
+    TS.test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, "discriminator_vgg")
+
+
 def test_validation_forward_and_self_ensemble(tmp_path):
     TS.test_validation_forward_and_self_ensemble(tmp_path)
 

@@ -660,3 +660,94 @@ def test_bilinear2x_and_skip_kernels(shape):
     ops.mask_copy(ops.View(d), ops.View(ab), ops.View(mb), 0.2)
     assert torch.equal(to_nchw(d, 0, C), a * gate)
     assert torch.equal(to_nchw(ab, 0, C), a)                            # the source stays intact
+
+
+def _bf(t):
+    """round to bf16 (nearest even) and back: what TNR_MMA_BF16 feeds the matrix core"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def test_bf16_operand_mode(monkeypatch):
+    """TNR_MMA_BF16 (`use_amp: true`): activations and weights rounded to bf16 in front of the matrix core, fp32 accumulate,
+    fp32 epilogue / storage.  Products of bf16 values are exact in fp32, so every launch must equal the fp32 PyTorch op
+    on bf16-ROUNDED operands up to summation order (tolerance as for the fp32 kernels) -- forward with fused epilogue,
+    strided forward, both data-gradients, the up-sampling stager, the dense-block chain, and every weight-gradient class."""
+    from trainner_amd import hip
+    ops = _ops()
+    monkeypatch.setattr(ops, "MMA", hip.MMA_BF16)
+    # 3x3 forward, window of a wider buffer, bias + LeakyReLU + residual
+    N, H, W, Cin, Cout = 2, 20, 37, 96, 32
+    x, w, b, r = rnd(N, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, lo=-0.2, hi=0.2), rnd(Cout, seed=3), rnd(N, Cout, H, W, seed=4)
+    ref = F.leaky_relu(F.conv2d(_bf(x), _bf(w), b, padding=1), 0.2) * 0.5 + r
+    xb, rb = nhwc_buf(x, 192, 0), nhwc_buf(r)
+    yb = torch.full((N, H, W, 192), -3.0, device=DEV)
+    wp, _k1 = pack(ops, w.to(DEV), ops.PACK_FWD)
+    ops.conv(ops.View(xb, 0, Cin), wp, ops.View(yb, 96, Cout), bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.5, r1=ops.View(rb))
+    close(to_nchw(yb, 96, Cout), ref, what="bf16 conv3x3")
+    plain = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2) * 0.5 + r
+    assert (to_nchw(yb, 96, Cout) - plain).abs().max().item() > 1e-4        # and it really is the rounded-operand result
+    # 64-cout tile class, nearest-x2 stager
+    w2 = rnd(64, 64, 3, 3, seed=5, lo=-0.2, hi=0.2)
+    x2 = rnd(1, 64, 12, 20, seed=6)
+    wp2, _k2 = pack(ops, w2.to(DEV), ops.PACK_FWD)
+    y2 = torch.zeros(1, 24, 40, 64, device=DEV)
+    ops.conv(ops.View(nhwc_buf(x2)), wp2, ops.View(y2), mode=ops.CONV_3x3_UP2)
+    close(to_nchw(y2, 0, 64), F.conv2d(F.interpolate(_bf(x2), scale_factor=2.0, mode="nearest"), _bf(w2), None, padding=1), what="bf16 up2")
+    # 4x4 s2 forward and its data-gradient, 3x3 data-gradient
+    w4 = rnd(64, 32, 4, 4, seed=7, lo=-0.2, hi=0.2)
+    x4 = rnd(2, 32, 16, 24, seed=8)
+    wp4, _k4 = pack(ops, w4.to(DEV), ops.PACK_FWD_S2D)
+    y4 = torch.zeros(2, 8, 12, 64, device=DEV)
+    ops.conv(ops.View(nhwc_buf(x4)), wp4, ops.View(y4), mode=ops.CONV_4x4_S2)
+    close(to_nchw(y4, 0, 64), F.conv2d(_bf(x4), _bf(w4), None, stride=2, padding=1), what="bf16 4x4s2")
+    g4 = rnd(2, 64, 8, 12, seed=9)
+    wd4, _k5 = pack(ops, w4.to(DEV), ops.PACK_DGRAD_S2)
+    gx4 = torch.zeros(2, 16, 24, 32, device=DEV)
+    ops.conv(ops.View(nhwc_buf(g4)), wd4, ops.View(gx4), mode=ops.DGRAD_4x4_S2)
+    close(to_nchw(gx4, 0, 32), F.conv_transpose2d(_bf(g4), _bf(w4), None, stride=2, padding=1), what="bf16 dgrad4x4s2")
+    g3 = rnd(N, Cout, H, W, seed=10)
+    wd3, _k6 = pack(ops, w.to(DEV), ops.PACK_DGRAD_3x3)
+    gx3 = torch.zeros(N, H, W, Cin, device=DEV)
+    ops.conv(ops.View(nhwc_buf(g3)), wd3, ops.View(gx3))
+    close(to_nchw(gx3, 0, Cin), F.conv_transpose2d(_bf(g3), _bf(w), None, padding=1), what="bf16 dgrad3x3")
+    # weight gradients: every workgroup tile class (32 x 32/64/96/128 pixel-split and shared-pixel, 64 x 64, strided)
+    for (mode, Nn, Hh, Ww, ci, co) in (("3x3", 2, 32, 32, 32, 32), ("3x3", 1, 32, 48, 64, 32), ("3x3", 2, 16, 16, 96, 32),
+                                       ("3x3", 1, 24, 32, 128, 32), ("3x3", 2, 16, 32, 192, 64), ("s2", 2, 16, 32, 64, 64)):
+        xx = rnd(Nn, ci, Hh, Ww, seed=11)
+        k = 3 if mode == "3x3" else 4
+        ww = rnd(co, ci, k, k, seed=12).requires_grad_(True)
+        yy = F.conv2d(_bf(xx), ww, None, padding=1) if mode == "3x3" else F.conv2d(_bf(xx), ww, None, stride=2, padding=1)
+        gg = rnd(*yy.shape, seed=13)
+        (rw,) = torch.autograd.grad(yy, ww, _bf(gg))
+        dw, db = torch.zeros(co, ci, k, k, device=DEV), torch.zeros(co, device=DEV)
+        ops.wgrad(ops.View(nhwc_buf(xx)), ops.View(nhwc_buf(gg)), dw, db, mode=ops.CONV_3x3 if mode == "3x3" else ops.CONV_4x4_S2, beta=0.0)
+        close(dw.cpu(), rw, tol=5e-5, what="bf16 wgrad %s %d->%d" % (mode, ci, co))
+        close(db.cpu(), gg.sum(dim=(0, 2, 3)), tol=5e-5, what="bf16 wgrad bias (fp32 sum of the un-rounded gradient)")
+    # dense-block chain == per-layer launches, bit for bit, in this mode too
+    nf, gc = 64, 32
+    ws = [rnd(gc, nf + k * gc, 3, 3, seed=70 + k, lo=-0.05, hi=0.05).to(DEV) for k in range(4)] + [rnd(nf, nf + 4 * gc, 3, 3, seed=74, lo=-0.05, hi=0.05).to(DEV)]
+    p = ops.WeightPacker(DEV)
+    idx = [p.add(wk, ops.PACK_FWD) for wk in ws]
+    p.run()
+    x0 = rnd(3, nf, 40, 72, seed=90).permute(0, 2, 3, 1).contiguous().to(DEV)
+
+    def run(chain):
+        buf = torch.zeros((3, 40, 72, nf + 4 * gc), device=DEV)
+        buf[..., :nf] = x0
+        out = torch.zeros((3, 40, 72, nf), device=DEV)
+        st = [dict(x=ops.View(buf, 0, nf + gc * k), wp=p.get(idx[k]), y=ops.View(buf, nf + gc * k, gc), act=ops.ACT_LRELU, slope=0.2,
+                   fresh_from=(nf + gc * (k - 1) if k else None)) for k in range(4)]
+        st.append(dict(x=ops.View(buf), wp=p.get(idx[4]), y=ops.View(out), alpha=0.2, r1=ops.View(buf, 0, nf), fresh_from=nf + 3 * gc))
+        if chain:
+            ops.conv_chain(st)
+        else:
+            for d in st:
+                ops.conv(**{kk: v for kk, v in d.items() if kk != "fresh_from"})
+        torch.cuda.synchronize()
+        return buf.cpu(), out.cpu()
+
+    rb_, ro_ = run(False)
+    gb_, go_ = run(True)
+    assert torch.equal(gb_, rb_) and torch.equal(go_, ro_) and ops.chain_error_flag() == 0
+    x1 = F.leaky_relu(F.conv2d(_bf(x0.cpu().permute(0, 3, 1, 2)), _bf(ws[0].cpu()), None, padding=1), 0.2)
+    close(rb_[..., nf:nf + gc].permute(0, 3, 1, 2), x1, what="bf16 chain stage 0")

@@ -128,6 +128,38 @@ def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
         assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
 
 
+@pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
+def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
+    """`use_amp: true` (options/sr/train_sr.yml:6): bf16 matrix-core operands, fp32 everything else.  Three G+D steps
+    against the fp32 CPU oracle: the SR image within 0.05 dB PSNR (north star), the losses within bf16's resolution
+    (2^-8 relative per operand; stated bound 3 % on the loss scalars), and the mode really is bf16 (not bit-equal to fp32)."""
+    from trainner_amd import hip, ops
+    kw = dict(nb=2, batch=2, crop=64, d_nf=16, d_type=d_type)
+    try:
+        opt, model = build_engine_model(dict(kw, amp=True), tmp_path)
+        assert model.amp and ops.MMA == hip.MMA_BF16
+        g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+        d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+        f = FX.vgg_state(77)
+        load_initial(model, g, d, f)
+        orc = O.OracleSRStep(g, d, f, arch="rrdb_net", nb=2, d_size=64, d_nf=16, d_arch="unet" if d_type == "unet" else "discriminator_vgg")
+        worst = 0.0
+        for s in (1, 2, 3):
+            LR, HR = detrand.synthetic_pair(2, 64, 40 + s)
+            ref_log = orc.step(LR, HR)
+            model.feed_data({"LR": LR, "HR": HR})
+            model.optimize_parameters(s)
+            log = model.get_current_log()
+            for k in ("pix-l1", "fea-vgg19-l1", "l_g_gan", "l_d_real", "l_d_fake"):
+                assert abs(log[k] - ref_log[k]) <= 0.03 * abs(ref_log[k]) + 1e-5, (s, k, log[k], ref_log[k])
+            got, ref = model.fake_H.detach().cpu(), orc.fake_H.detach()
+            worst = max(worst, (got - ref).abs().max().item())
+            assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
+        assert 1e-5 < worst < 2e-2, worst                  # bf16-sized differences: neither fp32-exact nor broken
+    finally:
+        ops.MMA = hip.MMA_F32                                # the precision is process-wide: restore for the other tests
+
+
 def test_validation_forward_and_self_ensemble(tmp_path):
     """SRModel.test() (no-grad forward, sr_model.py:268-276) and test_x8() (8-fold geometric self-ensemble,
     :277-315) on a non-square LR batch against the oracle's functional RRDBNet."""

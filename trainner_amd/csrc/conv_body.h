@@ -6,6 +6,18 @@
 namespace {
 
 typedef unsigned tnr_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 tnr_bf16x8 __attribute__((ext_vector_type(8)));
+
+// two fp32 quads (channels 4h .. 4h+3 of the chunk's first and second 8-channel group) -> 8 bf16, round to nearest even
+__device__ __forceinline__ tnr_bf16x8 tnr_pack_bf16(const f32x4 lo, const f32x4 hi) {
+    tnr_bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r[i] = (__bf16)lo[i];
+        r[4 + i] = (__bf16)hi[i];
+    }
+    return r;
+}
 constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | sc1 (bit 4) = system-coherent
 #ifndef TNR_COH_LOAD_AUX
 #define TNR_COH_LOAD_AUX TNR_AUX_SC0_SC1
@@ -27,6 +39,7 @@ struct ConvK {
     int th_space, tw_space;  // extent of the tile space (output dims, or gout dims for DGRAD_S2)
     int ksplit;              // split-K factor (1: none); split s writes its partial sums to y + s * split_stride
     size_t split_stride;
+    int bf;                  // operands rounded to bf16 in front of the matrix core (tnr_conv_desc.mma)
 };
 
 #ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps, 8 per body call */
@@ -63,7 +76,11 @@ __device__ unsigned long long tnr_phase[8192 * 8 * 8];
 //   wait()   called once, before the loads of input chunk `wait_chunk` are issued (-1: never).
 //            wait.drain() / wait.publish() bracket the barrier after the LDS refill of chunk 1: the chain
 //            kernel publishes the PREVIOUS stage's tile there, one MFMA phase after its stores were issued.
-template <int MODE, int TW, int NT, int MT, bool COH, class WaitFn>
+//   BF       operands rounded to bf16 on their way from LDS into the matrix core (tnr_conv_desc.mma = TNR_MMA_BF16): LDS
+//            and HBM keep fp32, so staging, layouts and the epilogue are unchanged; per tap ONE v_mfma_f32_32x32x16_bf16
+//            per 32x32 tile replaces EIGHT v_mfma_f32_32x32x2_f32 (lane-half h supplies channels 4h..4h+3 of both
+//            8-channel groups = 8 of the 16 k-values; the k-order inside an MFMA is free as long as A and B agree).
+template <int MODE, int TW, int NT, int MT, bool COH, bool BF, class WaitFn>
 __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, const int tx, const int ty, const int n,
                                                const int par, float *smem, const int wait_chunk, WaitFn &&wait,
                                                const int ksplit = 1, const int split = 0) {
@@ -252,6 +269,64 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         // would otherwise sink the reads next to their first use).  All steps are unrolled: every LDS
         // address is a per-lane base + compile-time offset.
         constexpr int KG = CK / 8, NSTEP = NTAPS * KG;
+        if constexpr (BF) {
+            // a step = one tap: 2 (MT + NT) ds_read_b128 into the raw set, converted to bf16x8 AFTER the MFMAs of the
+            // previous tap were issued (the reads had a whole MFMA group to land), MT*NT MFMAs of k = 16
+            f32x4 ra[MT][2], rb[NT][2];
+            tnr_bf16x8 ca[MT], cb_[NT];
+            auto tap_off = [&](int t, int &tapoff, int &woff) {
+                int pos_y, pos_x;
+                if (DG2) {
+                    pos_y = 1 + py - (t >> 1);
+                    pos_x = 1 + px - (t & 1);
+                } else if (S2D) {
+                    pos_y = t >> 1;
+                    pos_x = t & 1;
+                } else if (P11) {
+                    pos_y = 0;
+                    pos_x = 0;
+                } else {
+                    pos_y = t / 3;
+                    pos_x = t - pos_y * 3;
+                }
+                tapoff = (pos_y * WT + pos_x) * PST;
+                woff = t * NC * PST + boff;
+            };
+            auto fetch_raw = [&](int t) {
+                int tapoff, woff;
+                tap_off(t, tapoff, woff);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    ra[mi][0] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff);
+                    ra[mi][1] = *reinterpret_cast<const f32x4 *>(s_in + aoff[mi] + tapoff + 8);
+                }
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) {
+                    rb[nn][0] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
+                    rb[nn][1] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + 8);
+                }
+            };
+            auto convert = [&]() {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) ca[mi] = tnr_pack_bf16(ra[mi][0], ra[mi][1]);
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) cb_[nn] = tnr_pack_bf16(rb[nn][0], rb[nn][1]);
+            };
+            fetch_raw(0);
+            convert();
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                if (t + 1 < NTAPS) fetch_raw(t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn)
+                        acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi], cb_[nn], acc[mi][nn], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) convert();
+            }
+        } else {
         f32x4 fa[2][MT], fb[2][NT];
         auto fetch = [&](int s_, int set) {
             const int t = s_ / KG, kk = s_ - t * KG;
@@ -292,6 +367,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             __builtin_amdgcn_sched_barrier(0);
             mma(s_ & 1);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
 #ifdef TNR_TIMELINE
         {

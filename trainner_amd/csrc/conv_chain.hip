@@ -88,6 +88,7 @@ __device__ __forceinline__ ConvK chain_stage(int s, int *wait_chunk) {
 #endif
 }
 
+template <bool BF>
 __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int pend_tile = -1;          // wave-uniform
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
                 int txo = tx, tyo = ty, no = n;
                 asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(no));
                 TNR_STAMP_CALL(calls++);
-                conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
+                conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true, BF>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
             }
             // this tile's stage-s output is on its way to memory: published from inside the next tile body
             // (every stage has >= 2 input chunks, so the previous pending tile has been published by now)
@@ -141,9 +142,11 @@ int chain_capacity(int *out) {
             tnr_set_error("conv_chain: cannot query the device");
             return TNR_ELAUNCH;
         }
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)chain_lds()) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel, 256, chain_lds()) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds()) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel<false>, 256, chain_lds()) != hipSuccess) {
             tnr_set_error("conv_chain: cannot size the grid");
             return TNR_ELAUNCH;
         }
@@ -211,7 +214,8 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
         k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
         k.th_space = d->Ho; k.tw_space = d->Wo;
-        k.ksplit = 1; k.split_stride = 0;
+        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16;
+        TNR_REQUIRE(d->mma == d0.mma, "conv_chain: stage %d: all stages share one matrix-core precision", i);
         c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
     }
     for (int i = n; i < TNR_CHAIN_MAX; ++i) { c.st[i] = c.st[0]; c.wait_chunk[i] = -1; }
@@ -219,6 +223,9 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     const int rc = chain_capacity(&cap);
     if (rc != TNR_OK) return rc;
     const int grid = c.tiles < cap ? c.tiles : cap;
-    hipLaunchKernelGGL(conv_chain_kernel, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    if (d0.mma == TNR_MMA_BF16)
+        hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    else
+        hipLaunchKernelGGL(conv_chain_kernel<false>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     return tnr_check_launch("conv_chain");
 }

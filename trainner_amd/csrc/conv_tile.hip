@@ -22,7 +22,7 @@
 
 namespace {
 
-template <int MODE, int TW, int NT, int MT>
+template <int MODE, int TW, int NT, int MT, bool BF>
 __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     TNR_STAMP_CALL(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     }
     ConvK b = a;
     b.y = a.y + (size_t)split * a.split_stride;
-    conv_tile_body<MODE, TW, NT, MT, false>(b, cb, tx, ty, bid, par, smem, -1, NoWait(), a.ksplit, split);
+    conv_tile_body<MODE, TW, NT, MT, false, BF>(b, cb, tx, ty, bid, par, smem, -1, NoWait(), a.ksplit, split);
 }
 
 // Second launch of a split-K convolution: y = act(sum_s ws[s] + bias) * alpha, splits summed in index order.
@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const SplitRedK
     }
 }
 
-template <int MODE, int TW, int NT, int MT = 2>
-int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
+template <int MODE, int TW, int NT, int MT, bool BF>
+int launch_conv_t(const ConvK &k, int tiles, hipStream_t s) {
     constexpr int TH = 128 * MT / TW;
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
@@ -87,7 +87,7 @@ int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
     static_assert(lds <= 80 * 1024, "conv tile exceeds the 2-workgroups-per-CU LDS budget");
 #endif
     static bool attr_done = false;
-    auto fn = conv_tile_kernel<MODE, TW, NT, MT>;
+    auto fn = conv_tile_kernel<MODE, TW, NT, MT, BF>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -98,6 +98,11 @@ int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
     }
     hipLaunchKernelGGL(fn, dim3(tiles), dim3(256), lds, s, k);
     return tnr_check_launch("conv_tile");
+}
+
+template <int MODE, int TW, int NT, int MT = 2>
+int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
+    return k.bf ? launch_conv_t<MODE, TW, NT, MT, true>(k, tiles, s) : launch_conv_t<MODE, TW, NT, MT, false>(k, tiles, s);
 }
 
 template <int MODE>
@@ -188,6 +193,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     // split-K for launches that cannot fill the chip (see tnr_conv_workspace_bytes)
     const int ksplit = conv_ksplit(d, tiles);
+    k.bf = d->mma == TNR_MMA_BF16;
     k.ksplit = 1;
     k.split_stride = 0;
     SplitRedK red;

@@ -27,6 +27,7 @@ struct WgJob {
 struct WgK {
     int N, H, W, Ho, Wo;
     int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits, njobs;
+    int bf;                       // operands rounded to bf16 (tnr_wgrad_desc.mma); one setting per launch
     WgJob job[TNR_WGRAD_GROUP_MAX];
 };
 
@@ -52,7 +53,12 @@ struct WgCfg {
     static constexpr int WAVES_PER_SIMD = (J >= 9) ? 1 : 2;
 };
 
-template <int MODE, int A_T, int B_T, int THG>
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF: operands rounded to bf16 in front of the matrix core (tnr_wgrad_desc.mma = TNR_MMA_BF16).  The reduction index of
+// this GEMM is the pixel: a 16-pixel tile row is exactly the k = 16 of one v_mfma_f32_32x32x16_bf16 (lane-half h supplies
+// pixels h, 2 + h, .., 14 + h: the same 8 values it feeds to 8 fp32 k-steps), so a row costs J MFMAs instead of 8 J.
+template <int MODE, int A_T, int B_T, int THG, bool BF>
 __global__ void __launch_bounds__(256, (WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD))
 wgrad_tile_kernel(const WgK ga) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
@@ -238,6 +244,41 @@ wgrad_tile_kernel(const WgK ga) {
             int xo[J];
 #pragma unroll
             for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
+            if constexpr (BF) {
+                float ra[8], rb[8][J];
+                wg_bf16x8 ca, cb[J];
+                auto read_row = [&]() {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        ra[kk] = smem[go + 2 * kk * COB];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) rb[kk][j] = smem[xo[j] + 2 * kk * CIB];
+                    }
+                };
+                auto pack_row = [&]() {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        bsum += ra[kk];
+                        ca[kk] = (__bf16)ra[kk];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) cb[j][kk] = (__bf16)rb[kk][j];
+                    }
+                };
+                read_row();
+                pack_row();
+#pragma unroll 1
+                for (int r = 0; r < ROWS; ++r) {
+                    go += TWG * COB;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
+                    if (r + 1 < ROWS) read_row();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca, cb[j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r + 1 < ROWS) pack_row();
+                }
+            } else {
             float fa[2], fb[2][J];
             fa[0] = smem[go];
 #pragma unroll
@@ -263,6 +304,7 @@ wgrad_tile_kernel(const WgK ga) {
                 go += TWG * COB;
 #pragma unroll
                 for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
+            }
             }
         }
     }
@@ -454,15 +496,15 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     return 0;
 }
 
-template <int MODE, int A_T, int B_T, int THG>
-int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
+template <int MODE, int A_T, int B_T, int THG, bool BF>
+int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
     constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
     constexpr bool one_wg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD == 1;
     static_assert(lds <= (one_wg ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
-    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG>;
+    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -473,6 +515,11 @@ int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
     }
     hipLaunchKernelGGL(fn, dim3(k.nsplits, jobs, 1), dim3(256), lds, s, k);
     return tnr_check_launch("wgrad_tile");
+}
+
+template <int MODE, int A_T, int B_T, int THG>
+int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
+    return k.bf ? launch_wgrad_t<MODE, A_T, B_T, THG, true>(k, jobs, s) : launch_wgrad_t<MODE, A_T, B_T, THG, false>(k, jobs, s);
 }
 
 template <int MODE>
@@ -568,6 +615,8 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
     k.N = d0.N; k.H = d0.H; k.W = d0.W; k.Ho = d0.Ho; k.Wo = d0.Wo;
     k.tiles_x = p0.tiles_x; k.tiles_y = p0.tiles_y; k.tiles_total = p0.tiles_total;
     k.tiles_per_split = p0.tiles_per_split; k.nsplits = p0.splits; k.njobs = n;
+    k.bf = d0.mma == TNR_MMA_BF16;
+    for (int i = 1; i < n; ++i) TNR_REQUIRE(descs[i].mma == d0.mma, "wgrad_group: layer %d: one matrix-core precision per launch", i);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (d0.mode) {

@@ -265,9 +265,19 @@ class BaseModel:
         self.accumulations = self.virtual_batch // batch_size
 
     def setup_amp(self):
-        self.amp = False
+        """`use_amp: true` (the reference's ESRGAN recipe ships it: options/sr/train_sr.yml:6; base_model.py:736-744 wraps
+        the forward / loss code in torch.cuda.amp.autocast + GradScaler, i.e. fp16 convolutions with fp32 master weights).
+        The engine's policy: every matrix-core launch (convolutions forward / data-gradient / weight-gradient of G, D and
+        the VGG feature net) rounds its operands to bf16 on their way into v_mfma_f32_32x32x16_bf16 and accumulates in
+        fp32; activations, master weights, BatchNorm, the losses, clip + Adam stay fp32.  bf16 has fp32's exponent
+        range, so there is no loss scaling (no GradScaler state: the reference never saves it either, base_model.py:466).
+        The precision is process-wide (ops.MMA), like an autocast region around the whole step."""
+        self.amp = bool(self.opt.get("use_amp"))
         self.cast = nullcontext
-        self._reject(self.opt.get("use_amp"), "AMP (use_amp; the engine computes in fp32 on the matrix cores)")
+        self.amp_scaler = None
+        ops.MMA = hip.MMA_BF16 if self.amp else hip.MMA_F32
+        if self.amp:
+            logger.info("AMP enabled: bf16 matrix-core operands, fp32 accumulation and master weights.")
 
     def setup_cem(self):
         self.CEM = None

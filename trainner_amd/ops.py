@@ -232,6 +232,7 @@ class ConvProfile:
 
 
 PROFILE = None      # set to a ConvProfile() to time launches
+MMA = hip.MMA_F32   # matrix-core operand precision of every MFMA launch below: hip.MMA_F32 (default) | hip.MMA_BF16 (`use_amp: true`)
 
 
 def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
@@ -253,6 +254,7 @@ def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, a
     d.m_lo = m_lo
     d.m_hi = (y.C if m_hi is None else m_hi)
     d.m_slope = m_slope
+    d.mma = MMA
 
 
 IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel for <= 4-channel image layers (A/B switch)
@@ -384,6 +386,7 @@ def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta):
     d.dw, d.cin_total, d.cin_begin = dw.data_ptr(), dw.shape[1], cin_begin
     d.db = hip.ptr(db)
     d.alpha, d.beta = alpha, beta
+    d.mma = MMA
 
 
 def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
