@@ -202,6 +202,17 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* --- data-parallel collectives (RCCL over xGMI; replaces nn.DataParallel's reduce_add of replica gradients,
+ * networks.py:252-255).  One communicator per process.  Rank 0 fills a 128-byte id with tnr_dp_unique_id and shares it
+ * out of band; every rank calls tnr_dp_init(id, rank, world, &comm).  Per optimiser step: tnr_dp_allreduce_bucket(comm,
+ * bucket, count, average = 1, side_stream) for every gradient bucket as soon as its last gradient kernel is enqueued
+ * (in place; ncclAvg = mean over ranks), tnr_dp_broadcast to align replicas at start, tnr_dp_finalize at exit.
+ * librccl is dlopen()ed on first use.  Calls on one communicator must be issued in the same order on every rank.     */
+int tnr_dp_unique_id(void *id128);
+int tnr_dp_init(const void *id128, int32_t rank, int32_t world, void **comm);
+int tnr_dp_allreduce_bucket(void *comm, float *buf, int64_t count, int32_t average, void *stream);
+int tnr_dp_broadcast(void *comm, float *buf, int64_t count, int32_t root, void *stream);
+int tnr_dp_finalize(void *comm);
 /* Real-ESRGAN style degradations on fp32 NCHW images in [0, 1] (the LR synthesis the reference runs per sample with
  * OpenCV on DataLoader workers: dataops/augmentations.py:1666-1801, options/presets/resrgan_*.yaml).
  * tnr_filter2d: cv2.filter2D semantics (correlation, centred anchor, BORDER_REFLECT_101) with one 21 x 21 kernel slot per

@@ -37,7 +37,8 @@ def main():
         model.optimize_parameters(s)
         logs.append(model.get_current_log())
     w = model.netG.state_dict()["model.0.weight"].detach().cpu().flatten()[:8].tolist()
-    print("DPSELF " + json.dumps({"logs": logs, "w": w, "active": bool(model.dp.active)}))
+    print("DPSELF " + json.dumps({"logs": logs, "w": w, "active": bool(model.dp.active), "abi": model.dp._abi is not None}))
+    model.dp.finalize()
 
 
 if __name__ == "__main__":

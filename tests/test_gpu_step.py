@@ -265,3 +265,8 @@ def test_dp_collectives_single_rank():
     assert plain["active"] is False and dp["active"] is True
     assert plain["logs"] == dp["logs"], (plain["logs"], dp["logs"])
     assert plain["w"] == dp["w"]
+    # the same through the library's own RCCL entry points (tnr_dp_init / tnr_dp_allreduce_bucket / tnr_dp_broadcast)
+    abi = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(29950 + os.getpid() % 40), worker], dict(env2, TNR_DP_BACKEND="abi"))
+    assert abi["active"] is True and abi.get("abi") is True
+    assert plain["logs"] == abi["logs"] and plain["w"] == abi["w"]

@@ -11,6 +11,9 @@ traffic is:
      the reference's global-batch value.
 `torch.distributed` is the communicator plumbing (backend 'nccl' is RCCL on ROCm; 'gloo' on CPU for
 the world_size-2 tests).  With world_size 1 every method is a no-op on the same code path.
+TNR_DP_BACKEND=abi routes the collectives through the library's own RCCL entry points instead (tnr_dp_init /
+tnr_dp_allreduce_bucket / tnr_dp_broadcast, include/trainner_hip.h) -- the path a C / C++ consumer of the C ABI uses;
+torch.distributed then only carries the 128-byte communicator id from rank 0 to the others.
 """
 import os
 
@@ -30,14 +33,48 @@ class DPGroup:
         self.active = self.world_size > 1 or (dist.is_initialized() and os.environ.get("TNR_DP_SELFTEST") == "1")
         self._side = None
         self._pending = []
+        self._abi = None                         # (lib, communicator handle) when TNR_DP_BACKEND=abi
         if self.active:
             from . import ops
             ops.COLLECTIVES_IN_FLIGHT = True     # see ops.conv_chain
+            if os.environ.get("TNR_DP_BACKEND", "torch") == "abi" and torch.cuda.is_available():
+                self._init_abi()
+
+    def _init_abi(self):
+        import ctypes
+        from . import hip
+        lib = hip.load()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            hip.check(lib.tnr_dp_unique_id(uid.data_ptr()), "dp_unique_id")
+        uid_d = uid.to(dev)
+        dist.broadcast(uid_d, src=0, group=self.group)           # the id travels out of band (here: the torch group)
+        uid = uid_d.cpu()
+        comm = ctypes.c_void_p()
+        hip.check(lib.tnr_dp_init(uid.data_ptr(), self.rank, self.world_size, ctypes.byref(comm)), "dp_init")
+        self._abi = (lib, comm)
+
+    def finalize(self):
+        if self._abi is not None:
+            lib, comm = self._abi
+            torch.cuda.synchronize()
+            lib.tnr_dp_finalize(comm)
+            self._abi = None
 
     # ---------------------------------------------------------------- small forward exchanges
+    def _abi_ok(self, t):
+        return self._abi is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+
     def all_reduce_sum(self, t):
-        if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.active:
+            return
+        if self._abi_ok(t):
+            from . import hip
+            lib, comm = self._abi
+            hip.check(lib.tnr_dp_allreduce_bucket(comm, t.data_ptr(), t.numel(), 0, torch.cuda.current_stream().cuda_stream), "dp_allreduce")
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def mean_scalar(self, t):
         """Global-batch mean of a per-rank mean (equal shards): what nn.DataParallel's gather-then-loss reports."""
@@ -55,7 +92,12 @@ class DPGroup:
         if not self.active:
             return
         for t in tensors:
-            dist.broadcast(t, src=0, group=self.group)
+            if self._abi_ok(t):
+                from . import hip
+                lib, comm = self._abi
+                hip.check(lib.tnr_dp_broadcast(comm, t.data_ptr(), t.numel(), 0, torch.cuda.current_stream().cuda_stream), "dp_broadcast")
+            else:
+                dist.broadcast(t, src=0, group=self.group)
 
     # ---------------------------------------------------------------- gradient buckets
     def _stream(self, device):
@@ -80,7 +122,12 @@ class DPGroup:
         ev.record(torch.cuda.current_stream(flat_grad.device))
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)     # ncclAvg: mean in the collective
+            if self._abi_ok(seg):
+                from . import hip
+                lib, comm = self._abi
+                hip.check(lib.tnr_dp_allreduce_bucket(comm, seg.data_ptr(), seg.numel(), 1, side.cuda_stream), "dp_allreduce_bucket")
+            else:
+                dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)     # ncclAvg: mean in the collective
             done = torch.cuda.Event()
             done.record(side)
         self._pending.append(done)

@@ -89,6 +89,11 @@ _SIGS = {
     "tnr_space_to_depth_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
     "tnr_maxpool2_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
     "tnr_maxpool2_bwd": (c_i, [CView, CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_dp_unique_id": (c_i, [c_p]),
+    "tnr_dp_init": (c_i, [c_p, c_i, c_i, C.POINTER(c_p)]),
+    "tnr_dp_allreduce_bucket": (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    "tnr_dp_broadcast": (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    "tnr_dp_finalize": (c_i, [c_p]),
     "tnr_filter2d": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "tnr_resize": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_noise_gaussian": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, C.c_uint64, c_i, c_p]),
