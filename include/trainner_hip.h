@@ -202,6 +202,31 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 #define TNR_WGRAD_GROUP_MAX 8
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
+/* --- image-to-image family (Pix2Pix / CycleGAN: ResnetGenerator ResNet_arch.py:11-90, NLayerDiscriminator
+ * discriminators.py:472-579).  Generic convolution on the vector ALUs for the layers outside the matrix-core geometries
+ * (7x7 reflection-padded first / last convolutions, the PatchGAN's 4x4 stride-1 layers): any square kernel k, stride,
+ * zero (reflect = 0) or nn.ReflectionPad2d (reflect = 1, stride 1) padding; OIHW weights as stored in the state_dict.
+ *   fwd:   y = act(conv(x, w) + bias);  dgrad: gx = conv_backward_data(g, w) (reflection folded back);
+ *   wgrad: dw = beta dw + alpha sum g (x) x, db likewise (db may be NULL); two-stage fp64 reduction in a fixed order,
+ *          ws: tnr_gconv_wgrad_workspace_bytes(Cout, Cin, k).
+ * tnr_pad2d / tnr_unpad2d: materialise a zero (mode 0) or reflection (mode 1) border of `pad` pixels / crop it (mode 0) or
+ * apply the adjoint of the reflection padding (mode 1) -- the residual blocks' reflection-padded 3x3 convolutions run on
+ * the MFMA 3x3 kernel over the padded tensor.  tnr_tanh_*: the generator's output activation.  tnr_gan_loss: GANLoss
+ * against a constant label (modules/loss.py:61-137): type 0 vanilla (BCE with logits), 1 lsgan (MSE), mean reduction;
+ * out[0] = loss, grad = d loss / d pred (may be NULL).                                                              */
+int tnr_gconv_fwd(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w, const float *bias, tnr_view y, int32_t Ho,
+                  int32_t Wo, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t reflect, int32_t act, float slope, void *stream);
+int tnr_gconv_dgrad(tnr_view g, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w, tnr_view gx, int32_t Ho, int32_t Wo,
+                    int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t reflect, void *stream);
+int64_t tnr_gconv_wgrad_workspace_bytes(int32_t Cout, int32_t Cin, int32_t k);
+int tnr_gconv_wgrad(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, tnr_view g, int32_t Ho, int32_t Wo, int32_t Cout, int32_t k,
+                    int32_t stride, int32_t pad, int32_t reflect, float *dw, float *db, float alpha, float beta, double *ws,
+                    int64_t ws_bytes, void *stream);
+int tnr_pad2d(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
+int tnr_unpad2d(tnr_view xp, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
+int tnr_tanh_fwd(const float *x, float *y, int64_t n, void *stream);
+int tnr_tanh_bwd(const float *g, const float *y, float *gx, int64_t n, void *stream);
+int tnr_gan_loss(const float *pred, int64_t n, int32_t type, float target, float *out, float *grad, void *stream);
 /* --- data-parallel collectives (RCCL over xGMI; replaces nn.DataParallel's reduce_add of replica gradients,
  * networks.py:252-255).  One communicator per process.  Rank 0 fills a 128-byte id with tnr_dp_unique_id and shares it
  * out of band; every rank calls tnr_dp_init(id, rank, world, &comm).  Per optimiser step: tnr_dp_allreduce_bucket(comm,

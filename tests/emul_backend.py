@@ -218,6 +218,67 @@ def mask_copy(dst, src, y, mslope=0.2):
     dst.dense().copy_(src.dense() * _mask(y.dense(), mslope))
 
 
+def _gpad(t, pad, reflect):
+    return F.pad(t, (pad,) * 4, mode="reflect") if (reflect and pad) else F.pad(t, (pad,) * 4)
+
+
+def gconv_fwd(x, w, y, bias=None, stride=1, pad=0, reflect=False, act=ops.ACT_NONE, slope=0.2):
+    o = F.conv2d(_gpad(_nchw(x)[:, :w.shape[1]], pad, reflect), w.detach(), None if bias is None else bias.detach(), stride=stride)
+    o = F.leaky_relu(o, slope) if act == ops.ACT_LRELU else (F.relu(o) if act == ops.ACT_RELU else o)
+    y.dense().copy_(_fit(o, y.C).permute(0, 2, 3, 1))
+
+
+def gconv_dgrad(g, w, gx, stride=1, pad=0, reflect=False):
+    with torch.enable_grad():
+        xin = torch.zeros(gx.N, w.shape[1], gx.H, gx.W, requires_grad=True)
+        (gr,) = torch.autograd.grad(F.conv2d(_gpad(xin, pad, reflect), w.detach(), None, stride=stride), xin, _nchw(g)[:, :w.shape[0]])
+    gx.dense().copy_(_fit(gr, gx.C).permute(0, 2, 3, 1))
+
+
+def gconv_wgrad(x, g, dw, db=None, stride=1, pad=0, reflect=False, alpha=1.0, beta=1.0):
+    gin = _nchw(g)[:, :dw.shape[0]]
+    with torch.enable_grad():
+        w0 = torch.zeros_like(dw, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(_gpad(_nchw(x)[:, :dw.shape[1]], pad, reflect), w0, None, stride=stride), w0, gin)
+    dw.copy_(beta * dw + alpha * gw)
+    if db is not None:
+        db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
+
+
+def pad2d(x, y, pad, reflect):
+    y.dense().copy_(_gpad(_nchw(x), pad, reflect).permute(0, 2, 3, 1))
+
+
+def unpad2d(xp, y, pad, fold):
+    t = _nchw(xp)
+    if not fold:
+        y.dense().copy_(t[:, :, pad:pad + y.H, pad:pad + y.W].permute(0, 2, 3, 1))
+        return
+    with torch.enable_grad():
+        xin = torch.zeros(y.N, y.C, y.H, y.W, requires_grad=True)
+        (gr,) = torch.autograd.grad(_gpad(xin, pad, True), xin, t)
+    y.dense().copy_(gr.permute(0, 2, 3, 1))
+
+
+def tanh_fwd(x, y):
+    y.copy_(torch.tanh(x))
+
+
+def tanh_bwd(g, y, gx):
+    gx.copy_(g * (1 - y * y))
+
+
+def gan_loss(pred, kind, target, out, grad=None):
+    p = pred.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        t = torch.full_like(p, float(target))
+        l = F.binary_cross_entropy_with_logits(p, t) if kind == 0 else F.mse_loss(p, t)
+        (g,) = torch.autograd.grad(l, p)
+    out.reshape(-1)[0] = l.detach()
+    if grad is not None:
+        grad.copy_(g)
+
+
 def axpby(dst, src, a=1.0, b=1.0):
     d = dst.dense()
     d.copy_(a * src.dense() + (b * d if b != 0 else 0))
@@ -348,7 +409,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
 
 
-_NAMES = ["bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

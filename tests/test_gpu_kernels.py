@@ -751,3 +751,75 @@ def test_bf16_operand_mode(monkeypatch):
     assert torch.equal(gb_, rb_) and torch.equal(go_, ro_) and ops.chain_error_flag() == 0
     x1 = F.leaky_relu(F.conv2d(_bf(x0.cpu().permute(0, 3, 1, 2)), _bf(ws[0].cpu()), None, padding=1), 0.2)
     close(rb_[..., nf:nf + gc].permute(0, 3, 1, 2), x1, what="bf16 chain stage 0")
+
+
+@pytest.mark.parametrize("case", [(7, 1, 3, True, 3, 64, 2, 20, 28), (7, 1, 3, True, 64, 3, 1, 16, 24), (4, 1, 1, False, 32, 48, 2, 9, 13),
+                                  (4, 1, 1, False, 64, 1, 1, 12, 12), (3, 2, 1, False, 8, 12, 2, 10, 14), (3, 1, 1, True, 16, 8, 1, 7, 9)])
+def test_generic_conv_family(case):
+    """tnr_gconv_fwd / _dgrad / _wgrad (vector ALUs; the 7x7 reflection-padded and 4x4 stride-1 layers of the image-to-image
+    networks) against F.conv2d + autograd, zero and reflection padding, inside channel windows of wider buffers."""
+    ops = _ops()
+    k, stride, pad, reflect, Cin, Cout, N, H, W = case
+    x = rnd(N, Cin, H, W, seed=401)
+    w = rnd(Cout, Cin, k, k, seed=402, lo=-0.3, hi=0.3).requires_grad_(True)
+    b = rnd(Cout, seed=403)
+    xr = x.clone().requires_grad_(True)
+    xp = F.pad(xr, (pad,) * 4, mode="reflect") if reflect else F.pad(xr, (pad,) * 4)
+    ref = F.leaky_relu(F.conv2d(xp, w, b, stride=stride), 0.2)
+    Ho, Wo = ref.shape[2:]
+    g = rnd(N, Cout, Ho, Wo, seed=404)
+    pre = F.conv2d(xp, w, b, stride=stride)
+    gx_ref, gw_ref = torch.autograd.grad(pre, (xr, w), g)
+    ci4, co4 = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xb = nhwc_buf(F.pad(x, (0, 0, 0, 0, 0, ci4 - Cin)), ci4 + 4, 4, fill=0.0)
+    yb = torch.full((N, Ho, Wo, co4), 5.0, device=DEV)
+    wd, bd = w.detach().to(DEV), b.to(DEV)
+    ops.gconv_fwd(ops.View(xb, 4, ci4), wd, ops.View(yb, 0, co4), bias=bd, stride=stride, pad=pad, reflect=reflect, act=ops.ACT_LRELU, slope=0.2)
+    close(to_nchw(yb, 0, Cout), ref.detach(), what="gconv fwd")
+    gb = nhwc_buf(F.pad(g, (0, 0, 0, 0, 0, co4 - Cout)), fill=0.0)
+    gxb = torch.full((N, H, W, ci4), 5.0, device=DEV)
+    ops.gconv_dgrad(ops.View(gb), wd, ops.View(gxb), stride=stride, pad=pad, reflect=reflect)
+    close(to_nchw(gxb, 0, Cin), gx_ref, what="gconv dgrad")
+    dw0, db0 = rnd(Cout, Cin, k, k, seed=405), rnd(Cout, seed=406)
+    dw, db = dw0.to(DEV), db0.to(DEV)
+    ops.gconv_wgrad(ops.View(xb, 4, ci4), ops.View(gb), dw, db, stride=stride, pad=pad, reflect=reflect, alpha=0.5, beta=1.0)
+    close(dw.cpu(), dw0 + 0.5 * gw_ref, tol=5e-5, what="gconv wgrad")
+    close(db.cpu(), db0 + 0.5 * g.sum(dim=(0, 2, 3)), tol=5e-5, what="gconv bias grad")
+
+
+def test_pad_tanh_ganloss_kernels():
+    ops = _ops()
+    x = rnd(2, 8, 9, 11, seed=411)
+    xb = nhwc_buf(x)
+    for refl_ in (True, False):
+        yb = torch.zeros(2, 9 + 4, 11 + 4, 8, device=DEV)
+        ops.pad2d(ops.View(xb), ops.View(yb), 2, refl_)
+        want = F.pad(x, (2,) * 4, mode="reflect") if refl_ else F.pad(x, (2,) * 4)
+        assert torch.equal(to_nchw(yb, 0, 8), want)
+        back = torch.zeros(2, 9, 11, 8, device=DEV)
+        ops.unpad2d(ops.View(yb), ops.View(back), 2, False)
+        assert torch.equal(to_nchw(back, 0, 8), x)
+    gp = rnd(2, 8, 13, 15, seed=412)
+    xr = x.clone().requires_grad_(True)
+    (fold_ref,) = torch.autograd.grad(F.pad(xr, (2,) * 4, mode="reflect"), xr, gp)
+    fb = torch.zeros(2, 9, 11, 8, device=DEV)
+    ops.unpad2d(ops.View(nhwc_buf(gp)), ops.View(fb), 2, True)
+    close(to_nchw(fb, 0, 8), fold_ref, tol=1e-6, what="reflection fold")
+    t = rnd(3, 5, 7, seed=413, lo=-3, hi=3).to(DEV)
+    y = torch.empty_like(t)
+    ops.tanh_fwd(t, y)
+    close(y.cpu(), torch.tanh(t.cpu()), tol=1e-6, what="tanh")
+    g = rnd(3, 5, 7, seed=414).to(DEV)
+    gx = torch.empty_like(t)
+    ops.tanh_bwd(g, y, gx)
+    close(gx.cpu(), g.cpu() * (1 - torch.tanh(t.cpu()) ** 2), tol=1e-6, what="tanh bwd")
+    p = rnd(2, 1, 30, 30, seed=415, lo=-4, hi=4)
+    for kind, target in ((0, 1.0), (0, 0.0), (1, 1.0), (1, 0.0)):
+        pr = p.clone().requires_grad_(True)
+        tt = torch.full_like(pr, target)
+        l = F.binary_cross_entropy_with_logits(pr, tt) if kind == 0 else F.mse_loss(pr, tt)
+        (gr,) = torch.autograd.grad(l, pr)
+        out, grad = torch.zeros(1, device=DEV), torch.zeros_like(p, device=DEV)
+        ops.gan_loss(p.to(DEV), kind, target, out, grad)
+        assert abs(float(out) - float(l)) < 1e-6 * max(1.0, abs(float(l)))
+        close(grad.cpu(), gr, tol=1e-6, what="gan loss grad")

@@ -89,6 +89,15 @@ _SIGS = {
     "tnr_space_to_depth_bwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, CView, c_f, c_p]),
     "tnr_maxpool2_fwd": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_p]),
     "tnr_maxpool2_bwd": (c_i, [CView, CView, CView, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_gconv_fwd": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, c_p, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "tnr_gconv_dgrad": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_gconv_wgrad_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "tnr_gconv_wgrad": (c_i, [CView, c_i, c_i, c_i, c_i, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_l, c_p]),
+    "tnr_pad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_unpad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),
+    "tnr_tanh_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    "tnr_gan_loss": (c_i, [c_p, c_l, c_i, c_f, c_p, c_p, c_p]),
     "tnr_dp_unique_id": (c_i, [c_p]),
     "tnr_dp_init": (c_i, [c_p, c_i, c_i, C.POINTER(c_p)]),
     "tnr_dp_allreduce_bucket": (c_i, [c_p, c_p, c_l, c_i, c_p]),

@@ -494,6 +494,53 @@ def mask_copy(dst, src, y, mslope=0.2):
     hip.check(hip.load().tnr_mask_copy(dst.c(), src.c(), y.c(), dst.pixels, dst.C, mslope, hip.stream()), "mask_copy")
 
 
+# ----------------------------------------------------------------------------------------------
+# image-to-image family: generic convolution (vector ALUs), padding helpers, tanh, GAN loss
+# ----------------------------------------------------------------------------------------------
+def gconv_fwd(x, w, y, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, slope=0.2):
+    """y = act(conv(x, w) + bias): any square kernel / stride, zero or reflection padding (tnr_gconv_fwd); w OIHW."""
+    Cout, Cin, k, _ = w.shape
+    hip.check(hip.load().tnr_gconv_fwd(x.c(), x.N, x.H, x.W, Cin, w.data_ptr(), hip.ptr(bias), y.c(), y.H, y.W, Cout, k, stride, pad,
+                                       int(reflect), act, slope, hip.stream()), "gconv_fwd")
+
+
+def gconv_dgrad(g, w, gx, stride=1, pad=0, reflect=False):
+    Cout, Cin, k, _ = w.shape
+    hip.check(hip.load().tnr_gconv_dgrad(g.c(), gx.N, gx.H, gx.W, Cin, w.data_ptr(), gx.c(), g.H, g.W, Cout, k, stride, pad, int(reflect),
+                                         hip.stream()), "gconv_dgrad")
+
+
+def gconv_wgrad(x, g, dw, db=None, stride=1, pad=0, reflect=False, alpha=1.0, beta=1.0):
+    Cout, Cin, k, _ = dw.shape
+    lib = hip.load()
+    ws = WS.get("gconv_wgrad@%x" % hip.stream(), lib.tnr_gconv_wgrad_workspace_bytes(Cout, Cin, k), x.buf.device)
+    hip.check(lib.tnr_gconv_wgrad(x.c(), x.N, x.H, x.W, Cin, g.c(), g.H, g.W, Cout, k, stride, pad, int(reflect), dw.data_ptr(), hip.ptr(db),
+                                  alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "gconv_wgrad")
+
+
+def pad2d(x, y, pad, reflect):
+    """y [N, H + 2 pad, W + 2 pad, C] = x with a zero (reflect False) or reflected border."""
+    hip.check(hip.load().tnr_pad2d(x.c(), y.c(), x.N, x.H, x.W, x.C, pad, int(reflect), hip.stream()), "pad2d")
+
+
+def unpad2d(xp, y, pad, fold):
+    """y [N,H,W,C] = centre crop of xp (fold False) or the adjoint of the reflection padding (fold True)."""
+    hip.check(hip.load().tnr_unpad2d(xp.c(), y.c(), y.N, y.H, y.W, y.C, pad, int(fold), hip.stream()), "unpad2d")
+
+
+def tanh_fwd(x, y):
+    hip.check(hip.load().tnr_tanh_fwd(x.data_ptr(), y.data_ptr(), x.numel(), hip.stream()), "tanh_fwd")
+
+
+def tanh_bwd(g, y, gx):
+    hip.check(hip.load().tnr_tanh_bwd(g.data_ptr(), y.data_ptr(), gx.data_ptr(), g.numel(), hip.stream()), "tanh_bwd")
+
+
+def gan_loss(pred, kind, target, out, grad=None):
+    """GANLoss against a constant label: kind 0 vanilla (BCE with logits), 1 lsgan (MSE); out[0] = mean loss."""
+    hip.check(hip.load().tnr_gan_loss(pred.data_ptr(), pred.numel(), kind, float(target), out.data_ptr(), hip.ptr(grad), hip.stream()), "gan_loss")
+
+
 def axpby(dst, src, a=1.0, b=1.0):
     """dst = a*src + b*dst"""
     hip.check(hip.load().tnr_axpby(dst.c(), src.c(), dst.pixels, dst.C, a, b, hip.stream()), "axpby")
