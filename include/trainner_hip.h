@@ -222,6 +222,9 @@ int64_t tnr_gconv_wgrad_workspace_bytes(int32_t Cout, int32_t Cin, int32_t k);
 int tnr_gconv_wgrad(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, tnr_view g, int32_t Ho, int32_t Wo, int32_t Cout, int32_t k,
                     int32_t stride, int32_t pad, int32_t reflect, float *dw, float *db, float alpha, float beta, double *ws,
                     int64_t ws_bytes, void *stream);
+/* db = beta db + alpha sum_pixels g[p][c] (bias gradient of a layer whose weight gradient runs on another kernel);
+ * ws: >= 64 * C doubles.                                                                                          */
+int tnr_bias_grad(tnr_view g, int64_t pixels, int32_t C, float *db, float alpha, float beta, double *ws, int64_t ws_bytes, void *stream);
 int tnr_pad2d(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
 int tnr_unpad2d(tnr_view xp, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
 int tnr_tanh_fwd(const float *x, float *y, int64_t n, void *stream);

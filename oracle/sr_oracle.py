@@ -153,6 +153,52 @@ def unet_disc_forward(x, sd, skip_connection=True):
     return c(out, 9)
 
 
+def _norm2d(x, sd, key, norm, training=True):
+    """BatchNorm2d (train mode: batch statistics, running statistics updated in place) or InstanceNorm2d (no affine)."""
+    if norm == "instance":
+        return F.instance_norm(x, eps=1e-5)
+    out = F.batch_norm(x, sd[key + ".running_mean"], sd[key + ".running_var"], sd[key + ".weight"], sd[key + ".bias"], training, 0.1, 1e-5)
+    if training:
+        sd[key + ".num_batches_tracked"] += 1
+    return out
+
+
+def resnet_generator_forward(x, sd, n_blocks, norm="instance"):
+    """ResnetGenerator.forward (models/modules/architectures/ResNet_arch.py:11-149): reflect-pad 7x7 conv + norm + ReLU; two
+    3x3 s2 convs + norm + ReLU; n_blocks residual blocks (reflect-pad 3x3 conv + norm + ReLU + reflect-pad 3x3 conv + norm, + x);
+    two ConvTranspose2d(k3, s2, p1, op1) + norm + ReLU; reflect-pad 7x7 conv + tanh.  Keys `model.<i>.*` as in the reference."""
+    def conv(t, i, stride=1, pad=0):
+        return F.conv2d(t, sd["model.%d.weight" % i], sd.get("model.%d.bias" % i), stride=stride, padding=pad)
+
+    h = F.relu(_norm2d(conv(F.pad(x, (3,) * 4, mode="reflect"), 1), sd, "model.2", norm))
+    h = F.relu(_norm2d(conv(h, 4, 2, 1), sd, "model.5", norm))
+    h = F.relu(_norm2d(conv(h, 7, 2, 1), sd, "model.8", norm))
+    for b in range(n_blocks):
+        p = "model.%d.conv_block" % (10 + b)
+        t = F.conv2d(F.pad(h, (1,) * 4, mode="reflect"), sd[p + ".1.weight"], sd.get(p + ".1.bias"))
+        t = F.relu(_norm2d(t, sd, p + ".2", norm))
+        t = F.conv2d(F.pad(t, (1,) * 4, mode="reflect"), sd[p + ".5.weight"], sd.get(p + ".5.bias"))
+        h = h + _norm2d(t, sd, p + ".6", norm)
+    i = 10 + n_blocks
+    for j in (i, i + 3):
+        h = F.conv_transpose2d(h, sd["model.%d.weight" % j], sd.get("model.%d.bias" % j), stride=2, padding=1, output_padding=1)
+        h = F.relu(_norm2d(h, sd, "model.%d" % (j + 1), norm))
+    return torch.tanh(conv(F.pad(h, (3,) * 4, mode="reflect"), i + 7))
+
+
+def patchgan_forward(x, sd, n_layers=3):
+    """NLayerDiscriminator.forward (discriminators.py:472-579), default configuration: conv4 s2 + LReLU; (n_layers - 1) x
+    [conv4 s2 + BatchNorm + LReLU]; conv4 s1 + BatchNorm + LReLU; conv4 s1 -> 1 channel."""
+    h = F.leaky_relu(F.conv2d(x, sd["model.0.weight"], sd["model.0.bias"], stride=2, padding=1), LRELU)
+    i = 2
+    for n in range(1, n_layers + 1):
+        stride = 2 if n < n_layers else 1
+        h = F.conv2d(h, sd["model.%d.weight" % i], None, stride=stride, padding=1)
+        h = F.leaky_relu(_norm2d(h, sd, "model.%d" % (i + 1), "batch"), LRELU)
+        i += 3
+    return F.conv2d(h, sd["model.%d.weight" % i], sd["model.%d.bias" % i], stride=1, padding=1)
+
+
 # --------------------------------------------------------------------------------------
 # VGG19 feature extractor  (models/modules/architectures/perceptual.py:103-214)
 # --------------------------------------------------------------------------------------

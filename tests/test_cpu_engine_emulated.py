@@ -37,6 +37,15 @@ def test_unet_discriminator_schedule(skip):
     TN.test_unet_discriminator(16, skip)
 
 
+@pytest.mark.parametrize("norm,nb", [("instance", 2), ("batch", 1)])
+def test_resnet_generator_schedule(norm, nb):
+    TN.test_resnet_generator(norm, nb)
+
+
+def test_patchgan_schedule():
+    TN.test_patchgan_discriminator(6, 64)
+
+
 def test_vgg_schedule():
     TN.test_vgg19_features()
 

@@ -206,6 +206,65 @@ def test_unet_discriminator(nf, skip):
     assert rel_err(xd2.grad, xg64.grad) < 2e-4
 
 
+@pytest.mark.parametrize("norm,nb", [("instance", 2), ("batch", 1)])
+def test_resnet_generator(norm, nb):
+    """ResnetGenerator (CycleGAN / Pix2Pix G, ResNet_arch.py:11-149): output, input gradient and every parameter gradient
+    against the oracle (reflection padding, stride-2 and transposed convolutions, Instance / BatchNorm, tanh)."""
+    from trainner_amd.models.modules.architectures.ResNet_arch import ResnetGenerator
+    net = ResnetGenerator(3, 3, ngf=16, norm_type=norm, n_blocks=nb)
+    sd = seeded(net, 31, gain=0.5)
+    net = net.to(DEV).train()
+    x = detrand.uniform((2, 3, 32, 40), 32, -1.0, 1.0)
+    gout = detrand.uniform((2, 3, 32, 40), 33, -1.0, 1.0)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = net(xd)
+    out.backward(gout.to(DEV))
+    osd = oracle_params(sd)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = O.resnet_generator_forward(xr, osd, nb, norm)
+    ref.backward(gout)
+    assert out.shape == ref.shape and rel_err(out, ref) < 5e-5
+    # ReLU gates: bounded like the other ungated comparisons (robust_err), tight on the median
+    l2, med = robust_err(xd.grad, xr.grad)
+    assert l2 < 2e-2 and med < 2e-5, (l2, med)
+    last_bias = "model.%d.bias" % (17 + nb)
+    for k, p in net.named_parameters():
+        if k.endswith(".bias") and k != last_bias and norm == "instance":
+            continue          # a conv bias in front of a normalisation has an exactly-zero true gradient: noise on both sides
+        l2, med = robust_err(p.grad, osd[k].grad)
+        assert l2 < 2e-2 and med < 5e-5, (k, l2, med)
+    if norm == "batch":
+        new = net.state_dict()
+        for k in sd:
+            if "running_" in k:
+                assert rel_err(new[k], osd[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("in_nc,size", [(6, 64), (3, 48)])
+def test_patchgan_discriminator(in_nc, size):
+    """NLayerDiscriminator (PatchGAN, discriminators.py:472-579) with 6 input channels (conditional pix2pix pair) and 3."""
+    from trainner_amd.models.modules.architectures.discriminators import NLayerDiscriminator
+    net = NLayerDiscriminator(in_nc, ndf=16, n_layers=3)
+    sd = seeded(net, 41, gain=0.5)
+    net = net.to(DEV).train()
+    x = detrand.uniform((2, in_nc, size, size), 42, -1.0, 1.0)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    out = net(xd)
+    osd = oracle_params(sd)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = O.patchgan_forward(xr, osd, 3)
+    assert out.shape == ref.shape == (2, 1, size // 8 - 2, size // 8 - 2)
+    gout = detrand.uniform(tuple(ref.shape), 43, -1.0, 1.0)
+    out.backward(gout.to(DEV))
+    ref.backward(gout)
+    assert rel_err(out, ref) < 5e-5
+    l2, med = robust_err(xd.grad, xr.grad)
+    assert l2 < 2e-2 and med < 2e-5, (l2, med)
+    for k, p in net.named_parameters():
+        l2, med = robust_err(p.grad, osd[k].grad)
+        assert l2 < 2e-2 and med < 1e-4, (k, l2, med)
+
+
 def test_vgg19_features():
     from trainner_amd.models.modules.architectures.perceptual import FeatureExtractor
     from oracle import fixtures as FX

@@ -317,6 +317,22 @@ extern "C" int tnr_gconv_wgrad(tnr_view x, int32_t N, int32_t H, int32_t W, int3
     return tnr_check_launch("gconv_wgrad");
 }
 
+// db = beta db + alpha * sum over pixels of g[p][c]: the bias gradient of layers whose weight gradient runs elsewhere
+// (transposed convolutions on the MFMA kernels); same two-stage fixed-order reduction (ws: >= 64 * C doubles)
+extern "C" int tnr_bias_grad(tnr_view g, int64_t pixels, int32_t C, float *db, float alpha, float beta, double *ws, int64_t ws_bytes,
+                             void *stream) {
+    TNR_REQUIRE(v_ok(g) && db && ws && pixels >= 1 && C >= 1 && ws_bytes >= (int64_t)GW_SPLITS * C * (int64_t)sizeof(double),
+                "bias_grad: bad arguments");
+    GcK a = {};
+    a.y = g.ptr; a.y_ct = g.ctot; a.y_co = g.coff;
+    a.N = 1; a.Ho = 1; a.Wo = (int)pixels; a.H = 1; a.W = (int)pixels; a.Cin = 0; a.Cout = C; a.k = 1; a.stride = 1;
+    TNR_REQUIRE(pixels < (1LL << 31), "bias_grad: too many pixels");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gconv_wgrad_partial_kernel, dim3(g1d(C), GW_SPLITS), dim3(256), 0, s, a, ws, ws);
+    hipLaunchKernelGGL(gconv_wgrad_final_kernel, dim3(g1d(C)), dim3(256), 0, s, ws, ws, (int64_t)0, C, db, db, alpha, beta);
+    return tnr_check_launch("bias_grad");
+}
+
 extern "C" int tnr_pad2d(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream) {
     TNR_REQUIRE(v_ok(x) && v_ok(y) && (C % 4) == 0 && (x.ctot % 4) == 0 && (x.coff % 4) == 0 && (y.ctot % 4) == 0 && (y.coff % 4) == 0 &&
                     pad >= 0 && (mode == 0 || (pad < H && pad < W)),

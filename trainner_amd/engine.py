@@ -142,6 +142,10 @@ class HipNet(torch.nn.Module):
     def flat_params(self):
         return self._flat.ensure()
 
+    def _refresh_derived(self):
+        """Hook: tensors derived from the parameters that the packer reads (zero-extended taps, ...) are rebuilt here,
+        right before the weights are re-packed."""
+
     def _prepare(self, x):
         hip.require_device(x)
         if x.dtype != torch.float32:
@@ -160,6 +164,7 @@ class HipNet(torch.nn.Module):
         # (fp.flat._version also moves on any in-place torch write through a parameter view)
         key = (fp.version, fp.flat._version)
         if self._packed_version != key:
+            self._refresh_derived()
             self._packer.run()
             self._dense_packer.run()
             self._packed_version = key

@@ -93,6 +93,7 @@ _SIGS = {
     "tnr_gconv_dgrad": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_gconv_wgrad_workspace_bytes": (c_l, [c_i, c_i, c_i]),
     "tnr_gconv_wgrad": (c_i, [CView, c_i, c_i, c_i, c_i, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_l, c_p]),
+    "tnr_bias_grad": (c_i, [CView, c_l, c_i, c_p, c_f, c_f, c_p, c_l, c_p]),
     "tnr_pad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_unpad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),

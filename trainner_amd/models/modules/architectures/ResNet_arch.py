@@ -1,0 +1,318 @@
+"""ResnetGenerator (CycleGAN / Pix2Pix generator) on the MI355X engine.
+
+Constructor, `state_dict` keys and arithmetic follow codes/models/modules/architectures/ResNet_arch.py:11-149:
+ReflectionPad(3) + conv7x7(in -> ngf) + norm + ReLU; two conv3x3 stride 2 + norm + ReLU; n_blocks x [x + (ReflectionPad(1) +
+conv3x3 + norm + ReLU + ReflectionPad(1) + conv3x3 + norm)]; two ConvTranspose2d(k3, s2, p1, output_padding 1) + norm + ReLU;
+ReflectionPad(3) + conv7x7(ngf -> out) + Tanh.  norm = InstanceNorm2d (no affine, no running statistics; convolutions
+then carry a bias) or BatchNorm2d (train mode).  `self.model` is an nn.Sequential with the reference's child indices.
+
+Kernel mapping (all fp32 NHWC):
+  * residual blocks (>= 95 % of the FLOP): the reflection-padded tensor is materialised (tnr_pad2d) and the 3x3 implicit-GEMM
+    MFMA kernel runs over the padded grid (its own zero border only touches the cropped-away rim); backward = zero-embedded
+    gradient -> weight-gradient / data-gradient MFMA kernels -> adjoint of the reflection (tnr_unpad2d fold);
+  * stride-2 3x3 convolutions and the transposed convolutions: the 4x4 stride-2 MFMA kernels with the 3x3 taps zero-extended
+    to 4x4 (3x3 s2 p1 == 4x4 s2 p1 with a zero fourth row / column; ConvTranspose2d(k3,s2,p1,op1) == the data-gradient of
+    that convolution, its input gradient == the forward, its weight gradient == the weight gradient with roles swapped);
+  * the two 7x7 image-side convolutions: generic convolution on the vector ALUs (csrc/gconv.hip);
+  * normalisation: the BatchNorm-train kernels (per image for InstanceNorm), ReLU fused; Tanh as one pass.
+"""
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....engine import ConvOp, HipNet
+from ....ops import View, new_act
+from . import block as B
+
+
+class ConvTranspose2dHIP(nn.Module):
+    """nn.ConvTranspose2d's tensors: weight [in, out, k, k] (class name contains 'Conv' for init_weights)."""
+
+    def __init__(self, in_nc, out_nc, kernel_size=3, stride=2, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_nc, out_nc, kernel_size, stride
+        self.weight = nn.Parameter(torch.empty(in_nc, out_nc, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_nc)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+    def forward(self, x):
+        raise RuntimeError("ConvTranspose2dHIP is executed by its owning network's HIP engine")
+
+
+class ResnetBlock(nn.Module):
+    """x + conv_block(x) (ResNet_arch.py:96-149); child indices of `conv_block` as in the reference (reflect padding, no dropout)."""
+
+    def __init__(self, dim, norm, use_bias):
+        super().__init__()
+        self.conv_block = nn.Sequential(B.Marker("reflectpad1"), B.Conv2dHIP(dim, dim, 3, 1, bias=use_bias), _norm_module(norm, dim),
+                                        B.Marker("act:relu"), B.Marker("reflectpad1"), B.Conv2dHIP(dim, dim, 3, 1, bias=use_bias),
+                                        _norm_module(norm, dim))
+
+
+def _norm_module(norm, nc):
+    return B.BatchNorm2dHIP(nc, affine=True) if norm == "batch" else B.Marker("instancenorm")
+
+
+class _Padded4x4:
+    """A 3x3 stride-2 (transposed) convolution on the 4x4 stride-2 MFMA kernels: a zero-extended [O, I, 4, 4] copy of the
+    3x3 weight is what gets packed; its gradient comes back through the same copy."""
+
+    def __init__(self, weight, packer, transposed):
+        o, i = weight.shape[0], weight.shape[1]
+        self.weight, self.transposed = weight, transposed
+        self.w4 = torch.zeros((o, i, 4, 4), dtype=torch.float32, device=weight.device)
+        self.dw4 = torch.zeros_like(self.w4)
+        self.packer = packer
+        self.i_f = packer.add(self.w4, ops.PACK_FWD_S2D)
+        self.i_d = packer.add(self.w4, ops.PACK_DGRAD_S2)
+
+    def refresh(self):
+        self.w4[:, :, :3, :3].copy_(self.weight.detach())          # (the fourth row / column stays zero)
+
+    def conv(self, x, y, **epi):            # large -> small: the 3x3 s2 convolution (or the transposed layer's input gradient)
+        ops.conv(x, self.packer.get(self.i_f), y, mode=ops.CONV_4x4_S2, **epi)
+
+    def conv_t(self, x, y, **epi):          # small -> large: its data-gradient (or the transposed layer's forward)
+        ops.conv(x, self.packer.get(self.i_d), y, mode=ops.DGRAD_4x4_S2, **epi)
+
+    def wgrad(self, x_large, g_small):
+        ops.wgrad(x_large, g_small, self.dw4, None, mode=ops.CONV_4x4_S2, beta=0.0)
+        self.weight.grad.add_(self.dw4[:, :, :3, :3])
+
+
+class ResnetGenerator(HipNet):
+    def __init__(self, input_nc, output_nc, ngf=64, norm_type="batch", use_dropout=False, n_blocks=6, padding_type="reflect",
+                 upsample_mode="deconv"):
+        super().__init__()
+        if norm_type in ("BN", "batch"):
+            norm = "batch"
+        elif norm_type in ("IN", "instance"):
+            norm = "instance"
+        else:
+            raise NameError("Unknown norm layer")
+        if use_dropout or padding_type != "reflect" or upsample_mode != "deconv":
+            raise NotImplementedError("HIP ResnetGenerator implements reflect padding, deconv up-sampling, no dropout")
+        if input_nc > 4 or output_nc > 4 or ngf % 8:
+            raise NotImplementedError("HIP ResnetGenerator needs <= 4 image channels and ngf %% 8 == 0")
+        self.input_nc, self.output_nc, self.ngf, self.norm, self.n_blocks = input_nc, output_nc, ngf, norm, n_blocks
+        ub = norm == "instance"                                   # use_bias (ResNet_arch.py:47-50)
+        m = [B.Marker("reflectpad3"), B.Conv2dHIP(input_nc, ngf, 7, 1, bias=ub), _norm_module(norm, ngf), B.Marker("act:relu")]
+        for i in range(2):
+            mult = 2 ** i
+            m += [B.Conv2dHIP(ngf * mult, ngf * mult * 2, 3, 2, bias=ub), _norm_module(norm, ngf * mult * 2), B.Marker("act:relu")]
+        for _ in range(n_blocks):
+            m.append(ResnetBlock(ngf * 4, norm, ub))
+        for i in range(2):
+            mult = 2 ** (2 - i)
+            m += [ConvTranspose2dHIP(ngf * mult, ngf * mult // 2, 3, 2, bias=ub), _norm_module(norm, ngf * mult // 2), B.Marker("act:relu")]
+        m += [B.Marker("reflectpad3"), B.Conv2dHIP(ngf, output_nc, 7, 1, bias=True), B.Marker("tanh")]
+        self.model = nn.Sequential(*m)
+        self._init_engine()
+
+    # ------------------------------------------------------------------ executors
+    def _build_ops(self, packer):
+        m, nb = self.model, self.n_blocks
+        self._c_in, self._c_out = m[1], m[17 + nb]
+        self._downs = [_Padded4x4(m[4].weight, packer, False), _Padded4x4(m[7].weight, packer, False)]
+        self._down_mods = [m[4], m[7]]
+        self._ups = [_Padded4x4(m[10 + nb].weight, packer, True), _Padded4x4(m[13 + nb].weight, packer, True)]
+        self._up_mods = [m[10 + nb], m[13 + nb]]
+        self._norms = {"in": m[2], "d0": m[5], "d1": m[8], "u0": m[11 + nb], "u1": m[14 + nb]}
+        self._blocks = []
+        for i in range(nb):
+            cb = m[10 + i].conv_block
+            self._blocks.append(((ConvOp(cb[1], packer, need_dgrad=True), cb[2]), (ConvOp(cb[5], packer, need_dgrad=True), cb[6])))
+        self._ops = True
+        self._ones = {}
+
+    def _refresh_derived(self):
+        for p in self._downs + self._ups:
+            p.refresh()
+
+    # normalisation: BatchNorm2d (train) over the batch, or InstanceNorm2d = the same kernels per image with unit affine
+    def _affine(self, C, dev):
+        k = (C, str(dev))
+        if k not in self._ones:
+            self._ones[k] = (torch.ones(C, dtype=torch.float32, device=dev), torch.zeros(C, dtype=torch.float32, device=dev))
+        return self._ones[k]
+
+    def _norm_fwd(self, mod, z, y, act):
+        dev, C = z.buf.device, z.C
+        if self.norm == "batch":
+            mean, inv = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            ops.bn_train_fwd(z, y, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.num_batches_tracked, mean, inv,
+                             momentum=mod.momentum, eps=mod.eps, act=act, slope=0.0)
+            return [(mean, inv)]
+        one, zero = self._affine(C, dev)
+        stats = []
+        for n in range(z.N):
+            mean, inv = torch.empty(C, device=dev), torch.empty(C, device=dev)
+            ops.bn_train_fwd(View(z.buf[n:n + 1], z.coff, C), View(y.buf[n:n + 1], y.coff, C), one, zero, None, None, None, mean, inv,
+                             momentum=0.1, eps=1e-5, act=act, slope=0.0)
+            stats.append((mean, inv))
+        return stats
+
+    def _norm_bwd(self, mod, stats, gy, y, z, gz, relu, want_w):
+        ms = 0.0 if relu else 1.0                                 # ReLU' gate taken from y (slope 0), or no gate at all
+        if self.norm == "batch":
+            mean, inv = stats[0]
+            ops.bn_train_bwd(gy, y, z, gz, mod.weight, mean, inv, dgamma=mod.weight.grad if want_w else None,
+                             dbeta=mod.bias.grad if want_w else None, mslope=ms)
+            return
+        one, _ = self._affine(z.C, z.buf.device)
+        for n, (mean, inv) in enumerate(stats):
+            ops.bn_train_bwd(View(gy.buf[n:n + 1], gy.coff, gy.C), View(y.buf[n:n + 1], y.coff, y.C), View(z.buf[n:n + 1], z.coff, z.C),
+                             View(gz.buf[n:n + 1], gz.coff, gz.C), one, mean, inv, mslope=ms)
+
+    # ------------------------------------------------------------------ forward
+    def engine_forward(self, x, save):
+        N, Cc, H, W = x.shape
+        if H % 4 or W % 4:
+            raise ValueError("ResnetGenerator needs input sizes divisible by 4")
+        dev, ngf = x.device, self.ngf
+        R, NONE = ops.ACT_RELU, ops.ACT_NONE
+        x4 = View(new_act(N, H, W, 4, dev))
+        ops.nchw_to_nhwc(x, x4, Cpad=4)
+        tape = {}
+        z = View(new_act(N, H, W, ngf, dev))
+        ops.gconv_fwd(x4, self._c_in.weight, z, bias=self._c_in.bias, stride=1, pad=3, reflect=True)
+        a = View(new_act(N, H, W, ngf, dev))
+        tape["in"] = (x4, z, a, self._norm_fwd(self._norms["in"], z, a, R))
+        cur = a
+        for i, (p4, mod) in enumerate(zip(self._downs, self._down_mods)):
+            z = View(new_act(N, cur.H // 2, cur.W // 2, mod.out_channels, dev))
+            p4.conv(cur, z, bias=mod.bias)
+            a = View(new_act(N, z.H, z.W, z.C, dev))
+            tape["d%d" % i] = (cur, z, a, self._norm_fwd(self._norms["d%d" % i], z, a, R))
+            cur = a
+        blocks = []
+        for (c1, n1), (c2, n2) in self._blocks:
+            h, w_, C = cur.H, cur.W, cur.C
+            xp = View(new_act(N, h + 2, w_ + 2, C, dev))
+            ops.pad2d(cur, xp, 1, True)
+            zp = View(new_act(N, h + 2, w_ + 2, C, dev))
+            c1.fwd(xp, zp)
+            z1 = View(new_act(N, h, w_, C, dev))
+            ops.unpad2d(zp, z1, 1, False)
+            h1 = View(new_act(N, h, w_, C, dev))
+            s1 = self._norm_fwd(n1, z1, h1, R)
+            hp = View(new_act(N, h + 2, w_ + 2, C, dev))
+            ops.pad2d(h1, hp, 1, True)
+            c2.fwd(hp, zp)                                          # (zp is scratch: only its cropped centre is kept)
+            z2 = View(new_act(N, h, w_, C, dev))
+            ops.unpad2d(zp, z2, 1, False)
+            y2 = View(new_act(N, h, w_, C, dev))
+            s2 = self._norm_fwd(n2, z2, y2, NONE)
+            out = View(new_act(N, h, w_, C, dev))
+            ops.add2(out, cur, y2)
+            blocks.append((xp, z1, h1, s1, hp, z2, y2, s2))
+            cur = out
+        for i, (p4, mod) in enumerate(zip(self._ups, self._up_mods)):
+            z = View(new_act(N, cur.H * 2, cur.W * 2, mod.out_channels, dev))
+            p4.conv_t(cur, z, bias=mod.bias)
+            a = View(new_act(N, z.H, z.W, z.C, dev))
+            tape["u%d" % i] = (cur, z, a, self._norm_fwd(self._norms["u%d" % i], z, a, R))
+            cur = a
+        o4 = new_act(N, H, W, 4, dev)
+        ops.gconv_fwd(cur, self._c_out.weight, View(o4, 0, 4), bias=None, stride=1, pad=3, reflect=True)     # bias added with the tanh pass
+        pre = torch.empty((N, self.output_nc, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(o4, 0, self.output_nc), pre)
+        pre += self._c_out.bias.detach().view(1, -1, 1, 1)
+        out = torch.empty_like(pre)
+        ops.tanh_fwd(pre, out)
+        saved = dict(tape=tape, blocks=blocks, last_in=cur, out=out) if save else None
+        return out, saved
+
+    # ------------------------------------------------------------------ backward
+    def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
+        Wg = need_param_grad
+        gout = gout.contiguous()
+        dev = gout.device
+        tape, blocks, last_in, out = sv["tape"], sv["blocks"], sv["last_in"], sv["out"]
+        N, _, H, W = gout.shape
+        gpre = torch.empty_like(gout)
+        ops.tanh_bwd(gout, out, gpre)
+        g4 = View(new_act(N, H, W, 4, dev))
+        ops.nchw_to_nhwc(gpre, g4, Cpad=4)
+        go = View(g4.buf, 0, 4)
+        co = self._c_out
+        if Wg:
+            dw4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
+            db4 = torch.zeros(4, dtype=torch.float32, device=dev)
+            ops.gconv_wgrad(last_in, go, dw4, db4, stride=1, pad=3, reflect=True, beta=0.0)
+            co.weight.grad.add_(dw4[:self.output_nc])
+            co.bias.grad.add_(db4[:self.output_nc])
+        w4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
+        w4[:self.output_nc].copy_(co.weight.detach())
+        g = View(new_act(N, H, W, self.ngf, dev))
+        ops.gconv_dgrad(go, w4, g, stride=1, pad=3, reflect=True)
+        # up-sampling stages
+        for i in (1, 0):
+            xin, z, a, st = tape["u%d" % i]
+            p4, mod = self._ups[i], self._up_mods[i]
+            gz = View(new_act(N, z.H, z.W, z.C, dev))
+            self._norm_bwd(self._norms["u%d" % i], st, g, a, z, gz, True, Wg)
+            if Wg:
+                p4.wgrad(gz, xin)                                  # roles swapped: the virtual convolution maps large -> small
+                if mod.bias is not None:
+                    ops.bias_grad(gz, mod.bias.grad)
+            g = View(new_act(N, xin.H, xin.W, xin.C, dev))
+            p4.conv(gz, g)
+        # residual blocks
+        for bi in range(len(blocks) - 1, -1, -1):
+            xp, z1, h1, s1, hp, z2, y2, s2 = blocks[bi]
+            (c1, n1), (c2, n2) = self._blocks[bi]
+            h, w_, C = z1.H, z1.W, z1.C
+            gz2 = View(new_act(N, h, w_, C, dev))
+            self._norm_bwd(n2, s2, g, y2, z2, gz2, False, Wg)
+            gzp = View(new_act(N, h + 2, w_ + 2, C, dev))
+            ops.pad2d(gz2, gzp, 1, False)
+            if Wg:
+                c2.wgrad(hp, gzp)
+            ghp = View(new_act(N, h + 2, w_ + 2, C, dev))
+            c2.dgrad(gzp, ghp)
+            gh1 = View(new_act(N, h, w_, C, dev))
+            ops.unpad2d(ghp, gh1, 1, True)
+            gz1 = View(new_act(N, h, w_, C, dev))
+            self._norm_bwd(n1, s1, gh1, h1, z1, gz1, True, Wg)
+            ops.pad2d(gz1, gzp, 1, False)
+            if Wg:
+                c1.wgrad(xp, gzp)
+            c1.dgrad(gzp, ghp)
+            gx = View(new_act(N, h, w_, C, dev))
+            ops.unpad2d(ghp, gx, 1, True)
+            gsum = View(new_act(N, h, w_, C, dev))
+            ops.add2(gsum, gx, g)                                   # skip connection
+            g = gsum
+        # down-sampling stages
+        for i in (1, 0):
+            xin, z, a, st = tape["d%d" % i]
+            p4, mod = self._downs[i], self._down_mods[i]
+            gz = View(new_act(N, z.H, z.W, z.C, dev))
+            self._norm_bwd(self._norms["d%d" % i], st, g, a, z, gz, True, Wg)
+            if Wg:
+                p4.wgrad(xin, gz)
+                if mod.bias is not None:
+                    ops.bias_grad(gz, mod.bias.grad)
+            g = View(new_act(N, xin.H, xin.W, xin.C, dev))
+            p4.conv_t(gz, g)
+        x4, z, a, st = tape["in"]
+        gz = View(new_act(N, z.H, z.W, z.C, dev))
+        self._norm_bwd(self._norms["in"], st, g, a, z, gz, True, Wg)
+        ci = self._c_in
+        if Wg:
+            dwi = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
+            dbi = torch.zeros(ci.out_channels, dtype=torch.float32, device=dev)
+            ops.gconv_wgrad(x4, gz, dwi, dbi, stride=1, pad=3, reflect=True, beta=0.0)
+            ci.weight.grad.add_(dwi[:, :self.input_nc])
+            if ci.bias is not None:
+                ci.bias.grad.add_(dbi)
+        if not need_input_grad:
+            return None
+        wi4 = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
+        wi4[:, :self.input_nc].copy_(ci.weight.detach())
+        gx4 = View(new_act(N, H, W, 4, dev))
+        ops.gconv_dgrad(gz, wi4, gx4, stride=1, pad=3, reflect=True)
+        gin = torch.empty((N, self.input_nc, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(gx4.buf, 0, self.input_nc), gin)
+        return gin

@@ -296,3 +296,145 @@ class UNetDiscriminator(HipNet):
         gin = torch.empty((N, self.input_nc, H, W), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(View(gx4.buf, 0, self.input_nc), gin)
         return gin
+
+
+class NLayerDiscriminator(HipNet):
+    """PatchGAN discriminator (Pix2Pix / CycleGAN) on the MI355X engine.
+
+    Constructor, `state_dict` keys (`model.<i>.*`) and arithmetic follow codes/models/modules/architectures/
+    discriminators.py:472-579 for the default configuration get_network builds (BatchNorm2d, patch output, no spectral norm,
+    no intermediate feature maps): conv4 s2 (in -> ndf, bias) + LReLU; n_layers-1 x [conv4 s2 (no bias) + BN + LReLU];
+    conv4 s1 (no bias) + BN + LReLU; conv4 s1 (-> 1, bias).  The stride-2 layers run on the space-to-depth MFMA kernels
+    (conv_tile.hip), the two stride-1 4x4 layers on the generic vector-ALU convolution (csrc/gconv.hip)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, get_feats=False, patch=True,
+                 use_spectral_norm=False):
+        super().__init__()
+        if use_sigmoid or get_feats or not patch or use_spectral_norm or norm_layer is not None:
+            raise NotImplementedError("HIP NLayerDiscriminator implements the default PatchGAN (BatchNorm, patch output)")
+        if input_nc > 8 or ndf % 8:
+            raise NotImplementedError("HIP NLayerDiscriminator needs <= 8 input channels and ndf %% 8 == 0")
+        self.input_nc, self.n_layers, self.slope = input_nc, n_layers, 0.2
+        seq = [B.Conv2dHIP(input_nc, ndf, 4, 2), B.Marker("act:leakyrelu")]
+        nf_mult = 1
+        for n in range(1, n_layers):
+            prev, nf_mult = nf_mult, min(2 ** n, 8)
+            seq += [B.Conv2dHIP(ndf * prev, ndf * nf_mult, 4, 2, bias=False), B.BatchNorm2dHIP(ndf * nf_mult), B.Marker("act:leakyrelu")]
+        prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+        seq += [B.Conv2dHIP(ndf * prev, ndf * nf_mult, 4, 1, bias=False), B.BatchNorm2dHIP(ndf * nf_mult), B.Marker("act:leakyrelu")]
+        seq += [B.Conv2dHIP(ndf * nf_mult, 1, 4, 1)]
+        self.model = nn.Sequential(*seq)
+        self._init_engine()
+
+    def _build_ops(self, packer):
+        mods = list(self.model)
+        self._layers = []          # (conv module, bn or None, has activation, ConvOp for the stride-2 layers)
+        i = 0
+        while i < len(mods):
+            conv = mods[i]
+            bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], B.BatchNorm2dHIP) else None
+            j = i + (2 if bn is not None else 1)
+            act = j < len(mods) and isinstance(mods[j], B.Marker)
+            op = ConvOp(conv, packer, need_dgrad=True) if conv.stride == 2 and conv.in_channels % 4 == 0 else None
+            self._layers.append((conv, bn, act, op))
+            i = j + (1 if act else 0)
+        self._ops = True
+
+    def engine_forward(self, x, save):
+        N, Cc, H, W = x.shape
+        dev, sl = x.device, self.slope
+        cpad = (Cc + 3) // 4 * 4
+        xin = View(new_act(N, H, W, cpad, dev))
+        ops.nchw_to_nhwc(x, xin, Cpad=cpad)
+        cur, tape = xin, []
+        for li, (conv, bn, act, op) in enumerate(self._layers):
+            k, s = conv.kernel_size, conv.stride
+            Ho, Wo = (cur.H + 2 - k) // s + 1, (cur.W + 2 - k) // s + 1
+            co = (conv.out_channels + 3) // 4 * 4
+            z = View(new_act(N, Ho, Wo, co, dev))
+            fused_act = act and bn is None
+            if op is not None:
+                op.fwd(cur, z, **(dict(act=ops.ACT_LRELU, slope=sl) if fused_act else {}))
+            else:
+                ops.gconv_fwd(cur, self._wpad(conv, cur.C), z, bias=self._bpad(conv, co),
+                              stride=s, pad=1, reflect=False, act=ops.ACT_LRELU if fused_act else ops.ACT_NONE, slope=sl)
+            y, stats = z, None
+            if bn is not None:
+                y = View(new_act(N, Ho, Wo, co, dev))
+                mean, inv = torch.empty(co, device=dev), torch.empty(co, device=dev)
+                ops.bn_train_fwd(z, y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, inv,
+                                 momentum=bn.momentum, eps=bn.eps, act=ops.ACT_LRELU if act else ops.ACT_NONE, slope=sl)
+                stats = (mean, inv)
+            tape.append((cur, z, y, stats))
+            cur = y
+        out = torch.empty((N, 1, cur.H, cur.W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(cur.buf, 0, 1), out)
+        return out, (dict(tape=tape) if save else None)
+
+    def _wpad(self, conv, cin_buf):
+        """OIHW weight with the input-channel dim zero-extended to the buffer's channel count and the output dim to a multiple of 4
+        (generic kernel reads `Cin` = buffer channels)."""
+        w = conv.weight.detach()
+        co = (w.shape[0] + 3) // 4 * 4
+        if w.shape[1] == cin_buf and co == w.shape[0]:
+            return w
+        wp = torch.zeros((co, cin_buf, w.shape[2], w.shape[3]), dtype=torch.float32, device=w.device)
+        wp[:w.shape[0], :w.shape[1]].copy_(w)
+        return wp
+
+    def _bpad(self, conv, co):
+        if conv.bias is None:
+            return None
+        if co == conv.out_channels:
+            return conv.bias.detach()
+        b = torch.zeros(co, dtype=torch.float32, device=conv.bias.device)
+        b[:conv.out_channels].copy_(conv.bias.detach())
+        return b
+
+    def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
+        Wg, sl = need_param_grad, self.slope
+        gout = gout.contiguous()
+        dev = gout.device
+        tape = sv["tape"]
+        N = gout.shape[0]
+        last = tape[-1][2]
+        gy = View(new_act(N, last.H, last.W, last.C, dev))
+        ops.nchw_to_nhwc(gout, gy, Cpad=last.C)
+        sched = getattr(self, "_bucket_schedule", None) if Wg else None
+        for li in range(len(self._layers) - 1, -1, -1):
+            conv, bn, act, op = self._layers[li]
+            xin, z, y, stats = tape[li]
+            if bn is not None:
+                gz = View(new_act(N, z.H, z.W, z.C, dev))
+                ops.bn_train_bwd(gy, y, z, gz, bn.weight, stats[0], stats[1], dgamma=bn.weight.grad if Wg else None,
+                                 dbeta=bn.bias.grad if Wg else None, mslope=sl if act else 1.0)
+            elif act:
+                gz = gy
+                ops.mask_mul(gz, y, sl)                              # LeakyReLU' of a layer without BatchNorm
+            else:
+                gz = gy
+            k, s = conv.kernel_size, conv.stride
+            if Wg:
+                if op is not None:
+                    op.wgrad(xin, gz)
+                else:
+                    co = gz.C
+                    dwp = torch.zeros((co, xin.C, k, k), dtype=torch.float32, device=dev)
+                    dbp = torch.zeros(co, dtype=torch.float32, device=dev)
+                    ops.gconv_wgrad(xin, gz, dwp, dbp, stride=s, pad=1, reflect=False, beta=0.0)
+                    conv.weight.grad.add_(dwp[:conv.out_channels, :conv.in_channels])
+                    if conv.bias is not None:
+                        conv.bias.grad.add_(dbp[:conv.out_channels])
+                if sched is not None:
+                    sched.mark_done(conv.weight)
+            if li == 0 and not need_input_grad:
+                return None
+            gx = View(new_act(N, xin.H, xin.W, xin.C, dev))
+            if op is not None:
+                op.dgrad(gz, gx)
+            else:
+                ops.gconv_dgrad(gz, self._wpad(conv, xin.C), gx, stride=s, pad=1, reflect=False)
+            gy = gx
+        gin = torch.empty((N, self.input_nc, gy.H, gy.W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(View(gy.buf, 0, self.input_nc), gin)
+        return gin

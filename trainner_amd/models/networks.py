@@ -65,6 +65,12 @@ def get_network(opt, step=0, selector=None):
     elif kind == "unet":
         from .modules.architectures import discriminators
         net = discriminators.UNetDiscriminator
+    elif kind == "resnet_net":
+        from .modules.architectures import ResNet_arch
+        net = ResNet_arch.ResnetGenerator
+    elif kind in ("patchgan", "nlayerdiscriminator"):
+        from .modules.architectures import discriminators
+        net = discriminators.NLayerDiscriminator
     else:
         raise NotImplementedError("Model [{:s}] not recognized by the HIP engine".format(kind))
 

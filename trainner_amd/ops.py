@@ -518,6 +518,12 @@ def gconv_wgrad(x, g, dw, db=None, stride=1, pad=0, reflect=False, alpha=1.0, be
                                   alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "gconv_wgrad")
 
 
+def bias_grad(g, db, alpha=1.0, beta=1.0):
+    """db = beta db + alpha * sum over the pixels of g (per channel)."""
+    ws = WS.get("bias_grad@%x" % hip.stream(), 64 * g.C * 8, g.buf.device)
+    hip.check(hip.load().tnr_bias_grad(g.c(), g.pixels, g.C, db.data_ptr(), alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "bias_grad")
+
+
 def pad2d(x, y, pad, reflect):
     """y [N, H + 2 pad, W + 2 pad, C] = x with a zero (reflect False) or reflected border."""
     hip.check(hip.load().tnr_pad2d(x.c(), y.c(), x.N, x.H, x.W, x.C, pad, int(reflect), hip.stream()), "pad2d")

@@ -56,6 +56,16 @@ def get_network_G_config(network_G, scale, crop_size):
         full["convtype"] = src.pop("convtype", "Conv2D")
         full["finalact"] = src.pop("finalact", None)
         full["res_scale"] = src.pop("res_scale", 1)
+    elif "resnet" in kind and kind != "sr_resnet":        # image-to-image ResNet generator (defaults.py:218-234)
+        full["type"] = "resnet_net"
+        full["input_nc"] = src.pop("in_nc", 3)
+        full["output_nc"] = src.pop("out_nc", 3)
+        full["n_blocks"] = src.pop("n_blocks", 6 if kind == "resnet_6blocks" else 9)
+        full["ngf"] = src.pop("ngf", 64)
+        full["norm_type"] = src.pop("norm_type", "instance")
+        full["use_dropout"] = src.pop("use_dropout", False)
+        full["upsample_mode"] = src.pop("upsample_mode", "deconv")
+        full["padding_type"] = src.pop("padding_type", "reflect")
     else:
         raise NotImplementedError("Generator model [{}] is outside the SR hot path of the HIP engine".format(kind))
     for k in ("type", "which_model_G"):
@@ -80,6 +90,16 @@ def get_network_D_config(network_D, scale, crop_size, model_G):
         full["convtype"] = src.pop("convtype", "Conv2D")
         full["arch"] = src.pop("G_arch", arch)
         full["size"] = src.pop("D_size", crop_size)
+    elif kind in ("patchgan", "nlayerdiscriminator"):  # PatchGAN (defaults.py:361-376)
+        src.pop("which_model_D", None)
+        src.pop("type", None)
+        full["type"] = "patchgan"
+        full["input_nc"] = src.pop("in_nc", 3)
+        full["ndf"] = src.pop("nf", 64)
+        full["n_layers"] = src.pop("n_layers", None) or src.pop("nlayer", 3)
+        full["get_feats"] = src.pop("get_feats", False)
+        full["patch"] = src.pop("patch_output", True)
+        full["use_spectral_norm"] = src.pop("spectral_norm", None) or src.pop("use_spectral_norm", False)
     elif "unet" in kind:                               # Real-ESRGAN's U-Net discriminator (defaults.py:378-382)
         src.pop("which_model_D", None)
         src.pop("type", None)
