@@ -78,7 +78,7 @@ def test_defaults_reject_off_path_kinds():
     with pytest.raises(NotImplementedError):
         defaults.get_network_G_config("pan", 4, 128)
     with pytest.raises(NotImplementedError):
-        defaults.get_network_D_config("patchgan", 4, 128, "rrdb_net")
+        defaults.get_network_D_config("multiscale", 4, 128, "rrdb_net")
     g = defaults.get_network_G_config("esrgan", 4, 128)
     assert g["type"] == "rrdb_net" and g["nb"] == 23 and g["upsample_mode"] == "upconv" and g["gaussian_noise"] is True
     d = defaults.get_network_D_config("discriminator_vgg", 4, 128, "rrdb_net")
