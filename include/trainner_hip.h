@@ -212,8 +212,8 @@ int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
  * tnr_pad2d / tnr_unpad2d: materialise a zero (mode 0) or reflection (mode 1) border of `pad` pixels / crop it (mode 0) or
  * apply the adjoint of the reflection padding (mode 1) -- the residual blocks' reflection-padded 3x3 convolutions run on
  * the MFMA 3x3 kernel over the padded tensor.  tnr_tanh_*: the generator's output activation.  tnr_gan_loss: GANLoss
- * against a constant label (modules/loss.py:61-137): type 0 vanilla (BCE with logits), 1 lsgan (MSE), mean reduction;
- * out[0] = loss, grad = d loss / d pred (may be NULL).                                                              */
+ * against a constant label (modules/loss.py:61-137): type 0 vanilla (BCE with logits), 1 lsgan (MSE), mean reduction,
+ * 2 = mean(pred) (the D_real / D_fake log entries, losses.py:519-520); out[0] = loss, grad = d loss / d pred (may be NULL). */
 int tnr_gconv_fwd(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w, const float *bias, tnr_view y, int32_t Ho,
                   int32_t Wo, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t reflect, int32_t act, float slope, void *stream);
 int tnr_gconv_dgrad(tnr_view g, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *w, tnr_view gx, int32_t Ho, int32_t Wo,

@@ -112,3 +112,38 @@ def buffers_error(sd, probes):
             if max(e_s, e_n) > worst[0]:
                 worst = (max(e_s, e_n), k)
     return worst
+
+
+# --------------------------------------------------------------------------------------------------------------
+# image-to-image fixtures (oracle/make_golden_i2i.py)
+# --------------------------------------------------------------------------------------------------------------
+def i2i_initial_states(fx):
+    return {n: initial_state(fx["keys"][n], fx["seeds"][n]) for n in fx["model_names"]}
+
+
+def i2i_batches(fx):
+    y = fx["spec"]["yaml"]
+    for s in range(1, fx["spec"]["steps"] + 1):
+        sd = fx["seeds"]["data"] + s
+        yield s, (detrand.uniform((y["batch"], 3, y["crop"], y["crop"]), sd, -1.0, 1.0),
+                  detrand.uniform((y["batch"], 3, y["crop"], y["crop"]), sd + 5000, -1.0, 1.0))
+
+
+def i2i_oracle_for(fx):
+    from . import i2i_oracle
+    y, st = fx["spec"]["yaml"], i2i_initial_states(fx)
+    common = dict(n_blocks=fx["network_G"]["n_blocks"], norm=fx["network_G"]["norm_type"], gan_type=y.get("gan_type", "vanilla"),
+                  pixel_weight=y["pixel_weight"])
+    if y["model"] == "pix2pix":
+        return i2i_oracle.OraclePix2PixStep(st["G"], st["D"], **common)
+    return i2i_oracle.OracleCycleGANStep(st["G_A"], st["G_B"], st["D_A"], st["D_B"], lambda_identity=y.get("lambda_identity"),
+                                         pool_size=y.get("pool_size", 0), **common)
+
+
+def norm_shadowed_biases(keys, norm_type):
+    """ResnetGenerator conv biases in front of an InstanceNorm (every conv bias but the last layer's, ResNet_arch.py:47-90):
+    exactly-zero true gradient, so Adam moves them by +-lr of arbitrary sign in any implementation (cf. bn_shadowed_biases)."""
+    if norm_type != "instance":
+        return set()
+    biases = [k for k, _ in keys if k.endswith(".bias")]
+    return set(biases[:-1])

@@ -116,3 +116,40 @@ def reference_netF(model):
         if "fea" in l["name"]:
             return l["function"].network
     return None
+
+
+def i2i_yaml(name="oracle_i2i", model="pix2pix", batch=2, crop=64, n_blocks=2, ngf=16, ndf=16, norm_G="instance",
+             gan_type="vanilla", pixel_weight=100.0, lambda_identity=None, pool_size=0, out_root=None, gpu_ids="[]",
+             lr_scheme="MultiStepLR", amp=False):
+    """A train_pix2pix.yml / train_cyclegan.yml-shaped config (codes/options/i2i/train_pix2pix.yml:1-143,
+    train_cyclegan.yml:1-140) with the ResNet generator + PatchGAN of BASELINE.json configs[4], for CPU."""
+    out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
+    os.makedirs(out_root, exist_ok=True)
+    d_in = 6 if model == "pix2pix" else 3            # conditional D sees (A, B) pairs (pix2pix_model.py:63-66)
+    train = ["  optim_G: adam", "  lr_G: 2e-4", "  beta1_G: 0.5", "  optim_D: adam", "  lr_D: 2e-4", "  beta1_D: 0.5"]
+    if lr_scheme == "Linear":
+        train += ["  lr_scheme: Linear", "  fixed_niter: 25000", "  niter_decay: 25000"]
+    else:
+        train += ["  lr_scheme: MultiStepLR", "  lr_steps: [50000, 100000]", "  lr_gamma: 0.5"]
+    train += ["  pixel_criterion: l1", "  pixel_weight: %g" % pixel_weight, "  gan_type: %s" % gan_type, "  gan_weight: 1",
+              "  gan_opt:", "    form: standard"]
+    if lambda_identity is not None:
+        train += ["  lambda_identity: %g" % lambda_identity]
+    train += ["  manual_seed: 0", "  niter: 50000", "  val_freq: 5000"]
+    txt = "\n".join([
+        "name: %s" % name, "use_tb_logger: false", "model: %s" % model, "scale: 1", "gpu_ids: %s" % gpu_ids,
+        "use_amp: %s" % ("true" if amp else "false"), "use_swa: false", "use_cem: false", "use_atg: false",
+        "pool_size: %d" % pool_size,
+        "datasets:", "  train:", "    name: synth", "    mode: aligned", "    outputs: AB",
+        "    dataroot_B: /tmp/none_b", "    dataroot_A: /tmp/none_a", "    znorm: true",
+        "    n_workers: 0", "    batch_size: %d" % batch, "    virtual_batch_size: %d" % batch,
+        "    preprocess: crop", "    crop_size: %d" % crop, "    image_channels: 3", "    input_nc: 3", "    output_nc: 3",
+        "path:", "  root: %s" % out_root,
+        "network_G:", "  which_model_G: resnet_net", "  n_blocks: %d" % n_blocks, "  ngf: %d" % ngf, "  norm_type: %s" % norm_G,
+        "network_D:", "  which_model_D: patchgan", "  in_nc: %d" % d_in, "  nf: %d" % ndf,
+        "train:", *train,
+        "logger:", "  print_freq: 1", "  save_checkpoint_freq: 1000000", ""])
+    path = os.path.join(out_root, name + ".yml")
+    with open(path, "w") as f:
+        f.write(txt)
+    return path

@@ -276,7 +276,7 @@ def gan_loss(pred, kind, target, out, grad=None):
     p = pred.detach().clone().requires_grad_(True)
     with torch.enable_grad():
         t = torch.full_like(p, float(target))
-        l = F.binary_cross_entropy_with_logits(p, t) if kind == 0 else F.mse_loss(p, t)
+        l = F.binary_cross_entropy_with_logits(p, t) if kind == 0 else (F.mse_loss(p, t) if kind == 1 else p.mean())
         (g,) = torch.autograd.grad(l, p)
     out.reshape(-1)[0] = l.detach()
     if grad is not None:

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import emul_backend
+import test_gpu_i2i as TI
 import test_gpu_nets as TN
 import test_gpu_step as TS
 
@@ -16,6 +17,7 @@ def emulated(monkeypatch):
     emul_backend.install(monkeypatch)
     monkeypatch.setattr(TN, "DEV", "cpu")
     monkeypatch.setattr(TS, "DEV", "cpu")
+    monkeypatch.setattr(TI, "DEV", "cpu")
     torch.set_num_threads(8)
 
 
@@ -54,6 +56,11 @@ def test_vgg_schedule():
                                   "esrgan_nb1_unet"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
+
+
+@pytest.mark.parametrize("case", TI.I2I_CASES)
+def test_i2i_step_vs_reference_golden(case, tmp_path):
+    TI.test_i2i_step_matches_reference_golden(case, tmp_path)
 
 
 def test_amp_policy_step(tmp_path):

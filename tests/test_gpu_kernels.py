@@ -823,3 +823,6 @@ def test_pad_tanh_ganloss_kernels():
         ops.gan_loss(p.to(DEV), kind, target, out, grad)
         assert abs(float(out) - float(l)) < 1e-6 * max(1.0, abs(float(l)))
         close(grad.cpu(), gr, tol=1e-6, what="gan loss grad")
+    out = torch.zeros(1, device=DEV)
+    ops.gan_loss(p.to(DEV), 2, 0.0, out, None)            # kind 2: mean of the logits (D_real / D_fake log entries)
+    assert abs(float(out) - float(p.mean())) < 1e-6

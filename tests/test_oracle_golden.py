@@ -58,3 +58,36 @@ def test_oracle_matches_reference(case):
         assert mean < STATE_MEAN and worst < STATE_WORST, ("D state", k, worst, mean)
         e, k = FX.buffers_error(orc.d_state(), fx["d_state"])
         assert e < 2e-3, ("D running stats", k, e)   # carries the BN-shadowed conv bias random walk
+
+
+I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt"]
+
+
+@pytest.mark.parametrize("case", I2I_CASES)
+def test_i2i_oracle_matches_reference(case):
+    """oracle/i2i_oracle.py (Pix2Pix / CycleGAN steps) against the reference-generated goldens: every log entry of every
+    step (incl. the one-step-late D entries of CycleGAN and the image-pool draws), the generated images of the last step
+    and the post-step weights of every network."""
+    import random
+    torch.set_num_threads(8)
+    fx = FX.load(case)
+    orc = FX.i2i_oracle_for(fx)
+    random.seed(fx["seeds"]["pool"])
+    for (s, (A, B)), ref_log in zip(FX.i2i_batches(fx), fx["logs"]):
+        log = orc.step(A, B)
+        assert list(log.keys()) == list(ref_log.keys()), (s, list(log.keys()), list(ref_log.keys()))
+        tol = LOG_RTOL if s <= 2 else 3e-4
+        for k, v in ref_log.items():
+            assert abs(log[k] - v) <= tol * max(1.0, abs(v)) + 2e-6, (case, s, k, log[k], v)
+    for k, ref in fx["images"].items():
+        diff = (getattr(orc, k).detach() - ref).abs().max().item()
+        assert diff <= 2e-4, (k, diff)
+    lr_steps = 2e-4 * fx["spec"]["steps"]
+    nets = {"G": "g", "D": "d", "G_A": "ga", "G_B": "gb", "D_A": "da", "D_B": "db"}
+    for n in fx["model_names"]:
+        sd = getattr(orc, nets[n]).state()
+        skip = FX.norm_shadowed_biases(fx["keys"][n], fx["network_G"]["norm_type"]) if n.startswith("G") else ()
+        worst, mean, k = FX.state_error(sd, fx["states"][n], skip, lr_steps=lr_steps)
+        assert mean < 0.02 and worst < 1.05, (n, k, worst, mean)
+        e, k = FX.buffers_error(sd, fx["states"][n])
+        assert e < 2e-3, (n, "running stats", k, e)

@@ -232,7 +232,8 @@ __global__ void tanh_bwd_kernel(const float *g, const float *y, float *gx, int64
         gx[e] = g[e] * (1.f - y[e] * y[e]);
 }
 
-// GANLoss against a constant label (modules/loss.py:61-137): type 0 vanilla = BCEWithLogits(mean), 1 lsgan = MSE(mean).
+// GANLoss against a constant label (modules/loss.py:61-137): type 0 vanilla = BCEWithLogits(mean), 1 lsgan = MSE(mean),
+// 2 = mean(pred) itself (log entries).
 // out[0] = loss; grad[i] = d loss / d pred[i] (unit upstream gradient).  One block: the logit maps are small (30 x 30 per image).
 __global__ void __launch_bounds__(256) gan_loss_kernel(const float *pred, int64_t n, int type, float target, float *out, float *grad) {
     __shared__ double sh[256];
@@ -243,10 +244,13 @@ __global__ void __launch_bounds__(256) gan_loss_kernel(const float *pred, int64_
         if (type == 0) {       // BCE with logits: max(x, 0) - x t + log(1 + exp(-|x|))
             l = fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
             g = 1.f / (1.f + expf(-x)) - target;
-        } else {
+        } else if (type == 1) {
             const float d = x - target;
             l = d * d;
             g = 2.f * d;
+        } else {               // plain mean of the logits (the D_real / D_fake log entries, losses.py:519-520)
+            l = x;
+            g = 1.f;
         }
         s += (double)l;
         if (grad) grad[i] = g / (float)n;
@@ -364,7 +368,7 @@ extern "C" int tnr_tanh_bwd(const float *g, const float *y, float *gx, int64_t n
 }
 
 extern "C" int tnr_gan_loss(const float *pred, int64_t n, int32_t type, float target, float *out, float *grad, void *stream) {
-    TNR_REQUIRE(pred && out && n >= 1 && (type == 0 || type == 1), "gan_loss: bad arguments");
+    TNR_REQUIRE(pred && out && n >= 1 && (type >= 0 && type <= 2), "gan_loss: bad arguments");
     hipLaunchKernelGGL(gan_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, n, type, target, out, grad);
     return tnr_check_launch("gan_loss");
 }

@@ -66,6 +66,24 @@ class BaseModel:
         self.dp = dpmod.init_from_env()
 
     # ------------------------------------------------------------------ protocol stubs
+    def _shard(self, t):
+        """Reference semantics of `batch_size` (options/README.md:31: the GLOBAL batch, split over gpu_ids by
+        nn.DataParallel's scatter): a fed tensor that carries the global batch is cut to this rank's contiguous
+        shard; a tensor that already holds batch_size / world samples (a per-rank loader) is taken as is."""
+        world = self.dp.world_size
+        if world == 1 or not self.is_train:
+            return t
+        gb = self.opt["datasets"]["train"]["batch_size"]
+        if gb % world:
+            raise ValueError("batch_size %d is not divisible by the %d data-parallel ranks" % (gb, world))
+        per = gb // world
+        if t.shape[0] == gb:
+            return t[self.dp.rank * per:(self.dp.rank + 1) * per]
+        if t.shape[0] == per:
+            return t
+        raise ValueError("fed batch of %d samples is neither the global batch (%d) nor this rank's shard (%d)"
+                         % (t.shape[0], gb, per))
+
     def feed_data(self, data):
         pass
 
@@ -112,8 +130,12 @@ class BaseModel:
             if load_path is None:
                 continue
             logger.info("Loading pretrained model for %s [%s]", name, load_path)
-            key = "network_{}".format(name)
-            strict = self.opt[key].get("strict", None) if self.opt[key] else True
+            # strict flag of this net's own option block, else of its family's (G_A -> network_G; base_model.py:201-206)
+            strict = True
+            for key in ("network_{}".format(name), "network_{}".format("D" if "D" in name else "G")):
+                if self.opt.get(key):
+                    strict = self.opt[key].get("strict", None)
+                    break
             self.load_network(load_path, getattr(self, "net" + name), strict, model_type=name)
 
     def save_network(self, network, network_label, iter_step, latest=False):
@@ -197,8 +219,11 @@ class BaseModel:
         for name, param in model.named_parameters():
             if target_layer is None:
                 param.requires_grad = flag
-            elif net_type == "D" and "features.{}.".format(target_layer) in name:
-                param.requires_grad = flag
+            elif net_type == "D":
+                # vgg-like D: features.<i>. ; PatchGAN: model.<i>. (base_model.py:343-351)
+                prefix = "features." if "features." in name else ("model." if "model." in name else None)
+                if prefix and "{}{}.".format(prefix, target_layer) in name:
+                    param.requires_grad = flag
 
     # ------------------------------------------------------------------ feature switches
     def _reject(self, enabled, what):
@@ -233,8 +258,12 @@ class BaseModel:
     def setup_freezeD(self):
         self.feature_loc = None
         loc = self.opt["train"].get("freeze_loc")
-        if loc and "discriminator_vgg" in self.opt["network_D"].get("type", ""):
+        disc = self.opt["network_D"].get("type", "") if loc else ""
+        if loc and "discriminator_vgg" in disc:
             self.feature_loc = (loc * 3) - 2
+            logger.info("FreezeD enabled")
+        elif loc and "patchgan" in disc:
+            self.feature_loc = (loc * 3) - 1
             logger.info("FreezeD enabled")
 
     def setup_optimizers(self, opt_G_nets, opt_D_nets, init_setup=False):

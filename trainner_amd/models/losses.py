@@ -99,6 +99,49 @@ class _RaGANFn(torch.autograd.Function):
         return of.view(ctx.shapes[0]), orr, None, None, None
 
 
+class _GanLabelFn(torch.autograd.Function):
+    """GANLoss against a constant label (modules/loss.py:85-88,112-137): mean BCE-with-logits ('vanilla', kind 0) or mean
+    squared error ('lsgan', kind 1) of the discriminator's logit map against `target` (1.0 real / 0.0 fake).  One launch
+    produces the loss and d loss / d pred (tnr_gan_loss)."""
+
+    @staticmethod
+    def forward(ctx, pred, kind, target):
+        hip.require_device(pred)
+        p = pred.contiguous().view(-1)
+        out = torch.empty(1, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        ops.gan_loss(p, kind, target, out, grad)
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        of = torch.empty_like(grad)
+        ops.scale_by(of, grad, g.reshape(1).contiguous())
+        return of.view(ctx.shape), None, None
+
+
+class _CatChannelsFn(torch.autograd.Function):
+    """torch.cat((a, b), 1) of two NCHW image batches for the conditional discriminator input (losses.py:445-455,
+    522-530): two strided device copies into one buffer; backward hands each operand its channel slice."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+        out[:, :a.shape[1]].copy_(a)
+        out[:, a.shape[1]:].copy_(b)
+        ctx.ca = a.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = g[:, :ctx.ca].contiguous() if ctx.needs_input_grad[0] else None
+        gb = g[:, ctx.ca:].contiguous() if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
 # ----------------------------------------------------------------------------------------------
 # builders
 # ----------------------------------------------------------------------------------------------
@@ -165,38 +208,78 @@ class PerceptualLoss(nn.Module):
 
 
 class Adversarial(nn.Module):
-    """Discriminator-driven losses (losses.py:343-604): vanilla GAN, relativistic or standard form."""
+    """Discriminator-driven losses (losses.py:343-604) for single-scale discriminators without feature maps:
+    `gan_opt.form` relativistic (vanilla GAN: the ESRGAN recipe) or standard (vanilla / lsgan: Pix2Pix, CycleGAN), and the
+    conditional formulation (Pix2Pix: D sees the (condition, image) channel concatenation, losses.py:445-455,522-530)."""
+
+    _KINDS = {"vanilla": 0, "lsgan": 1}
 
     def __init__(self, train_opt=None, device="cpu", diffaug=False, dapolicy="", conditional=False):
         super().__init__()
-        if diffaug or conditional or train_opt.get("gan_featmaps"):
-            raise NotImplementedError("diffaug / conditional / feature-map GAN options are not implemented by the HIP engine")
+        if diffaug or train_opt.get("gan_featmaps"):
+            raise NotImplementedError("diffaug / feature-map GAN options are not implemented by the HIP engine")
         self.device = device
+        self.conditional = bool(conditional)
         self.gan_type = train_opt["gan_type"]
-        if self.gan_type != "vanilla":
+        if self.gan_type not in self._KINDS:
             raise NotImplementedError("GAN type [{}] is not implemented by the HIP engine".format(self.gan_type))
         self.l_gan_w = train_opt["gan_weight"]
         self.form = (train_opt.get("gan_opt") or {}).get("form", "relativistic")
-        if self.form != "relativistic":
+        if self.form not in ("relativistic", "standard"):
             raise NotImplementedError("GAN form [{}] is not implemented by the HIP engine".format(self.form))
-        self.dp_group = None        # set by SRModel when running data-parallel
+        if self.form == "relativistic" and self.gan_type != "vanilla":
+            raise NotImplementedError("the relativistic form is implemented for gan_type vanilla only")
+        self.dp_group = None        # set by the model when running data-parallel
+
+    def _label_loss(self, pred, target_is_real):
+        return _GanLabelFn.apply(pred, self._KINDS[self.gan_type], 1.0 if target_is_real else 0.0)
+
+    def _logged(self, t):
+        """Logged scalars are global-batch means under data parallelism (equal shards), as the reference's gathered batch."""
+        t = t.detach()
+        return self.dp_group.mean_scalar(t) if self.dp_group is not None else t
 
     def forward(self, fake, real=None, condition=None, netD=None, stage="discriminator", fsfilter=None):
         if fsfilter is not None:
             raise NotImplementedError("frequency separation is not implemented by the HIP engine")
+        if self.conditional:
+            # like the reference's dispatch (losses.py:590-604) the second positional argument is the condition in the
+            # generator stage (pix2pix_model.py:152-154 passes it by keyword)
+            if condition is None:
+                raise ValueError("conditional GAN: no condition image was given")
+            fake = _CatChannelsFn.apply(condition, fake)
+            if real is not None:
+                real = _CatChannelsFn.apply(condition, real)
         if stage == "generator":
             pred_g_fake = netD(fake)
+            if self.form == "standard":                # D(real) is not needed (losses.py:395-403,424-426)
+                return self.l_gan_w * self._label_loss(pred_g_fake, True)
             with torch.no_grad():
                 pred_g_real = netD(real)          # detached in the reference (losses.py:430)
             res = _RaGANFn.apply(pred_g_fake, pred_g_real, 0, self.l_gan_w, self.dp_group)
             return res[0]
         pred_d_fake = netD(fake.detach())
         pred_d_real = netD(real)
+        if self.form == "standard":                    # losses.py:497-499,514-523
+            l_d_fake = self._label_loss(pred_d_fake, False)
+            l_d_real = self._label_loss(pred_d_real, True)
+            l_d_total = (l_d_fake + l_d_real) * 0.5
+            gan_logs = {"l_d_real": self._logged(l_d_real), "l_d_fake": self._logged(l_d_fake),
+                        "D_real": self._logged(ops_mean(pred_d_real)), "D_fake": self._logged(ops_mean(pred_d_fake))}
+            return l_d_total, gan_logs
         res = _RaGANFn.apply(pred_d_fake, pred_d_real, 1, 1.0, self.dp_group)
-        # kept on device: SRModel's log dict materialises lazily (one sync instead of four .item())
+        # kept on device: the model's log dict materialises lazily (one sync instead of four .item())
         gan_logs = {"l_d_real": res[1].detach(), "l_d_fake": res[2].detach(),
                     "D_real": res[3].detach(), "D_fake": res[4].detach()}
         return res[0], gan_logs
+
+
+def ops_mean(pred):
+    """torch.mean(pred.detach()) of a logit map for the D_real / D_fake log entries (losses.py:519-520)."""
+    p = pred.detach().contiguous().view(-1)
+    out = torch.empty(1, dtype=torch.float32, device=p.device)
+    ops.gan_loss(p, 2, 0.0, out, None)
+    return out[0]
 
 
 class GeneratorLoss(nn.Module):

@@ -59,24 +59,6 @@ class SRModel(BaseModel):
             self.sync_replicas()
         self.print_network(verbose=False)
 
-    def _shard(self, t):
-        """Reference semantics of `batch_size` (options/README.md:31: the GLOBAL batch, split over gpu_ids by
-        nn.DataParallel's scatter): a fed tensor that carries the global batch is cut to this rank's contiguous
-        shard; a tensor that already holds batch_size / world samples (a per-rank loader) is taken as is."""
-        world = self.dp.world_size
-        if world == 1 or not self.is_train:
-            return t
-        gb = self.opt["datasets"]["train"]["batch_size"]
-        if gb % world:
-            raise ValueError("batch_size %d is not divisible by the %d data-parallel ranks" % (gb, world))
-        per = gb // world
-        if t.shape[0] == gb:
-            return t[self.dp.rank * per:(self.dp.rank + 1) * per]
-        if t.shape[0] == per:
-            return t
-        raise ValueError("fed batch of %d samples is neither the global batch (%d) nor this rank's shard (%d)"
-                         % (t.shape[0], gb, per))
-
     def feed_data(self, data, need_HR=True):
         self.var_L = self._shard(data["LR"]).to(self.device, non_blocking=True)
         if need_HR:

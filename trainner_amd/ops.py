@@ -543,7 +543,7 @@ def tanh_bwd(g, y, gx):
 
 
 def gan_loss(pred, kind, target, out, grad=None):
-    """GANLoss against a constant label: kind 0 vanilla (BCE with logits), 1 lsgan (MSE); out[0] = mean loss."""
+    """GANLoss against a constant label: kind 0 vanilla (BCE with logits), 1 lsgan (MSE), 2 mean(pred); out[0] = mean loss."""
     hip.check(hip.load().tnr_gan_loss(pred.data_ptr(), pred.numel(), kind, float(target), out.data_ptr(), hip.ptr(grad), hip.stream()), "gan_loss")
 
 
