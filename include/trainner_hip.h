@@ -54,7 +54,8 @@ enum {
     TNR_PACK_FWD_S2D = 2,   /* [4][KoutP][4*KinP] (space-to-depth view of k4 s2)                           */
     TNR_PACK_DGRAD_S2 = 3,  /* [4 parities][4][KoutP=ci][KinP=co]                                          */
     TNR_PACK_COL_FWD = 4,   /* [1][KoutP][KinP = kh*kw*Cin]: column (ky*kw+kx)*Cin+ci of tnr_im2col          */
-    TNR_PACK_COL_DGRAD3 = 5,/* [1][KoutP=ci][KinP = 9*Cout]: column t*Cout+co <- W[co][ci][2-ty][2-tx]      */
+    TNR_PACK_COL_DGRAD3 = 5,/* [1][KoutP=ci][KinP = k*k*Cout]: column t*Cout+co <- W[co][ci][k-1-ty][k-1-tx]  */
+                            /* (any square k: the stride-1 data-gradient as im2col(g, pad k-1-p) x this)   */
     TNR_PACK_C4_FWD = 6,    /* [1][KoutP][48]: column 4*t + ci (Cin <= 4)        for TNR_CONV_3x3_C4             */
     TNR_PACK_C4_DGRAD3 = 7  /* [1][KoutP=ci][48]: column 4*t + co (Cout <= 4), taps flipped                     */
 };
@@ -223,10 +224,16 @@ int tnr_gconv_wgrad(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, tn
                     int32_t stride, int32_t pad, int32_t reflect, float *dw, float *db, float alpha, float beta, double *ws,
                     int64_t ws_bytes, void *stream);
 /* db = beta db + alpha sum_pixels g[p][c] (bias gradient of a layer whose weight gradient runs on another kernel);
- * ws: >= 64 * C doubles.                                                                                          */
+ * ws: >= 512 * C doubles (two-stage column sum in a fixed order; >= 64 * C selects the slow generic path).          */
 int tnr_bias_grad(tnr_view g, int64_t pixels, int32_t C, float *db, float alpha, float beta, double *ws, int64_t ws_bytes, void *stream);
 int tnr_pad2d(tnr_view x, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
 int tnr_unpad2d(tnr_view xp, tnr_view y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t mode, void *stream);
+/* dst[n,y,x,:] (+)= src[n, y+oy, x+ox, :] inside the source, 0 outside (zero-embedding at an offset / offset crop; acc != 0
+ * adds to dst): kernel geometries without their own tile run as shifted 3x3 windows of the 3x3 kernels -- the PatchGAN's 4x4
+ * stride-1 layers (discriminators.py:543-560: weight gradient = four windows) and the ResnetGenerator's 7x7 reflection-padded
+ * first / last convolutions (ResNet_arch.py:52-55,86-88: nine 3x3 blocks of taps).                                      */
+int tnr_window2d(tnr_view src, int32_t Hs, int32_t Ws, tnr_view dst, int32_t N, int32_t Hd, int32_t Wd, int32_t C, int32_t oy,
+                 int32_t ox, int32_t acc, void *stream);
 int tnr_tanh_fwd(const float *x, float *y, int64_t n, void *stream);
 int tnr_tanh_bwd(const float *g, const float *y, float *gx, int64_t n, void *stream);
 int tnr_gan_loss(const float *pred, int64_t n, int32_t type, float target, float *out, float *grad, void *stream);
@@ -316,6 +323,15 @@ int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const fl
 int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int64_t pixels, int32_t C,
                      const float *gamma, const float *save_mean, const float *save_invstd, float mslope,
                      float *dgamma, float *dbeta, float acc_beta, void *ws, void *stream);
+/* InstanceNorm2d without affine parameters or running statistics (the ResnetGenerator's norm layer, ResNet_arch.py:40-50 ->
+ * nn.InstanceNorm2d defaults) over a whole batch: the BatchNorm kernels with one statistics group per image.
+ * y = act((z - mean[n,c]) * invstd[n,c]); save_mean / save_invstd: [N * C].  bwd: gz from gy (masked by act'(y), slope mslope:
+ * 0 ReLU, 1 none).  ws: tnr_instnorm_workspace_bytes(N, C).                                                            */
+int64_t tnr_instnorm_workspace_bytes(int32_t N, int32_t C);
+int tnr_instnorm_fwd(tnr_view z, tnr_view y, int32_t N, int64_t pixels_per_image, int32_t C, float eps, float *save_mean,
+                     float *save_invstd, int32_t act, float slope, void *ws, void *stream);
+int tnr_instnorm_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int32_t N, int64_t pixels_per_image, int32_t C,
+                     const float *save_mean, const float *save_invstd, float mslope, void *ws, void *stream);
 
 /* --- classifier (nn.Linear, discriminators.py:40-45) ------------------------------------------- */
 int tnr_linear_fwd(const float *x, const float *w, const float *b, float *y, int32_t N, int32_t In,

@@ -97,17 +97,22 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
     w = None if wp.kind == ops.PACK_DENSE_DGRAD else _mm(wp.w.detach())
     if wp.kind == ops.PACK_DENSE_DGRAD:
         out = _dense_dgrad(xin, wp, y.C)
-    elif wp.kind == ops.PACK_FWD:
+    elif wp.kind in (ops.PACK_FWD, ops.PACK_C4_FWD):
         xi = _fit(xin, w.shape[1])
         if mode == ops.CONV_3x3_UP2:
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
         out = F.conv2d(xi, w, None, padding=1)
     elif wp.kind == ops.PACK_FWD_S2D:
         out = F.conv2d(_fit(xin, w.shape[1]), w, None, stride=2, padding=1)
-    elif wp.kind == ops.PACK_DGRAD_3x3:
+    elif wp.kind in (ops.PACK_DGRAD_3x3, ops.PACK_C4_DGRAD3):
         out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, padding=1)
     else:
         out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, stride=2, padding=1)
+    _epilogue(out, y, bias, act, slope, alpha, r1, r1_ch, beta1, r2, alpha2, mask, m_lo, m_hi, m_slope)
+
+
+def _epilogue(out, y, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None, beta1=1.0, r2=None, alpha2=1.0,
+              mask=None, m_lo=0, m_hi=None, m_slope=0.2):
     out = _fit(out, y.C)
     if bias is not None:
         out = out + _fit(bias.detach().view(1, -1, 1, 1), y.C)
@@ -126,6 +131,47 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
         mm = _mask(_nchw(mask)[:, m_lo:hi], m_slope)
         out = torch.cat([out[:, :m_lo], out[:, m_lo:hi] * mm, out[:, hi:]], 1)
     y.dense().copy_(out.permute(0, 2, 3, 1))
+
+
+def conv_col(x, wp, y, k, stride=1, pad=1, **epi):
+    xin, w = _mm(_nchw(x)), _mm(wp.w.detach())
+    if wp.kind == ops.PACK_COL_FWD:
+        out = F.conv2d(_fit(xin, w.shape[1]), w, None, stride=stride, padding=pad)
+    else:       # PACK_COL_DGRAD3: x is the gradient of the layer's output, pad = k - 1 - (the layer's padding)
+        out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, stride=1, padding=k - 1 - pad)
+    _epilogue(out, y, **epi)
+
+
+def window2d(src, dst, oy, ox, acc=False):
+    s = src.dense()
+    d = dst.dense()
+    if not acc:
+        d.zero_()
+    y0, x0 = max(0, -oy), max(0, -ox)
+    y1, x1 = min(dst.H, src.H - oy), min(dst.W, src.W - ox)
+    if y1 > y0 and x1 > x0:
+        d[:, y0:y1, x0:x1].add_(s[:, y0 + oy:y1 + oy, x0 + ox:x1 + ox])
+
+
+def conv_thin(x, w, y, bias=None, alpha=1.0, dgrad=False):
+    xin, wt = _nchw(x), w.detach()
+    out = F.conv_transpose2d(_fit(xin, wt.shape[0]), wt, None, padding=1) if dgrad else F.conv2d(_fit(xin, wt.shape[1]), wt, None, padding=1)
+    if bias is not None:
+        out = out + bias.detach().view(1, -1, 1, 1)
+    ops.View(y.buf, y.coff, out.shape[1]).dense().copy_((out * alpha).permute(0, 2, 3, 1))
+
+
+def wgrad_thin(big, small4, dw, db, flip, alpha=1.0, beta=1.0):
+    """flip False: layer small(<= 3 ch) -> big: x = small4, g = big;  flip True: layer big -> small: x = big, g = small4."""
+    xv, gv = (big, small4) if flip else (small4, big)
+    O, I = dw.shape[0], dw.shape[1]
+    xin, gin = _nchw(xv)[:, :I], _nchw(gv)[:, :O]
+    with torch.enable_grad():
+        w0 = torch.zeros(O, I, 3, 3, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(xin, w0, None, padding=1), w0, gin)
+    dw.copy_(beta * dw + alpha * gw)
+    if db is not None:
+        db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
 
 
 def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
@@ -325,6 +371,29 @@ def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta
         dbeta.copy_(acc_beta * dbeta + s)
 
 
+def instnorm_fwd(z, y, save_mean, save_invstd, eps=1e-5, act=ops.ACT_NONE, slope=0.0):
+    zin = _nchw(z)
+    mean = zin.mean(dim=(2, 3))
+    var = zin.var(dim=(2, 3), unbiased=False)
+    save_mean.copy_(mean.reshape(-1))
+    save_invstd.copy_((1.0 / torch.sqrt(var + eps)).reshape(-1))
+    out = (zin - mean[:, :, None, None]) * (1.0 / torch.sqrt(var + eps))[:, :, None, None]
+    out = F.leaky_relu(out, slope) if act == ops.ACT_LRELU else (F.relu(out) if act == ops.ACT_RELU else out)
+    y.dense().copy_(out.permute(0, 2, 3, 1))
+
+
+def instnorm_bwd(gy, y, z, gz, save_mean, save_invstd, mslope=1.0):
+    g = _nchw(gy) * _mask(_nchw(y), mslope)
+    zin = _nchw(z)
+    N, C = zin.shape[0], zin.shape[1]
+    n = zin.shape[2] * zin.shape[3]
+    mean, inv = save_mean.view(N, C, 1, 1), save_invstd.view(N, C, 1, 1)
+    xm = zin - mean
+    s, dot = g.sum(dim=(2, 3), keepdim=True), (g * xm).sum(dim=(2, 3), keepdim=True)
+    dz = (g - s / n - xm * (dot * inv * inv / n)) * inv
+    gz.dense().copy_(dz.permute(0, 2, 3, 1))
+
+
 def linear_fwd(x, w, b, y, act=ops.ACT_NONE, slope=0.2):
     o = F.linear(x, w.detach(), None if b is None else b.detach())
     y.copy_(F.leaky_relu(o, slope) if act == ops.ACT_LRELU else o)
@@ -413,7 +482,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
 
 
-_NAMES = ["bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

@@ -826,3 +826,87 @@ def test_pad_tanh_ganloss_kernels():
     out = torch.zeros(1, device=DEV)
     ops.gan_loss(p.to(DEV), 2, 0.0, out, None)            # kind 2: mean of the logits (D_real / D_fake log entries)
     assert abs(float(out) - float(p.mean())) < 1e-6
+
+
+@pytest.mark.parametrize("case", [(2, 31, 31, 64, 96), (1, 32, 32, 256, 512), (3, 16, 20, 32, 4)])
+def test_conv4x4_s1_through_the_patch_matrix(case):
+    """The PatchGAN's 4x4 stride-1 pad-1 layers (discriminators.py:543-560) on the matrix cores: forward and data-gradient as
+    tnr_im2col + the 1x1 GEMM kernel over the natural image shape (ops.conv_col; pad 2 + flipped taps for the gradient),
+    tnr_window2d (zero-embedding at an offset), and the weight gradient as four shifted 3x3 windows (_K4S1.wgrad)."""
+    ops = _ops()
+    from trainner_amd.models.modules.architectures import block as B
+    from trainner_amd.models.modules.architectures.discriminators import _K4S1
+    N, H, W, Cin, Cout = case
+    conv = B.Conv2dHIP(Cin, 1 if Cout == 4 else Cout, 4, 1).to(DEV)
+    co_real = conv.out_channels
+    w = rnd(co_real, Cin, 4, 4, seed=402, lo=-0.05, hi=0.05)
+    b = rnd(co_real, seed=403)
+    with torch.no_grad():
+        conv.weight.copy_(w.to(DEV))
+        conv.bias.copy_(b.to(DEV))
+    conv.weight.grad = torch.zeros_like(conv.weight)
+    conv.bias.grad = torch.zeros_like(conv.bias)
+    x = rnd(N, Cin, H, W, seed=401)
+    g = rnd(N, co_real, H - 1, W - 1, seed=404)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=1)
+    ref.backward(g)
+    packer = ops.WeightPacker(torch.device(DEV))
+    op = _K4S1(conv, packer, Cin)
+    op.refresh()
+    packer.run()
+    xb = ops.View(nhwc_buf(x))
+    y = torch.zeros((N, H - 1, W - 1, Cout), device=DEV)
+    op.fwd(xb, ops.View(y))
+    close(to_nchw(y, 0, co_real), ref.detach(), what="k4s1 fwd")
+    gb = ops.View(nhwc_buf(g, ctot=Cout, fill=0.0))
+    gx = torch.zeros((N, H, W, Cin), device=DEV)
+    op.dgrad(gb, ops.View(gx))
+    close(to_nchw(gx, 0, Cin), xr.grad, what="k4s1 dgrad")
+    op.wgrad(xb, gb)
+    close(conv.weight.grad.cpu(), wr.grad, tol=5e-5, what="k4s1 wgrad")
+    close(conv.bias.grad.cpu(), br.grad, tol=5e-5, what="k4s1 bias grad")
+    # window2d on its own: offset crop and offset embed
+    src = rnd(2, 8, 5, 7, seed=405)
+    dst = torch.full((2, 6, 9, 8), 3.0, device=DEV)
+    ops.window2d(ops.View(nhwc_buf(src)), ops.View(dst), -1, 2)
+    exp = torch.zeros(2, 8, 6, 9)
+    exp[:, :, 1:6, 0:5] = src[:, :, 0:5, 2:7]
+    assert torch.equal(to_nchw(dst, 0, 8), exp)
+
+
+@pytest.mark.parametrize("shape", [(3, 17, 23, 64), (2, 64, 64, 256), (16, 8, 8, 16)])
+def test_instance_norm_grouped_launch(shape):
+    """tnr_instnorm_fwd / bwd (InstanceNorm2d without affine, ResNet_arch.py:40-50) over a batch in one set of launches,
+    with the fused ReLU, against F.instance_norm under autograd."""
+    ops = _ops()
+    N, H, W, C = shape
+    x = rnd(N, C, H, W, seed=501) * 2.0 + rnd(1, C, 1, 1, seed=502)
+    g = rnd(N, C, H, W, seed=503)
+    for relu in (True, False):
+        xr = x.clone().requires_grad_(True)
+        ref = F.instance_norm(xr, eps=1e-5)
+        ref = F.relu(ref) if relu else ref
+        ref.backward(g)
+        zb = ops.View(nhwc_buf(x))
+        y = torch.zeros((N, H, W, C), device=DEV)
+        mean, inv = torch.zeros(N * C, device=DEV), torch.zeros(N * C, device=DEV)
+        ops.instnorm_fwd(zb, ops.View(y), mean, inv, act=ops.ACT_RELU if relu else ops.ACT_NONE, slope=0.0)
+        close(to_nchw(y, 0, C), ref.detach(), tol=1e-5, what="instnorm fwd")
+        close(mean.view(N, C).cpu(), x.mean(dim=(2, 3)), tol=1e-6, what="instnorm mean")
+        gz = torch.zeros((N, H, W, C), device=DEV)
+        ops.instnorm_bwd(ops.View(nhwc_buf(g)), ops.View(y), zb, ops.View(gz), mean, inv, mslope=0.0 if relu else 1.0)
+        close(to_nchw(gz, 0, C), xr.grad, tol=2e-5, what="instnorm bwd")
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 17, 64), (16, 64, 64, 128), (1, 5, 7, 12)])
+def test_bias_grad_column_sum(shape):
+    """tnr_bias_grad: db = beta db + alpha sum over pixels (two-stage, fixed order), on a channel window of a wider buffer."""
+    ops = _ops()
+    N, H, W, C = shape
+    g = rnd(N, C, H, W, seed=601)
+    buf = nhwc_buf(g, ctot=C + 8, coff=4)
+    db = torch.full((C,), 2.0, device=DEV)
+    ops.bias_grad(ops.View(buf, 4, C), db, alpha=0.5, beta=1.0)
+    close(db.cpu(), 2.0 + 0.5 * g.double().sum(dim=(0, 2, 3)).float(), tol=2e-6, what="bias_grad")

@@ -1,0 +1,113 @@
+"""Variant bench (NOT the headline): images/sec of the full G+D step of the image-to-image models of BASELINE.json configs[4]
+-- Pix2PixModel / CycleGANModel.optimize_parameters, 256 x 256, ResNet-9 generator (ngf 64, InstanceNorm), PatchGAN
+(ndf 64), fp32 on the matrix cores, synthetic znorm images resident in HBM, random-init weights.
+
+    python tools/bench_i2i.py --model pix2pix|cyclegan [--batch 16] [--steps 8] [--warmup 2]
+
+`step_tflops` uses the convolution FLOP of the step counted from the layer table below (2*MAC, real channels; transposed
+and stride-2 layers by their true tap counts): forward G 99.1 GFLOP/img, forward D 6.3 (3 ch) / 6.4 (6 ch) GFLOP/img;
+a pass that needs weight + data gradients costs 3x its forward, data-gradient only 2x.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def g_fwd_flop(size=256, ngf=64, nb=9, nc=3):
+    s = size
+    f = 2 * s * s * 49 * nc * ngf                                   # c7s1-64
+    f += 2 * (s // 2) ** 2 * 9 * ngf * 2 * ngf                      # d128
+    f += 2 * (s // 4) ** 2 * 9 * 2 * ngf * 4 * ngf                  # d256
+    f += nb * 2 * 2 * (s // 4) ** 2 * 9 * (4 * ngf) ** 2            # residual blocks
+    f += 2 * (s // 4) ** 2 * 9 * 4 * ngf * 2 * ngf                  # u128 (each input pixel meets all 9 taps)
+    f += 2 * (s // 2) ** 2 * 9 * 2 * ngf * ngf                      # u64
+    f += 2 * s * s * 49 * ngf * nc                                  # c7s1-3
+    return f
+
+
+def d_fwd_flop(size=256, ndf=64, in_nc=3):
+    f, s, c = 0, size, in_nc
+    for co in (ndf, 2 * ndf, 4 * ndf):
+        s //= 2
+        f += 2 * s * s * 16 * c * co
+        c = co
+    s -= 1
+    f += 2 * s * s * 16 * c * 8 * ndf
+    f += 2 * (s - 1) ** 2 * 16 * 8 * ndf
+    return f
+
+
+def step_flop(model, size):
+    g, d3, d6 = g_fwd_flop(size), d_fwd_flop(size, in_nc=3), d_fwd_flop(size, in_nc=6)
+    if model == "pix2pix":
+        # G fwd + G bwd (w + d grads); D step: 2 passes fwd + full bwd (the fake pass needs no input gradient: ~3x);
+        # G step through D: fwd + data-gradient
+        return 3 * g + 2 * 3 * d6 + 2 * d6
+    # cyclegan: 4 G passes in forward() + 2 identity passes, all with both gradients; per D: G-side fwd + dgrad, D-side 2 x full
+    return 6 * 3 * g + 2 * (2 * d3 + 2 * 3 * d3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", choices=["pix2pix", "cyclegan"], default="pix2pix")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--amp", action="store_true")
+    args = ap.parse_args()
+    from oracle import ref_harness          # (only its YAML writer: test infrastructure shared with the parity tests)
+    from trainner_amd import hip, ops
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    hip.require_device()
+    dev = torch.device("cuda", 0)
+    root = tempfile.mkdtemp(prefix="tnr_bench_i2i_")
+    yml = ref_harness.i2i_yaml(name="bench_" + args.model, model=args.model, batch=args.batch, crop=args.size, n_blocks=9, ngf=64,
+                               ndf=64, pixel_weight=100.0 if args.model == "pix2pix" else 10.0,
+                               lambda_identity=0.5 if args.model == "cyclegan" else None,
+                               pool_size=50 if args.model == "cyclegan" else 0, lr_scheme="Linear", out_root=root,
+                               gpu_ids="[0]", amp=args.amp)
+    torch.manual_seed(1234)
+    model = create_model(options.parse(yml, is_train=True), verbose=False)
+    g = torch.Generator().manual_seed(7)
+    data = {"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
+            "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev), "A_path": ["a"] * args.batch}
+    step = 0
+    for _ in range(args.warmup):
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log = model.get_current_log()
+    imgs = args.batch * args.steps
+    fl = step_flop(args.model, args.size)
+    print(json.dumps({
+        "metric": "images/sec (G+D step), %s %dx%d" % (args.model, args.size, args.size), "value": round(imgs / dt, 2), "unit": "img/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
+        "higher_is_better": True, "dtype": "bf16" if args.amp else "f32", "data": "synthetic", "variant": True,
+        "config": {"workload": "%s: ResnetGenerator-9 (ngf 64, InstanceNorm) + PatchGAN (ndf 64), batch %d, %dx%d, "
+                               "vanilla GAN (standard form) + L1%s (BASELINE configs[4])"
+                               % (args.model, args.batch, args.size, args.size, ", identity 0.5, pool 50" if args.model == "cyclegan" else "")},
+        "conv_gflop_per_img": round(fl / 1e9, 1), "step_tflops": round(fl * imgs / dt / 1e12, 2),
+        "losses": {k: round(v, 5) for k, v in log.items()}}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,5 @@
+cd /root/repo
+mkdir -p gpurun_out
+( time timeout 900 python -m pytest tests/test_gpu_i2i.py tests/test_gpu_kernels.py tests/test_gpu_nets.py -x -q -k "i2i or ganloss or k4s1 or conv4x4_s1 or patchgan" ) > gpurun_out/r02c_i2i_tests.log 2>&1
+tail -5 gpurun_out/r02c_i2i_tests.log
+bash tools/gpu_prof_i2i.sh pix2pix 16

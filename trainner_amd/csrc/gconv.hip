@@ -264,6 +264,73 @@ __global__ void __launch_bounds__(256) gan_loss_kernel(const float *pred, int64_
     if (threadIdx.x == 0) out[0] = (float)(sh[0] / (double)n);
 }
 
+// dst[n, y, x, c] (+)= src[n, y + oy, x + ox, c] where that lies inside the source, else 0 (float4 per thread; acc: added to dst): zero-embedding of a
+// gradient at an offset (oy, ox < 0) and offset crops, for the convolutions that run as shifted windows of another geometry.
+__global__ void window2d_kernel(const float *src, int s_ct, int s_co, int Hs, int Ws, float *dst, int d_ct, int d_co, int N, int Hd,
+                                int Wd, int C, int oy, int ox, int acc) {
+    const int c4n = C / 4;
+    const int64_t total = (int64_t)N * Hd * Wd * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        int64_t q = e / c4n;
+        const int x = (int)(q % Wd);
+        q /= Wd;
+        const int y = (int)(q % Hd);
+        const int n = (int)(q / Hd);
+        const int sy = y + oy, sx = x + ox;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws)
+            v = *reinterpret_cast<const f32x4 *>(src + (((size_t)n * Hs + sy) * Ws + sx) * s_ct + s_co + c4 * 4);
+        float *dp = dst + (((size_t)n * Hd + y) * Wd + x) * d_ct + d_co + c4 * 4;
+        if (acc) v += *reinterpret_cast<const f32x4 *>(dp);
+        *reinterpret_cast<f32x4 *>(dp) = v;
+    }
+}
+
+// ---- bias gradient: column sums of an NHWC view.  partial[b][c] = sum over the block's contiguous pixel range (thread =
+// (pixel lane, 4 channels), double accumulation, lanes combined through LDS in lane order); colsum_final adds the blocks in
+// index order: fixed summation order, bit-reproducible.
+constexpr int CS_BLOCKS = 512;
+
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float *g, int ct, int co, int64_t pixels, int C, int64_t ppb, double *partial) {
+    extern __shared__ double cs_sh[];      // [lanes][C]
+    const int G = C / 4, lanes = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, pl = tid / G;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    const int64_t p1 = p0 + ppb < pixels ? p0 + ppb : pixels;
+    if (pl < lanes) {
+        double s[4] = {0, 0, 0, 0};
+        for (int64_t p = p0 + pl; p < p1; p += lanes) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(g + p * ct + co + cg * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] += (double)v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs_sh[(size_t)pl * C + cg * 4 + k] = s[k];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double a = 0;
+        for (int l = 0; l < lanes; ++l) a += cs_sh[(size_t)l * C + c];
+        partial[(size_t)blockIdx.x * C + c] = a;
+    }
+}
+
+__global__ void colsum_final_kernel(const double *partial, int nblocks, int C, float *db, float alpha, float beta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        s0 += partial[(size_t)b * C + c];
+        s1 += partial[(size_t)(b + 1) * C + c];
+        s2 += partial[(size_t)(b + 2) * C + c];
+        s3 += partial[(size_t)(b + 3) * C + c];
+    }
+    for (; b < nblocks; ++b) s0 += partial[(size_t)b * C + c];
+    db[c] = (beta != 0.f ? beta * db[c] : 0.f) + alpha * (float)((s0 + s1) + (s2 + s3));
+}
+
 inline unsigned g1d(int64_t n) {
     int64_t b = tnr_cdiv64(n, 256);
     return (unsigned)(b > 65535 ? 65535 : (b < 1 ? 1 : b));
@@ -327,11 +394,22 @@ extern "C" int tnr_bias_grad(tnr_view g, int64_t pixels, int32_t C, float *db, f
                              void *stream) {
     TNR_REQUIRE(v_ok(g) && db && ws && pixels >= 1 && C >= 1 && ws_bytes >= (int64_t)GW_SPLITS * C * (int64_t)sizeof(double),
                 "bias_grad: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if ((C % 4) == 0 && C / 4 <= 256 && (g.ctot % 4) == 0 && (g.coff % 4) == 0 && ws_bytes >= (int64_t)CS_BLOCKS * C * (int64_t)sizeof(double)) {
+        const int lanes = 256 / (C / 4);
+        int64_t want = tnr_cdiv64(pixels, (int64_t)lanes * 16);
+        if (want > CS_BLOCKS) want = CS_BLOCKS;
+        const int64_t ppb = tnr_cdiv64(pixels, want);
+        const int nblocks = (int)tnr_cdiv64(pixels, ppb);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), (size_t)lanes * C * sizeof(double), s, g.ptr, g.ctot, g.coff,
+                           pixels, C, ppb, ws);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(tnr_cdiv(C, 256)), dim3(256), 0, s, ws, nblocks, C, db, alpha, beta);
+        return tnr_check_launch("bias_grad");
+    }
     GcK a = {};
     a.y = g.ptr; a.y_ct = g.ctot; a.y_co = g.coff;
     a.N = 1; a.Ho = 1; a.Wo = (int)pixels; a.H = 1; a.W = (int)pixels; a.Cin = 0; a.Cout = C; a.k = 1; a.stride = 1;
     TNR_REQUIRE(pixels < (1LL << 31), "bias_grad: too many pixels");
-    hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gconv_wgrad_partial_kernel, dim3(g1d(C), GW_SPLITS), dim3(256), 0, s, a, ws, ws);
     hipLaunchKernelGGL(gconv_wgrad_final_kernel, dim3(g1d(C)), dim3(256), 0, s, ws, ws, (int64_t)0, C, db, db, alpha, beta);
     return tnr_check_launch("bias_grad");
@@ -353,6 +431,16 @@ extern "C" int tnr_unpad2d(tnr_view xp, tnr_view y, int32_t N, int32_t H, int32_
     hipLaunchKernelGGL(unpad2d_kernel, dim3(g1d((int64_t)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, xp.ptr, xp.ctot, xp.coff,
                        y.ptr, y.ctot, y.coff, N, H, W, C, pad, mode);
     return tnr_check_launch("unpad2d");
+}
+
+extern "C" int tnr_window2d(tnr_view src, int32_t Hs, int32_t Ws, tnr_view dst, int32_t N, int32_t Hd, int32_t Wd, int32_t C, int32_t oy,
+                            int32_t ox, int32_t acc, void *stream) {
+    TNR_REQUIRE(v_ok(src) && v_ok(dst) && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && (C % 4) == 0 && (src.ctot % 4) == 0 &&
+                    (src.coff % 4) == 0 && (dst.ctot % 4) == 0 && (dst.coff % 4) == 0,
+                "window2d: bad arguments");
+    hipLaunchKernelGGL(window2d_kernel, dim3(g1d((int64_t)N * Hd * Wd * (C / 4))), dim3(256), 0, (hipStream_t)stream, src.ptr, src.ctot,
+                       src.coff, Hs, Ws, dst.ptr, dst.ctot, dst.coff, N, Hd, Wd, C, oy, ox, acc);
+    return tnr_check_launch("window2d");
 }
 
 extern "C" int tnr_tanh_fwd(const float *x, float *y, int64_t n, void *stream) {

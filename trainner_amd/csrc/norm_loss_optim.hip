@@ -32,6 +32,16 @@ __global__ void bn_partial_kernel(const float *z, int z_ct, int z_co, const floa
                                   int y_ct, int y_co, const float *mean, float mslope, int64_t pixels, int C,
                                   int64_t pix_per_block, double *partial) {
     extern __shared__ double sh_d[];  // [lanes][C][2]
+    {   // blockIdx.y = statistics group (InstanceNorm: one image; BatchNorm launches have one group): `pixels` per group
+        const size_t go = (size_t)blockIdx.y * (size_t)pixels;
+        z += go * z_ct;
+        if (MODE == 1) {
+            gy += go * g_ct;
+            y += go * y_ct;
+            mean += (size_t)blockIdx.y * C;
+        }
+        partial += (size_t)blockIdx.y * gridDim.x * C * 2;
+    }
     const int G = C / 4;
     const int lanes = 256 / G;
     const int tid = threadIdx.x;
@@ -107,6 +117,9 @@ __global__ void __launch_bounds__(256)
 bn_fwd_finalize_kernel(const double *partial, int nblocks, int C, int64_t pixels, float *running_mean, float *running_var,
                        int64_t *num_batches, float momentum, float eps, float *save_mean, float *save_invstd) {
     __shared__ double sh[8][2][33];
+    partial += (size_t)blockIdx.y * nblocks * C * 2;       // statistics group (see bn_partial_kernel)
+    save_mean += (size_t)blockIdx.y * C;
+    save_invstd += (size_t)blockIdx.y * C;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + el;
     double s, ss;
@@ -132,14 +145,19 @@ __global__ void bn_fwd_apply_kernel(const float *z, int z_ct, int z_co, float *y
                                     float slope) {
     const int G = C / 4;
     const int64_t total = pixels * G;
+    z += (size_t)blockIdx.y * (size_t)pixels * z_ct;       // statistics group (see bn_partial_kernel)
+    y += (size_t)blockIdx.y * (size_t)pixels * y_ct;
+    mean += (size_t)blockIdx.y * C;
+    invstd += (size_t)blockIdx.y * C;
+    const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(e % G);
         const int64_t p = e / G;
         const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + p * z_ct + z_co + cg * 4);
         const f32x4 mu = *reinterpret_cast<const f32x4 *>(mean + cg * 4);
         const f32x4 is = *reinterpret_cast<const f32x4 *>(invstd + cg * 4);
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cg * 4);
-        const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cg * 4);
+        const f32x4 ga = gamma ? *reinterpret_cast<const f32x4 *>(gamma + cg * 4) : one4;      // (no affine: InstanceNorm)
+        const f32x4 be = beta ? *reinterpret_cast<const f32x4 *>(beta + cg * 4) : zero4;
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = tnr_act(((zv[k] - mu[k]) * is[k]) * ga[k] + be[k], act, slope);
@@ -151,6 +169,9 @@ __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(const double *partial, int nblocks, int C, const float *invstd, double *sums, float *dgamma,
                        float *dbeta, float acc_beta) {
     __shared__ double sh[8][2][33];
+    partial += (size_t)blockIdx.y * nblocks * C * 2;       // statistics group (see bn_partial_kernel)
+    invstd += (size_t)blockIdx.y * C;
+    sums += (size_t)blockIdx.y * 2 * C;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + el;
     double s, dot;
@@ -174,6 +195,16 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
     const int G = C / 4;
     const int64_t total = pixels * G;
     const float inv_n = 1.f / (float)pixels;
+    {   // statistics group (see bn_partial_kernel)
+        const size_t go = (size_t)blockIdx.y * (size_t)pixels;
+        gy += go * g_ct;
+        y += go * y_ct;
+        z += go * z_ct;
+        gz += go * o_ct;
+        mean += (size_t)blockIdx.y * C;
+        invstd += (size_t)blockIdx.y * C;
+        sums += (size_t)blockIdx.y * 2 * C;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cg = (int)(e % G);
         const int64_t p = e / G;
@@ -188,7 +219,7 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
             const float gmean = (float)sums[2 * c + 0] * inv_n;
             const float kk = (float)sums[2 * c + 1] * is * is * inv_n;
             const float g = gv[k] * (yv[k] > 0.f ? 1.f : mslope);
-            o[k] = (g - gmean - (zv[k] - mean[c]) * kk) * is * gamma[c];
+            o[k] = (g - gmean - (zv[k] - mean[c]) * kk) * is * (gamma ? gamma[c] : 1.f);
         }
         *reinterpret_cast<f32x4 *>(gz + p * o_ct + o_co + cg * 4) = o;
     }
@@ -452,6 +483,53 @@ extern "C" int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz
                        y.ctot, y.coff, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, gamma, save_mean,
                        save_invstd, sums, mslope);
     return tnr_check_launch("bn_train_bwd");
+}
+
+// InstanceNorm2d (no affine, no running statistics: ResNet_arch.py:40-50) forward / backward over a batch in ONE set of
+// launches: the BatchNorm kernels with one statistics group per image (gridDim.y = N), optional ReLU / LeakyReLU fused.
+extern "C" int64_t tnr_instnorm_workspace_bytes(int32_t N, int32_t C) {
+    return (int64_t)N * ((int64_t)RED_BLOCKS * C * 2 + 2 * (int64_t)C) * (int64_t)sizeof(double);
+}
+
+extern "C" int tnr_instnorm_fwd(tnr_view z, tnr_view y, int32_t N, int64_t pixels, int32_t C, float eps, float *save_mean,
+                                float *save_invstd, int32_t act, float slope, void *ws, void *stream) {
+    TNR_REQUIRE(z.ptr && y.ptr && save_mean && save_invstd && ws && N > 0 && N <= 65535 && pixels > 0, "instnorm_fwd: bad arguments");
+    TNR_REQUIRE((C % 4) == 0 && C / 4 <= 256, "instnorm_fwd: unsupported C %d", C);
+    int nblocks; int64_t ppb; size_t lds;
+    bn_plan(pixels, C, nblocks, ppb, lds);
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)ws;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblocks, N), dim3(256), lds, s, z.ptr, z.ctot, z.coff, nullptr, 0, 0, nullptr, 0,
+                       0, nullptr, 0.f, pixels, C, ppb, partial);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(tnr_cdiv(C, 32), N), dim3(256), 0, s, partial, nblocks, C, pixels,
+                       nullptr, nullptr, nullptr, 0.f, eps, save_mean, save_invstd);
+    int64_t gx = tnr_cdiv64(pixels * (C / 4), 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3((unsigned)gx, N), dim3(256), 0, s, z.ptr, z.ctot, z.coff, y.ptr,
+                       y.ctot, y.coff, pixels, C, nullptr, nullptr, save_mean, save_invstd, act, slope);
+    return tnr_check_launch("instnorm_fwd");
+}
+
+extern "C" int tnr_instnorm_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int32_t N, int64_t pixels, int32_t C,
+                                const float *save_mean, const float *save_invstd, float mslope, void *ws, void *stream) {
+    TNR_REQUIRE(gy.ptr && y.ptr && z.ptr && gz.ptr && save_mean && save_invstd && ws && N > 0 && N <= 65535 && pixels > 0,
+                "instnorm_bwd: bad arguments");
+    TNR_REQUIRE((C % 4) == 0 && C / 4 <= 256, "instnorm_bwd: unsupported C %d", C);
+    int nblocks; int64_t ppb; size_t lds;
+    bn_plan(pixels, C, nblocks, ppb, lds);
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)ws;
+    double *sums = partial + (size_t)N * RED_BLOCKS * C * 2;
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(nblocks, N), dim3(256), lds, s, z.ptr, z.ctot, z.coff, gy.ptr, gy.ctot, gy.coff,
+                       y.ptr, y.ctot, y.coff, save_mean, mslope, pixels, C, ppb, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tnr_cdiv(C, 32), N), dim3(256), 0, s, partial, nblocks, C, save_invstd, sums,
+                       nullptr, nullptr, 0.f);
+    int64_t gx = tnr_cdiv64(pixels * (C / 4), 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)gx, N), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
+                       y.ctot, y.coff, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, nullptr, save_mean,
+                       save_invstd, sums, mslope);
+    return tnr_check_launch("instnorm_bwd");
 }
 
 extern "C" int tnr_linear_fwd(const float *x, const float *w, const float *b, float *y, int32_t N, int32_t In, int32_t Out,

@@ -53,8 +53,8 @@ extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, 
             n = (int64_t)ko * ki;
             break;
         case TNR_PACK_COL_DGRAD3:
-            TNR_REQUIRE(kh == 3 && kw == 3, "pack col dgrad3: kernel must be 3x3");
-            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(9 * Cout, TNR_CK);
+            TNR_REQUIRE(kh == kw && kh >= 1, "pack col dgrad: kernel must be square");
+            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(kh * kw * Cout, TNR_CK);
             n = (int64_t)ko * ki;
             break;
         case TNR_PACK_C4_FWD:
@@ -113,7 +113,7 @@ __global__ void pack_weights_kernel(const tnr_pack_item *items) {
             const int v_ = (int)(e % ki);
             const int ci = (int)(e / ki);
             const int t = v_ / Cout, co = v_ - t * Cout;
-            if (ci < Cin && t < 9) v = it.w[(((size_t)co * Cin + ci) * 3 + (2 - t / 3)) * 3 + (2 - t % 3)];
+            if (ci < Cin && t < kh * kw) v = it.w[(((size_t)co * Cin + ci) * kh + (kh - 1 - t / kw)) * kw + (kw - 1 - t % kw)];
         } else if (it.kind == TNR_PACK_C4_FWD) {       // [co][4*t + ci]
             const int v_ = (int)(e % ki);
             const int co = (int)(e / ki);

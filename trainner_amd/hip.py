@@ -96,6 +96,7 @@ _SIGS = {
     "tnr_bias_grad": (c_i, [CView, c_l, c_i, c_p, c_f, c_f, c_p, c_l, c_p]),
     "tnr_pad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_unpad2d": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "tnr_window2d": (c_i, [CView, c_i, c_i, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "tnr_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "tnr_tanh_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "tnr_gan_loss": (c_i, [c_p, c_l, c_i, c_f, c_p, c_p, c_p]),
@@ -124,6 +125,9 @@ _SIGS = {
     "tnr_bn_workspace_bytes": (c_l, [c_i]),
     "tnr_bn_train_fwd": (c_i, [CView, CView, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_i, c_f, c_p, c_p]),
     "tnr_bn_train_bwd": (c_i, [CView, CView, CView, CView, c_l, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]),
+    "tnr_instnorm_workspace_bytes": (c_l, [c_i, c_i]),
+    "tnr_instnorm_fwd": (c_i, [CView, CView, c_i, c_l, c_i, c_f, c_p, c_p, c_i, c_f, c_p, c_p]),
+    "tnr_instnorm_bwd": (c_i, [CView, CView, CView, CView, c_i, c_l, c_i, c_p, c_p, c_f, c_p, c_p]),
     "tnr_linear_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "tnr_linear_bwd": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     "tnr_reduce_workspace_bytes": (c_l, []),

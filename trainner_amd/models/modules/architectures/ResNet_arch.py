@@ -13,8 +13,12 @@ Kernel mapping (all fp32 NHWC):
   * stride-2 3x3 convolutions and the transposed convolutions: the 4x4 stride-2 MFMA kernels with the 3x3 taps zero-extended
     to 4x4 (3x3 s2 p1 == 4x4 s2 p1 with a zero fourth row / column; ConvTranspose2d(k3,s2,p1,op1) == the data-gradient of
     that convolution, its input gradient == the forward, its weight gradient == the weight gradient with roles swapped);
-  * the two 7x7 image-side convolutions: generic convolution on the vector ALUs (csrc/gconv.hip);
-  * normalisation: the BatchNorm-train kernels (per image for InstanceNorm), ReLU fused; Tanh as one pass.
+  * the two 7x7 reflection-padded image-side convolutions: nine 3x3 blocks of taps (_K7Image) on the 3x3 kernels built for
+    <= 4-channel image layers -- the taps-in-K MFMA mode on the feature side, the vector-ALU thin kernels on the image side --
+    over shifted copies of the 4-channel operand (tnr_window2d); the generic kernels of csrc/gconv.hip are the fallback for
+    channel counts those kernels do not take;
+  * normalisation: the BatchNorm-train kernels (InstanceNorm: one statistics group per image in the same launches:
+    tnr_instnorm_*), ReLU fused; Tanh as one pass.
 """
 import torch
 import torch.nn as nn
@@ -80,6 +84,108 @@ class _Padded4x4:
         self.weight.grad.add_(self.dw4[:, :, :3, :3])
 
 
+_K7_BLOCKS = tuple((by, bx) for by in (0, 3, 4) for bx in (0, 3, 4))     # first tap of each 3x3 block; a block at 4 owns tap 6 only
+
+
+def _k7_first(b):
+    return 2 if b == 4 else 0
+
+
+class _K7Image:
+    """A 7x7 stride-1 convolution over a ReflectionPad2d(3) input with a <= 4-channel image on one side (ResNet_arch.py:52-55:
+    image -> ngf, :86-88: ngf -> image), as the sum of nine 3x3 blocks of its taps: with x_p the reflection-padded input,
+    y[p] = sum_k w[k] x_p[p + k] = sum_blocks sum_t W_b[t] x_p[p + b + t].  Every block runs on the 3x3 kernels that exist for
+    image layers (TNR_CONV_3x3_C4 on the matrix cores towards the feature side, tnr_conv_thin / tnr_wgrad_thin on the vector
+    ALUs towards the image side); the offset b is applied to the 4-channel operand (tnr_window2d: the shifted image, the
+    embedded image-side gradient, or the 4-channel block results), never to the wide one.  Data-gradients are taken with
+    respect to the padded input and folded back (tnr_unpad2d, adjoint of the reflection)."""
+
+    def __init__(self, conv, packer, side):
+        self.mod, self.packer, self.side = conv, packer, side        # side: "in" (image -> features) | "out" (features -> image)
+        w = conv.weight
+        O, I = w.shape[0], w.shape[1]
+        self.ws = torch.zeros((9, O, I, 3, 3), dtype=torch.float32, device=w.device)
+        self.dws = torch.zeros_like(self.ws)
+        self.db = torch.zeros(O, dtype=torch.float32, device=w.device)
+        kind = ops.PACK_C4_FWD if side == "in" else ops.PACK_C4_DGRAD3
+        self.i_mma = [packer.add(self.ws[b], kind) for b in range(9)]
+
+    def refresh(self):
+        w = self.mod.weight.detach()
+        self.ws.zero_()
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            ty, tx = _k7_first(by), _k7_first(bx)
+            self.ws[b, :, :, ty:, tx:].copy_(w[:, :, by + ty:by + 3, bx + tx:bx + 3])
+
+    def _gather_grad(self, bias_grad):
+        gw = self.mod.weight.grad
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            ty, tx = _k7_first(by), _k7_first(bx)
+            gw[:, :, by + ty:by + 3, bx + tx:bx + 3].add_(self.dws[b, :, :, ty:, tx:])
+        if bias_grad and self.mod.bias is not None:
+            self.mod.bias.grad.add_(self.db)
+
+    # ---- image -> features (first layer): x4 [N,H,W,4] -> z [N,H,W,O]
+    def fwd_in(self, x4, z):
+        N, H, W, dev = x4.N, x4.H, x4.W, x4.buf.device
+        xp = View(new_act(N, H + 6, W + 6, 4, dev))
+        ops.pad2d(x4, xp, 3, True)
+        acc = View(new_act(N, H + 2, W + 2, z.C, dev))
+        shifted = []
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            sh = View(new_act(N, H + 2, W + 2, 4, dev))
+            ops.window2d(xp, sh, by, bx)                              # sh[u] = x_p[u + b]: block b reads sh[u + t - 1]
+            epi = dict(bias=self.mod.bias) if b == 0 else dict(r1=acc, beta1=1.0)
+            ops.conv(sh, self.packer.get(self.i_mma[b]), acc, mode=ops.CONV_3x3_C4, **epi)
+            shifted.append(sh)
+        ops.unpad2d(acc, z, 1, False)
+        return shifted
+
+    def bwd_in(self, shifted, gz, want_w, gx4):
+        """gz: gradient of this layer's output; gx4 (or None): [N,H,W,4] gradient of the image."""
+        N, H, W, dev = gz.N, gz.H, gz.W, gz.buf.device
+        g1 = View(new_act(N, H + 2, W + 2, gz.C, dev))
+        ops.pad2d(gz, g1, 1, False)                                   # g1[u] = gz[u - 1]
+        if want_w:
+            for b in range(9):
+                ops.wgrad_thin(g1, shifted[b], self.dws[b], self.db if b == 0 else None, flip=False, beta=0.0)
+            self._gather_grad(True)
+        if gx4 is None:
+            return
+        gxp = View(new_act(N, H + 6, W + 6, 4, dev))
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            d = View(new_act(N, H + 2, W + 2, 4, dev))
+            ops.conv_thin(g1, self.ws[b], d, dgrad=True)              # d[u] = sum_t W_b^T[t] gz[u - t]
+            ops.window2d(d, gxp, -by, -bx, acc=b > 0)                 # gx_p[q] += d[q - b]
+        ops.unpad2d(gxp, gx4, 3, True)
+
+    # ---- features -> image (last layer): x [N,H,W,I] -> o4 [N,H,W,4] (no bias: it joins the tanh pass)
+    def fwd_out(self, x, o4):
+        N, H, W, dev = x.N, x.H, x.W, x.buf.device
+        xp = View(new_act(N, H + 6, W + 6, x.C, dev))
+        ops.pad2d(x, xp, 3, True)
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            ob = View(new_act(N, H + 6, W + 6, 4, dev))
+            ops.conv_thin(xp, self.ws[b], ob)                         # ob[u] = sum_t W_b[t] x_p[u + t - 1]
+            ops.window2d(ob, o4, by + 1, bx + 1, acc=b > 0)           # y[p] += ob[p + b + 1]
+        return xp
+
+    def bwd_out(self, xp, go4, want_w, gx):
+        """go4: [N,H,W,4] gradient of the image-side output; gx: [N,H,W,I] gradient of the layer's input."""
+        N, H, W, dev = go4.N, go4.H, go4.W, go4.buf.device
+        gxp = View(new_act(N, H + 6, W + 6, gx.C, dev))
+        for b, (by, bx) in enumerate(_K7_BLOCKS):
+            sm = View(new_act(N, H + 6, W + 6, 4, dev))
+            ops.window2d(go4, sm, -(by + 1), -(bx + 1))               # sm[u] = g[u - b - 1]
+            if want_w:
+                ops.wgrad_thin(xp, sm, self.dws[b], self.db if b == 0 else None, flip=True, beta=0.0)
+            epi = {} if b == 0 else dict(r1=gxp, beta1=1.0)
+            ops.conv(sm, self.packer.get(self.i_mma[b]), gxp, mode=ops.CONV_3x3_C4, **epi)     # gx_p[u] += sum_t W_b^T[t] g[u - t - b]
+        if want_w:
+            self._gather_grad(True)
+        ops.unpad2d(gxp, gx, 3, True)
+
+
 class ResnetGenerator(HipNet):
     def __init__(self, input_nc, output_nc, ngf=64, norm_type="batch", use_dropout=False, n_blocks=6, padding_type="reflect",
                  upsample_mode="deconv"):
@@ -113,6 +219,8 @@ class ResnetGenerator(HipNet):
     def _build_ops(self, packer):
         m, nb = self.model, self.n_blocks
         self._c_in, self._c_out = m[1], m[17 + nb]
+        # the thin / taps-in-K kernels take 16-, 32- or 64-channel wide sides; other widths keep the generic kernels
+        self._k7 = (_K7Image(self._c_in, packer, "in"), _K7Image(self._c_out, packer, "out")) if self.ngf in (16, 32, 64) else None
         self._downs = [_Padded4x4(m[4].weight, packer, False), _Padded4x4(m[7].weight, packer, False)]
         self._down_mods = [m[4], m[7]]
         self._ups = [_Padded4x4(m[10 + nb].weight, packer, True), _Padded4x4(m[13 + nb].weight, packer, True)]
@@ -126,7 +234,7 @@ class ResnetGenerator(HipNet):
         self._ones = {}
 
     def _refresh_derived(self):
-        for p in self._downs + self._ups:
+        for p in self._downs + self._ups + list(self._k7 or ()):
             p.refresh()
 
     # normalisation: BatchNorm2d (train) over the batch, or InstanceNorm2d = the same kernels per image with unit affine
@@ -143,14 +251,9 @@ class ResnetGenerator(HipNet):
             ops.bn_train_fwd(z, y, mod.weight, mod.bias, mod.running_mean, mod.running_var, mod.num_batches_tracked, mean, inv,
                              momentum=mod.momentum, eps=mod.eps, act=act, slope=0.0)
             return [(mean, inv)]
-        one, zero = self._affine(C, dev)
-        stats = []
-        for n in range(z.N):
-            mean, inv = torch.empty(C, device=dev), torch.empty(C, device=dev)
-            ops.bn_train_fwd(View(z.buf[n:n + 1], z.coff, C), View(y.buf[n:n + 1], y.coff, C), one, zero, None, None, None, mean, inv,
-                             momentum=0.1, eps=1e-5, act=act, slope=0.0)
-            stats.append((mean, inv))
-        return stats
+        mean, inv = torch.empty(z.N * C, device=dev), torch.empty(z.N * C, device=dev)
+        ops.instnorm_fwd(z, y, mean, inv, eps=1e-5, act=act, slope=0.0)      # one statistics group per image, one set of launches
+        return [(mean, inv)]
 
     def _norm_bwd(self, mod, stats, gy, y, z, gz, relu, want_w):
         ms = 0.0 if relu else 1.0                                 # ReLU' gate taken from y (slope 0), or no gate at all
@@ -159,10 +262,8 @@ class ResnetGenerator(HipNet):
             ops.bn_train_bwd(gy, y, z, gz, mod.weight, mean, inv, dgamma=mod.weight.grad if want_w else None,
                              dbeta=mod.bias.grad if want_w else None, mslope=ms)
             return
-        one, _ = self._affine(z.C, z.buf.device)
-        for n, (mean, inv) in enumerate(stats):
-            ops.bn_train_bwd(View(gy.buf[n:n + 1], gy.coff, gy.C), View(y.buf[n:n + 1], y.coff, y.C), View(z.buf[n:n + 1], z.coff, z.C),
-                             View(gz.buf[n:n + 1], gz.coff, gz.C), one, mean, inv, mslope=ms)
+        mean, inv = stats[0]
+        ops.instnorm_bwd(gy, y, z, gz, mean, inv, mslope=ms)
 
     # ------------------------------------------------------------------ forward
     def engine_forward(self, x, save):
@@ -175,9 +276,13 @@ class ResnetGenerator(HipNet):
         ops.nchw_to_nhwc(x, x4, Cpad=4)
         tape = {}
         z = View(new_act(N, H, W, ngf, dev))
-        ops.gconv_fwd(x4, self._c_in.weight, z, bias=self._c_in.bias, stride=1, pad=3, reflect=True)
+        if self._k7:
+            x_in = self._k7[0].fwd_in(x4, z)              # (the nine shifted images: the weight gradient reads them again)
+        else:
+            ops.gconv_fwd(x4, self._c_in.weight, z, bias=self._c_in.bias, stride=1, pad=3, reflect=True)
+            x_in = x4
         a = View(new_act(N, H, W, ngf, dev))
-        tape["in"] = (x4, z, a, self._norm_fwd(self._norms["in"], z, a, R))
+        tape["in"] = (x_in, z, a, self._norm_fwd(self._norms["in"], z, a, R))
         cur = a
         for i, (p4, mod) in enumerate(zip(self._downs, self._down_mods)):
             z = View(new_act(N, cur.H // 2, cur.W // 2, mod.out_channels, dev))
@@ -214,7 +319,10 @@ class ResnetGenerator(HipNet):
             tape["u%d" % i] = (cur, z, a, self._norm_fwd(self._norms["u%d" % i], z, a, R))
             cur = a
         o4 = new_act(N, H, W, 4, dev)
-        ops.gconv_fwd(cur, self._c_out.weight, View(o4, 0, 4), bias=None, stride=1, pad=3, reflect=True)     # bias added with the tanh pass
+        if self._k7:
+            cur = self._k7[1].fwd_out(cur, View(o4, 0, 4))             # (keeps the reflection-padded input for the weight gradient)
+        else:
+            ops.gconv_fwd(cur, self._c_out.weight, View(o4, 0, 4), bias=None, stride=1, pad=3, reflect=True)     # bias added with the tanh pass
         pre = torch.empty((N, self.output_nc, H, W), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(View(o4, 0, self.output_nc), pre)
         pre += self._c_out.bias.detach().view(1, -1, 1, 1)
@@ -236,16 +344,19 @@ class ResnetGenerator(HipNet):
         ops.nchw_to_nhwc(gpre, g4, Cpad=4)
         go = View(g4.buf, 0, 4)
         co = self._c_out
-        if Wg:
-            dw4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
-            db4 = torch.zeros(4, dtype=torch.float32, device=dev)
-            ops.gconv_wgrad(last_in, go, dw4, db4, stride=1, pad=3, reflect=True, beta=0.0)
-            co.weight.grad.add_(dw4[:self.output_nc])
-            co.bias.grad.add_(db4[:self.output_nc])
-        w4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
-        w4[:self.output_nc].copy_(co.weight.detach())
         g = View(new_act(N, H, W, self.ngf, dev))
-        ops.gconv_dgrad(go, w4, g, stride=1, pad=3, reflect=True)
+        if self._k7:
+            self._k7[1].bwd_out(last_in, go, Wg, g)
+        else:
+            if Wg:
+                dw4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
+                db4 = torch.zeros(4, dtype=torch.float32, device=dev)
+                ops.gconv_wgrad(last_in, go, dw4, db4, stride=1, pad=3, reflect=True, beta=0.0)
+                co.weight.grad.add_(dw4[:self.output_nc])
+                co.bias.grad.add_(db4[:self.output_nc])
+            w4 = torch.zeros((4, co.in_channels, 7, 7), dtype=torch.float32, device=dev)
+            w4[:self.output_nc].copy_(co.weight.detach())
+            ops.gconv_dgrad(go, w4, g, stride=1, pad=3, reflect=True)
         # up-sampling stages
         for i in (1, 0):
             xin, z, a, st = tape["u%d" % i]
@@ -300,19 +411,25 @@ class ResnetGenerator(HipNet):
         gz = View(new_act(N, z.H, z.W, z.C, dev))
         self._norm_bwd(self._norms["in"], st, g, a, z, gz, True, Wg)
         ci = self._c_in
-        if Wg:
-            dwi = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
-            dbi = torch.zeros(ci.out_channels, dtype=torch.float32, device=dev)
-            ops.gconv_wgrad(x4, gz, dwi, dbi, stride=1, pad=3, reflect=True, beta=0.0)
-            ci.weight.grad.add_(dwi[:, :self.input_nc])
-            if ci.bias is not None:
-                ci.bias.grad.add_(dbi)
-        if not need_input_grad:
-            return None
-        wi4 = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
-        wi4[:, :self.input_nc].copy_(ci.weight.detach())
-        gx4 = View(new_act(N, H, W, 4, dev))
-        ops.gconv_dgrad(gz, wi4, gx4, stride=1, pad=3, reflect=True)
+        if self._k7:
+            gx4 = View(new_act(N, H, W, 4, dev)) if need_input_grad else None
+            self._k7[0].bwd_in(x4, gz, Wg, gx4)                      # (x4: the shifted images saved by fwd_in)
+            if not need_input_grad:
+                return None
+        else:
+            if Wg:
+                dwi = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
+                dbi = torch.zeros(ci.out_channels, dtype=torch.float32, device=dev)
+                ops.gconv_wgrad(x4, gz, dwi, dbi, stride=1, pad=3, reflect=True, beta=0.0)
+                ci.weight.grad.add_(dwi[:, :self.input_nc])
+                if ci.bias is not None:
+                    ci.bias.grad.add_(dbi)
+            if not need_input_grad:
+                return None
+            wi4 = torch.zeros((ci.out_channels, 4, 7, 7), dtype=torch.float32, device=dev)
+            wi4[:, :self.input_nc].copy_(ci.weight.detach())
+            gx4 = View(new_act(N, H, W, 4, dev))
+            ops.gconv_dgrad(gz, wi4, gx4, stride=1, pad=3, reflect=True)
         gin = torch.empty((N, self.input_nc, H, W), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(View(gx4.buf, 0, self.input_nc), gin)
         return gin

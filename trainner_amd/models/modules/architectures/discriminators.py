@@ -298,6 +298,93 @@ class UNetDiscriminator(HipNet):
         return gin
 
 
+class _PadCinOp:
+    """A convolution whose input-channel count is not a multiple of 4 (the conditional PatchGAN's first layer: 6 = A + B
+    channels) on the matrix-core kernels: the NHWC input buffer already carries the channels zero-extended to a multiple of 4,
+    the weight gets the same zero extension (a derived tensor, re-filled whenever the parameters change), and the weight
+    gradient comes back through it."""
+
+    def __init__(self, conv, packer, cin_buf):
+        self.conv = conv
+        shadow = nn.Module()
+        shadow.weight = nn.Parameter(torch.zeros((conv.out_channels, cin_buf, conv.kernel_size, conv.kernel_size),
+                                                 dtype=torch.float32, device=conv.weight.device), requires_grad=False)
+        shadow.weight.grad = torch.zeros_like(shadow.weight)
+        shadow.bias = conv.bias
+        shadow.kernel_size, shadow.stride = conv.kernel_size, conv.stride
+        shadow.in_channels, shadow.out_channels = cin_buf, conv.out_channels
+        self.shadow = shadow
+        self.op = ConvOp(shadow, packer, need_dgrad=True)
+
+    def refresh(self):
+        self.shadow.weight.data[:, :self.conv.in_channels].copy_(self.conv.weight.detach())
+
+    def fwd(self, x, y, **epi):
+        self.op.fwd(x, y, **epi)
+
+    def dgrad(self, g, gx):
+        self.op.dgrad(g, gx)
+
+    def wgrad(self, x, g):
+        ops.fill(self.shadow.weight.grad, 0.0)
+        self.op.wgrad(x, g)
+        self.conv.weight.grad.add_(self.shadow.weight.grad[:, :self.conv.in_channels])
+
+
+class _K4S1:
+    """A 4x4 stride-1 pad-1 convolution (the PatchGAN's last two layers) on the matrix cores.
+    Forward and data-gradient go through the patch matrix (tnr_im2col + the 1x1 implicit-GEMM kernel: ops.conv_col; the
+    data-gradient of a stride-1 layer is the same convolution with pad 2 and flipped / transposed taps).  The weight
+    gradient is taken as four shifted 3x3 windows of the MFMA weight-gradient kernel: with G_s = the output gradient
+    zero-embedded at offset s in {0,1}^2 of the input grid, wgrad3x3(x, G_s)[ty][tx] = dW[ty + sy][tx + sx], and the four
+    3x3 blocks cover the 4x4 taps (one grouped launch).  The output-channel dimension is zero-extended to the buffer's
+    multiple of 4 (the 512 -> 1 logit layer)."""
+
+    def __init__(self, conv, packer, cin_buf):
+        self.mod, self.packer = conv, packer
+        w = conv.weight
+        self.co = (w.shape[0] + 3) // 4 * 4
+        self.alias = self.co == w.shape[0] and cin_buf == w.shape[1]
+        self.wp4 = w if self.alias else torch.zeros((self.co, cin_buf, 4, 4), dtype=torch.float32, device=w.device)
+        self.i_f = packer.add(self.wp4, ops.PACK_COL_FWD)
+        self.i_d = packer.add(self.wp4, ops.PACK_COL_DGRAD3)
+        self.bias = None
+        if conv.bias is not None:
+            self.bias = conv.bias if self.co == conv.out_channels else torch.zeros(self.co, dtype=torch.float32, device=w.device)
+        self.dw3 = torch.zeros((4, self.co, cin_buf, 3, 3), dtype=torch.float32, device=w.device)
+        self.db = torch.zeros(self.co, dtype=torch.float32, device=w.device)
+
+    def refresh(self):
+        w = self.mod.weight.detach()
+        if not self.alias:
+            self.wp4[:w.shape[0], :w.shape[1]].copy_(w)
+        if self.bias is not None and self.bias is not self.mod.bias:
+            self.bias[:self.mod.out_channels].copy_(self.mod.bias.detach())
+
+    def fwd(self, x, y, **epi):
+        ops.conv_col(x, self.packer.get(self.i_f), y, 4, 1, 1, bias=self.bias, **epi)
+
+    def dgrad(self, g, gx):
+        ops.conv_col(g, self.packer.get(self.i_d), gx, 4, 1, 2)
+
+    def wgrad(self, x, g):
+        items = []
+        for s in range(4):
+            gs = View(new_act(x.N, x.H, x.W, g.C, x.buf.device))
+            ops.window2d(g, gs, -(s >> 1), -(s & 1))
+            items.append(dict(x=x, g=gs, dw=self.dw3[s], db=self.db if s == 0 else None, beta=0.0))
+        ops.wgrad_group(items, mode=ops.CONV_3x3)
+        O, I = self.mod.out_channels, self.mod.in_channels
+        gw, d = self.mod.weight.grad, self.dw3
+        gw[:, :, :3, :3].add_(d[0, :O, :I])                       # s = (0, 0): taps [0, 3)^2
+        gw[:, :, 3, 1:].add_(d[3, :O, :I, 2, :])                  # s = (1, 1): ky = 3, kx = 1..3
+        gw[:, :, 1:3, 3].add_(d[3, :O, :I, :2, 2])                #             ky = 1..2, kx = 3
+        gw[:, :, 3, 0].add_(d[2, :O, :I, 2, 0])                   # s = (1, 0): tap (3, 0)
+        gw[:, :, 0, 3].add_(d[1, :O, :I, 0, 2])                   # s = (0, 1): tap (0, 3)
+        if self.mod.bias is not None:
+            self.mod.bias.grad.add_(self.db[:O])
+
+
 class NLayerDiscriminator(HipNet):
     """PatchGAN discriminator (Pix2Pix / CycleGAN) on the MI355X engine.
 
@@ -305,7 +392,8 @@ class NLayerDiscriminator(HipNet):
     discriminators.py:472-579 for the default configuration get_network builds (BatchNorm2d, patch output, no spectral norm,
     no intermediate feature maps): conv4 s2 (in -> ndf, bias) + LReLU; n_layers-1 x [conv4 s2 (no bias) + BN + LReLU];
     conv4 s1 (no bias) + BN + LReLU; conv4 s1 (-> 1, bias).  The stride-2 layers run on the space-to-depth MFMA kernels
-    (conv_tile.hip), the two stride-1 4x4 layers on the generic vector-ALU convolution (csrc/gconv.hip)."""
+    (conv_tile.hip), the two stride-1 4x4 layers through the patch matrix + 1x1 GEMM / shifted 3x3 weight-gradient windows
+    (_K4S1); only a first layer with a channel count that is not a multiple of 4 would use the generic kernel (csrc/gconv.hip)."""
 
     def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=None, use_sigmoid=False, get_feats=False, patch=True,
                  use_spectral_norm=False):
@@ -335,10 +423,18 @@ class NLayerDiscriminator(HipNet):
             bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], B.BatchNorm2dHIP) else None
             j = i + (2 if bn is not None else 1)
             act = j < len(mods) and isinstance(mods[j], B.Marker)
-            op = ConvOp(conv, packer, need_dgrad=True) if conv.stride == 2 and conv.in_channels % 4 == 0 else None
+            if conv.in_channels % 4 == 0:
+                op = ConvOp(conv, packer, need_dgrad=True) if conv.stride == 2 else _K4S1(conv, packer, conv.in_channels)
+            else:
+                op = _PadCinOp(conv, packer, (conv.in_channels + 3) // 4 * 4) if conv.stride == 2 else None
             self._layers.append((conv, bn, act, op))
             i = j + (1 if act else 0)
         self._ops = True
+
+    def _refresh_derived(self):
+        for _, _, _, op in self._layers:
+            if isinstance(op, (_K4S1, _PadCinOp)):
+                op.refresh()
 
     def engine_forward(self, x, save):
         N, Cc, H, W = x.shape

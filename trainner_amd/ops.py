@@ -374,6 +374,19 @@ def conv_small(x, wp_col, y, k, stride, pad=1, **epi):
     conv(View(cimg), wp_col, yimg, mode=CONV_1x1, **epi)
 
 
+def conv_col(x, wp_col, y, k, stride=1, pad=1, **epi):
+    """y = conv_kxk(x) (TNR_PACK_COL_FWD weights) or the stride-1 data-gradient conv_kxk(g, pad = k - 1 - p) with flipped /
+    transposed weights (TNR_PACK_COL_DGRAD3) for kernel geometries without a direct MFMA tile (the PatchGAN's 4x4 stride-1
+    layers): tnr_im2col into [N, Ho, Wo, k*k*C], then the 1x1 implicit-GEMM kernel over that image."""
+    K = k * k * x.C
+    if K % 16 or K != wp_col.KinP:
+        raise hip.HipEngineError("conv_col: k*k*C = %d must be a multiple of 16 and match the packed weights (%d)" % (K, wp_col.KinP))
+    M = y.pixels
+    col = WS.get("im2col@%x" % hip.stream(), M * K * 4, x.buf.device)
+    hip.check(hip.load().tnr_im2col(x.c(), x.N, x.H, x.W, x.C, k, stride, pad, y.H, y.W, col.data_ptr(), hip.stream()), "im2col")
+    conv(View(col.view(torch.float32)[:M * K].view(y.N, y.H, y.W, K)), wp_col, y, mode=CONV_1x1, **epi)
+
+
 WGRAD_GROUP_MAX = 8
 
 
@@ -520,7 +533,7 @@ def gconv_wgrad(x, g, dw, db=None, stride=1, pad=0, reflect=False, alpha=1.0, be
 
 def bias_grad(g, db, alpha=1.0, beta=1.0):
     """db = beta db + alpha * sum over the pixels of g (per channel)."""
-    ws = WS.get("bias_grad@%x" % hip.stream(), 64 * g.C * 8, g.buf.device)
+    ws = WS.get("bias_grad@%x" % hip.stream(), 512 * g.C * 8, g.buf.device)
     hip.check(hip.load().tnr_bias_grad(g.c(), g.pixels, g.C, db.data_ptr(), alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "bias_grad")
 
 
@@ -532,6 +545,12 @@ def pad2d(x, y, pad, reflect):
 def unpad2d(xp, y, pad, fold):
     """y [N,H,W,C] = centre crop of xp (fold False) or the adjoint of the reflection padding (fold True)."""
     hip.check(hip.load().tnr_unpad2d(xp.c(), y.c(), y.N, y.H, y.W, y.C, pad, int(fold), hip.stream()), "unpad2d")
+
+
+def window2d(src, dst, oy, ox, acc=False):
+    """dst[n, y, x, :] (+)= src[n, y + oy, x + ox, :] inside src, 0 outside (same N and C; zero-embedding at an offset / offset
+    crop; acc: added to dst instead of replacing it)."""
+    hip.check(hip.load().tnr_window2d(src.c(), src.H, src.W, dst.c(), dst.N, dst.H, dst.W, dst.C, oy, ox, int(acc), hip.stream()), "window2d")
 
 
 def tanh_fwd(x, y):
@@ -579,6 +598,23 @@ def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta
     hip.check(lib.tnr_bn_train_bwd(gy.c(), y.c(), z.c(), gz.c(), z.pixels, z.C, gamma.data_ptr(),
                                    save_mean.data_ptr(), save_invstd.data_ptr(), mslope, hip.ptr(dgamma),
                                    hip.ptr(dbeta), acc_beta, ws.data_ptr(), hip.stream()), "bn_train_bwd")
+
+
+def instnorm_fwd(z, y, save_mean, save_invstd, eps=1e-5, act=ACT_NONE, slope=0.0):
+    """y = act(InstanceNorm2d(z)) (no affine, per image and channel statistics); save_mean / save_invstd: [N * C]."""
+    lib = hip.load()
+    ws = WS.get("instnorm", lib.tnr_instnorm_workspace_bytes(z.N, z.C), z.buf.device)
+    hip.check(lib.tnr_instnorm_fwd(z.c(), y.c(), z.N, z.H * z.W, z.C, eps, save_mean.data_ptr(), save_invstd.data_ptr(), act, slope,
+                                   ws.data_ptr(), hip.stream()), "instnorm_fwd")
+
+
+def instnorm_bwd(gy, y, z, gz, save_mean, save_invstd, mslope=1.0):
+    """gz = d loss / d z of instnorm_fwd from gy, the gradient of its (activated) output; mslope: the activation's negative slope
+    (0 ReLU, 1 no activation), the gate is read from y."""
+    lib = hip.load()
+    ws = WS.get("instnorm", lib.tnr_instnorm_workspace_bytes(z.N, z.C), z.buf.device)
+    hip.check(lib.tnr_instnorm_bwd(gy.c(), y.c(), z.c(), gz.c(), z.N, z.H * z.W, z.C, save_mean.data_ptr(), save_invstd.data_ptr(),
+                                   mslope, ws.data_ptr(), hip.stream()), "instnorm_bwd")
 
 
 def linear_fwd(x, w, b, y, act=ACT_NONE, slope=0.2):
