@@ -40,6 +40,8 @@ struct ConvK {
     int ksplit;              // split-K factor (1: none); split s writes its partial sums to y + s * split_stride
     size_t split_stride;
     int bf;                  // operands rounded to bf16 in front of the matrix core (tnr_conv_desc.mma)
+    int coh_from;            // chain kernel: first input channel another workgroup of THIS launch may have written; chunks below it
+                             // were complete before the launch and take ordinary (L2-cached) loads
 };
 
 #ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps, 8 per body call */
@@ -206,7 +208,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 if (off != -1) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)(off + c0));
             } else if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
                 const unsigned bo = (off >= 0 && c0 + q * 4 < a.Cin) ? (unsigned)(off + c0) * 4u : 0xfffffff0u;
-                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
+                if (c0 >= a.coh_from)       // (chunk-uniform) channels produced inside this launch: system-coherent, past L2
+                    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
+                else
+                    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
             } else if (off >= 0 && c0 + q * 4 < a.Cin) {
                 v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
             }

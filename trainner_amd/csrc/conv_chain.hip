@@ -26,6 +26,10 @@ struct ChainK {
     unsigned *progress;                // [tiles]: base + (stages of that tile whose output is visible)
     unsigned base;
     unsigned *err;                     // set to 1 when a dependency wait gives up (never in a healthy run)
+    unsigned *cu_ctr;                  // [CH_CU_KEYS] arrivals per CU, never reset: parity = which of the CU's two slots
+    unsigned *tile_ctr;                // [2 sets][2 populations] tile dispensers; set (epoch & 1) is live, the other gets zeroed
+    int dyn;                           // 1: one tile per workgroup, dealt at run time by CU slot (phase-shifted populations)
+    int set;
     int wait_chunk[TNR_CHAIN_MAX];
     ConvK st[TNR_CHAIN_MAX];
 };
@@ -95,11 +99,50 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
     unsigned pend_value = 0;
     int calls = 0;               // (timeline probe only)
     (void)calls;
+    // Phase-shifted populations (c.dyn: tiles == grid == 2 workgroups per CU, i.e. the benchmark's trunk layers): all
+    // workgroups reaching a stage boundary together leave the matrix pipes idle while the tile stores drain.  The two
+    // workgroups of a CU are therefore put into different halves of the batch (dependencies never cross images) and the
+    // second half starts TNR_CHAIN_STAGGER cycles late, so that one workgroup's boundary overlaps the other's MFMA phases.
+    // Which slot of its CU a workgroup got is the parity of a per-CU arrival counter; tiles are dealt by two dispensers
+    // (a workgroup whose half is exhausted takes from the other one, so the mapping stays a bijection whatever the parity).
+    int first_tile = blockIdx.x, tile_step = gridDim.x;
+#ifndef TNR_CHAIN_STAGGER
+#define TNR_CHAIN_STAGGER 0
+#endif
+    if (TNR_CHAIN_STAGGER > 0 && c.dyn) {
+        __shared__ int s_tile, s_slot;
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 15u;   // HW_REG_XCC_ID
+            const unsigned key = (xcc << 7) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            const unsigned slot = atomicAdd(c.cu_ctr + key, 1u) & 1u;
+            const unsigned half = (unsigned)c.tiles >> 1;
+            unsigned *disp = c.tile_ctr + 2 * c.set;
+            unsigned pop = slot, idx = atomicAdd(disp + pop, 1u);
+            if (idx >= half) {
+                pop ^= 1u;
+                idx = atomicAdd(disp + pop, 1u);
+            }
+            s_tile = (int)(pop * half + idx);
+            s_slot = (int)pop;
+            if (blockIdx.x == 0) {                    // the other set serves the next launch on this stream
+                c.tile_ctr[2 * (c.set ^ 1)] = 0u;
+                c.tile_ctr[2 * (c.set ^ 1) + 1] = 0u;
+            }
+        }
+        __syncthreads();
+        first_tile = s_tile;
+        tile_step = c.tiles;
+        if (s_slot) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)(TNR_CHAIN_STAGGER)) __builtin_amdgcn_s_sleep(64);
+        }
+    }
     for (int s = 0; s < c.nstages; ++s) {
         int wait_chunk;
         const ConvK st = chain_stage(s, &wait_chunk);
         const int ncb = st.KoutP >> 5;
-        for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+        for (int tile = first_tile; tile < c.tiles; tile += tile_step) {
             int q = tile;
             const int tx = q % c.tiles_x;
             q /= c.tiles_x;
@@ -128,6 +171,7 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
 }
 
 constexpr int CH_TH = 16, CH_TW = 32;
+constexpr int CH_CU_KEYS = 16 * 128;   // (xcc, se, sh, cu) keys of chain_kernel's per-CU arrival counters
 constexpr size_t chain_lds() {
     constexpr size_t lds_main = (size_t)((CH_TH + 2) * (CH_TW + 2) + 9 * 32) * TNR_PST * sizeof(float);
     constexpr size_t lds_epi = (size_t)4 * 4 * 32 * 32 * sizeof(float);
@@ -168,7 +212,8 @@ int chain_capacity(int *out) {
 extern "C" int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *d) {
     if (d == nullptr) return 0;
     const int64_t tiles = (int64_t)tnr_cdiv(d->Wo, CH_TW) * tnr_cdiv(d->Ho, CH_TH) * d->N;
-    return (tiles + 1) * (int64_t)sizeof(uint32_t);   // progress counters + the error word
+    // progress counters, per-CU arrival counters, 2 x 2 tile dispensers, the error word (last)
+    return (tiles + CH_CU_KEYS + 4 + 1) * (int64_t)sizeof(uint32_t);
 }
 
 extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,
@@ -183,7 +228,10 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     c.tiles_y = tnr_cdiv(d0.Ho, CH_TH);
     c.tiles = c.tiles_x * c.tiles_y * d0.N;
     c.progress = ws;
-    c.err = ws + c.tiles;
+    c.cu_ctr = ws + c.tiles;
+    c.tile_ctr = c.cu_ctr + CH_CU_KEYS;
+    c.err = c.tile_ctr + 4;
+    c.set = (int)(epoch & 1u);
     c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
     for (int i = 0; i < n; ++i) {
         const tnr_conv_desc *d = &stages[i];
@@ -217,12 +265,29 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16;
         TNR_REQUIRE(d->mma == d0.mma, "conv_chain: stage %d: all stages share one matrix-core precision", i);
         c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
+        // input channels below coh_from were complete before the launch (no earlier stage writes them): cached loads
+#ifndef TNR_CHAIN_NCLOAD
+#define TNR_CHAIN_NCLOAD 1
+#endif
+        k.coh_from = 0;
+        if (TNR_CHAIN_NCLOAD) {
+            int lo = 1 << 30;
+            for (int j = 0; j < i; ++j) {
+                const tnr_conv_desc *e = &stages[j];
+                if (e->y.ptr == d->x.ptr && e->y.coff + e->Cout > d->x.coff && e->y.coff < d->x.coff + d->Cin) {
+                    const int first = e->y.coff > d->x.coff ? e->y.coff - d->x.coff : 0;
+                    if (first < lo) lo = first;
+                }
+            }
+            k.coh_from = lo / TNR_CK * TNR_CK;
+        }
     }
     for (int i = n; i < TNR_CHAIN_MAX; ++i) { c.st[i] = c.st[0]; c.wait_chunk[i] = -1; }
     int cap = 0;
     const int rc = chain_capacity(&cap);
     if (rc != TNR_OK) return rc;
     const int grid = c.tiles < cap ? c.tiles : cap;
+    c.dyn = (c.tiles == cap && (c.tiles & 1) == 0 && d0.N >= 2 && (d0.N & 1) == 0) ? 1 : 0;   // whole images per population
     if (d0.mma == TNR_MMA_BF16)
         hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else

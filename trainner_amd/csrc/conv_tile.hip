@@ -194,6 +194,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     // split-K for launches that cannot fill the chip (see tnr_conv_workspace_bytes)
     const int ksplit = conv_ksplit(d, tiles);
     k.bf = d->mma == TNR_MMA_BF16;
+    k.coh_from = 0;
     k.ksplit = 1;
     k.split_stride = 0;
     SplitRedK red;
