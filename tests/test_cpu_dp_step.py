@@ -21,6 +21,32 @@ STEPS = 2
 BN_BIAS = None
 
 
+I2I_KW = dict(model="pix2pix", batch=4, crop=64, n_blocks=1, ngf=16, ndf=16, pixel_weight=100.0)
+
+
+def _build_i2i(tmp, seed_g, seed_d):
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    yml = ref_harness.i2i_yaml(name="dp_i2i", out_root=tmp, gpu_ids="[0]", **I2I_KW)
+    model = create_model(options.parse(yml, is_train=True), verbose=False)
+    model.netG.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netG.state_dict().items()}, seed_g))
+    model.netD.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netD.state_dict().items()}, seed_d))
+    return model
+
+
+def _run_i2i(model):
+    logs = []
+    for s in range(1, STEPS + 1):
+        A = detrand.uniform((I2I_KW["batch"], 3, 64, 64), 170 + s, -1.0, 1.0)     # every rank is fed the GLOBAL batch
+        B = detrand.uniform((I2I_KW["batch"], 3, 64, 64), 180 + s, -1.0, 1.0)
+        model.feed_data({"A": A, "B": B, "A_path": ["a"] * 4})
+        model.optimize_parameters(s)
+        logs.append(model.get_current_log())
+    return dict(logs=logs, fake=model.fake_B.detach().clone(),
+                g={k: v.detach().clone() for k, v in model.netG.state_dict().items()},
+                d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
+
+
 def _build(tmp, seed_g, seed_d):
     from trainner_amd.models import create_model
     from trainner_amd.options import options
@@ -49,7 +75,7 @@ def _run(model, rank=None, world=1):
                 d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
 
 
-def _worker(rank, world, port, tmp, q):
+def _worker(rank, world, port, tmp, q, kind="sr"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     try:
         torch.set_num_threads(4)
@@ -58,10 +84,11 @@ def _worker(rank, world, port, tmp, q):
         dpmod.BUCKET_FLOATS = 100_000             # several buckets per network, fired from inside backward
         # rank 1 holds DIFFERENT weights (as after a per-rank init RNG): sync_replicas must bring it to rank 0's
         # (SRModel's constructor calls it as its last act; here the seeded load happens after construction)
-        model = _build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666)
+        build, run = (_build, lambda m: _run(m, rank, world)) if kind == "sr" else (_build_i2i, _run_i2i)
+        model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666)
         assert model.dp.active and model.dp.world_size == world
         model.sync_replicas()
-        out = _run(model, rank, world)
+        out = run(model)
         path = os.path.join(tmp, "rank%d.pt" % rank)
         torch.save(out, path)                     # tensors travel by file (the worker exits before the parent reads)
         q.put((rank, path))
@@ -129,3 +156,48 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch):
     for k, v in res[0]["d"].items():
         if ".running_" not in k and v.is_floating_point():
             assert torch.equal(v, res[1]["d"][k]), k
+
+
+def test_two_rank_pix2pix_step_equals_single_process(tmp_path, monkeypatch):
+    """The same equivalence for Pix2PixModel (SURVEY.md 8(f)3 under 8(e)): conditional PatchGAN with per-replica BatchNorm
+    statistics, standard-form GAN criterion (no cross-rank coupling: every loss is a mean over the local shard, gradient
+    averaging makes it the global mean), InstanceNorm generator, D step before the G step, sharded feed of {'A','B'}."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, "pix2pix")) for r in range(2)]
+    for p in procs:
+        p.start()
+    emul_backend.install(monkeypatch)
+    from trainner_amd import ops
+    f, b = emul_backend.chunked_bn(2)
+    monkeypatch.setattr(ops, "bn_train_fwd", f)
+    monkeypatch.setattr(ops, "bn_train_bwd", b)
+    torch.set_num_threads(4)
+    one = _run_i2i(_build_i2i(str(tmp_path / "one"), 101, 202))
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in (0, 1):
+        assert res[r].endswith(".pt"), res[r]
+        res[r] = torch.load(res[r], weights_only=False)
+    per, lr_steps = I2I_KW["batch"] // 2, 2e-4 * STEPS
+    shadow = FX.norm_shadowed_biases([(k, None) for k in one["g"]], "instance")
+    for r in (0, 1):
+        out = res[r]
+        for s in range(STEPS):
+            assert list(out["logs"][s].keys()) == list(one["logs"][s].keys())
+            for k, v in one["logs"][s].items():
+                assert abs(out["logs"][s][k] - v) <= 5e-5 * abs(v) + 2e-6, (r, s, k, out["logs"][s][k], v)
+        diff = (out["fake"] - one["fake"][r * per:(r + 1) * per]).abs().max().item()
+        assert diff <= 2e-5, ("fake_B", r, diff)
+        for name, mine, ref in (("G", out["g"], one["g"]), ("D", out["d"], one["d"])):
+            tot, cnt, worst = 0.0, 0, 0.0
+            for k, v in ref.items():
+                if k in shadow or not v.is_floating_point() or ".running_" in k:
+                    continue
+                d = (mine[k] - v).abs() / lr_steps
+                tot, cnt, worst = tot + d.sum().item(), cnt + d.numel(), max(worst, d.max().item())
+            assert tot / cnt < 2e-3 and worst < 1.0, (name, r, worst, tot / cnt)
+    for k, v in res[0]["g"].items():
+        assert torch.equal(v, res[1]["g"][k]), k

@@ -159,3 +159,69 @@ def test_resrgan_strategy_synthesises_lr_on_device(tmp_path):
         model.feed_data(data)
         model.optimize_parameters(step)
     assert step == 2 and all(np.isfinite(v) for v in model.get_current_log().values())
+
+
+def test_unaligned_window_dataset_draw_order_and_flags(tmp_path):
+    """mode: unaligned (CycleGAN data, codes/data/unaligned_dataset.py:70-139): B's index is drawn first (random.randint),
+    then get_params for A, then for B -- the same `random` draws in the same order as the reference; per-image windows, flags."""
+    from trainner_amd.data import create_dataset
+    from trainner_amd.data.aligned_dataset import paired_params, read_image_bgr
+    a_dir, b_dir = tmp_path / "a", tmp_path / "b"
+    a_dir.mkdir()
+    b_dir.mkdir()
+    rng = np.random.RandomState(1)
+    for i in range(3):
+        np.save(str(a_dir / ("%d.npy" % i)), rng.randint(0, 256, (40, 56, 3), dtype=np.uint8))
+    for i in range(5):
+        np.save(str(b_dir / ("%d.npy" % i)), rng.randint(0, 256, (48, 44, 3), dtype=np.uint8))
+    ds = create_dataset({"mode": "unaligned", "dataroot_A": str(a_dir), "dataroot_B": str(b_dir), "crop_size": 32, "scale": 1,
+                         "use_flip": True, "use_rot": True, "preprocess": "crop", "outputs": "AB"})
+    assert len(ds) == 5
+    random.seed(9)
+    s = ds[4]                                   # A index wraps: 4 % 3 = 1
+    random.seed(9)
+    bi = random.randint(0, 4)
+    pa, pb = paired_params((56, 40), 32), paired_params((44, 48), 32)
+    assert s["A_path"].endswith("1.npy") and s["B_path"].endswith("%d.npy" % bi)
+    (xa, ya), (xb, yb) = pa["crop_pos"], pb["crop_pos"]
+    assert np.array_equal(s["A"], read_image_bgr(s["A_path"])[ya:ya + 32, xa:xa + 32])
+    assert np.array_equal(s["B"], read_image_bgr(s["B_path"])[yb:yb + 32, xb:xb + 32])
+    assert s["flags_A"] == FO.flags_of(pa["flip"], pa["rot"], pa["vflip"]) and s["flags_B"] == FO.flags_of(pb["flip"], pb["rot"], pb["vflip"])
+    # paired A / B folders (Pix2Pix): one draw, one crop position, one flag word
+    pd = create_dataset({"mode": "aligned", "outputs": "AB", "dataroot_A": str(a_dir), "dataroot_B": str(a_dir), "crop_size": 32,
+                         "scale": 1, "use_flip": True, "use_rot": False})
+    random.seed(3)
+    q = pd[2]
+    assert set(q) == {"A", "B", "flags", "A_path", "B_path"} and np.array_equal(q["A"], q["B"]) and q["A"].shape == (32, 32, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["pix2pix", "cyclegan"])
+def test_i2i_training_step_through_the_feeder(kind, tmp_path):
+    """create_dataset + create_dataloader for the image-to-image models: uint8 A / B windows (unaligned: each image with its own
+    flip / rot90 flags) -> DeviceFeeder (znorm: [-1, 1]) -> Pix2PixModel / CycleGANModel.optimize_parameters."""
+    import test_gpu_i2i as TI
+    from trainner_amd.data import create_dataloader, create_dataset
+    a_dir, b_dir = tmp_path / "a", tmp_path / "b"
+    a_dir.mkdir()
+    b_dir.mkdir()
+    rng = np.random.RandomState(5)
+    for i in range(4):
+        np.save(str(a_dir / ("%d.npy" % i)), rng.randint(0, 256, (80, 96, 3), dtype=np.uint8))
+        np.save(str(b_dir / ("%d.npy" % i)), rng.randint(0, 256, (80, 96, 3), dtype=np.uint8))
+    opt, model = TI.build_i2i_model(dict(model=kind, batch=2, crop=64, n_blocks=1, ngf=16, ndf=16,
+                                         pixel_weight=100.0 if kind == "pix2pix" else 10.0,
+                                         lambda_identity=0.5 if kind == "cyclegan" else None), tmp_path)
+    ds_opt = dict(opt["datasets"]["train"])
+    ds_opt.update(mode="aligned" if kind == "pix2pix" else "unaligned", dataroot_A=str(a_dir), dataroot_B=str(b_dir), use_flip=True,
+                  use_rot=True, use_shuffle=True, phase="train", scale=1, preprocess="crop")
+    loader = create_dataloader(create_dataset(ds_opt), ds_opt)
+    step = 0
+    for data in loader:
+        assert data["A"].is_cuda and tuple(data["A"].shape) == (2, 3, 64, 64) and tuple(data["B"].shape) == (2, 3, 64, 64)
+        assert -1.0 <= float(data["A"].min()) and float(data["A"].max()) <= 1.0 and float(data["A"].min()) < -0.9     # znorm
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    log = model.get_current_log()
+    assert step == 2 and len(log) >= 4 and all(np.isfinite(v) for v in log.values())

@@ -1,6 +1,7 @@
 """create_dataset / create_dataloader of the engine (reference: codes/data/__init__.py:8-97).
 
-`mode: aligned` builds data.aligned_dataset.AlignedWindowDataset (uint8 crop windows); create_dataloader wraps the
+`mode: aligned` builds data.aligned_dataset.AlignedWindowDataset (uint8 crop windows; `outputs: AB` the paired A / B variant),
+`mode: unaligned` the unpaired A / B dataset of the image-to-image models; create_dataloader wraps the
 torch DataLoader (same parameters as the reference: batch_size, use_shuffle, n_workers, drop_last, pin_memory) in a
 DeviceFeeder, so iterating it yields the reference's batch dicts with device fp32 tensors.  `batch_size` keeps the
 reference's meaning -- the GLOBAL batch (options/README.md:31): with one process per GPU each rank loads
@@ -14,8 +15,13 @@ from .feeder import DeviceFeeder
 def create_dataset(dataset_opt):
     mode = str(dataset_opt["mode"]).lower()
     if mode in ("aligned", "lrhr", "lrhrotf", "lrhrc"):
-        from .aligned_dataset import AlignedWindowDataset
+        from .aligned_dataset import AlignedABWindowDataset, AlignedWindowDataset
+        if str(dataset_opt.get("outputs", "LRHR")).upper() == "AB" and dataset_opt.get("dataroot_A") and dataset_opt.get("dataroot_B"):
+            return AlignedABWindowDataset(dataset_opt)          # paired image-to-image data (Pix2Pix)
         return AlignedWindowDataset(dataset_opt)
+    if mode == "unaligned":                                     # unpaired image-to-image data (CycleGAN)
+        from .aligned_dataset import UnalignedWindowDataset
+        return UnalignedWindowDataset(dataset_opt)
     raise NotImplementedError("Dataset [{:s}] is outside the SR hot path of the HIP engine".format(mode))
 
 

@@ -103,3 +103,51 @@ class AlignedWindowDataset(data.Dataset):
             flags |= 4
         return {"LR": np.ascontiguousarray(lr_w), "HR": np.ascontiguousarray(hr_w), "flags": flags,
                 "LR_path": self.lr_paths[index], "HR_path": self.hr_paths[index]}
+
+
+class UnalignedWindowDataset(data.Dataset):
+    """Unpaired A / B image folders for the image-to-image models (codes/data/unaligned_dataset.py:8-145, `mode: unaligned`,
+    `preprocess: crop`): image A by index (wrapped into range), image B at a random index unless `serial_batches`
+    (read_single_dataset, base_dataset.py:343-359 -- the `random.randint` is drawn before A's transform parameters, like
+    the reference reads B before get_params), then TWO independent parameter draws (get_params for A, then for B:
+    unaligned_dataset.py:93-98), a crop window per image and per-image flags (`flags_A`, `flags_B`: the feeder applies each
+    image's own flip / rot90).  Returns the reference's batch-dict entries {'A', 'B', 'A_path', 'B_path'} (:137-139)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.crop = int(opt["crop_size"])
+        self.use_flip, self.use_rot = bool(opt.get("use_flip")), bool(opt.get("use_rot"))
+        pre = str(opt.get("preprocess", "crop") or "crop")
+        if pre not in ("crop", "none"):
+            raise NotImplementedError("preprocess [%s]: the HIP engine feeder ships crop windows (`preprocess: crop`)" % pre)
+        self.a_paths = _list_images(opt["dataroot_A"])
+        self.b_paths = _list_images(opt["dataroot_B"])
+        self.serial = bool(opt.get("serial_batches"))
+
+    def __len__(self):
+        return max(len(self.a_paths), len(self.b_paths))
+
+    def _flags(self, p):
+        flags = (1 if (self.use_flip and p["flip"]) else 0) | (2 if (self.use_rot and p["rot"]) else 0)
+        if flags & 2 and p["vflip"]:
+            flags |= 4
+        return flags
+
+    def __getitem__(self, index):
+        a_path = self.a_paths[index % len(self.a_paths)]
+        b_path = self.b_paths[index % len(self.b_paths) if self.serial else random.randint(0, len(self.b_paths) - 1)]
+        img_a, img_b = read_image_bgr(a_path), read_image_bgr(b_path)
+        pa = paired_params((img_a.shape[1], img_a.shape[0]), self.crop)
+        pb = paired_params((img_b.shape[1], img_b.shape[0]), self.crop)
+        return {"A": np.ascontiguousarray(window(img_a, pa["crop_pos"], self.crop)),
+                "B": np.ascontiguousarray(window(img_b, pb["crop_pos"], self.crop)),
+                "flags_A": self._flags(pa), "flags_B": self._flags(pb), "A_path": a_path, "B_path": b_path}
+
+
+class AlignedABWindowDataset(AlignedWindowDataset):
+    """Paired A / B folders with `outputs: AB` (codes/data/aligned_dataset.py:166-175 returns {'A','B','A_path','B_path'} instead
+    of LR / HR): the paired windows of AlignedWindowDataset under the image-to-image names (scale 1: one crop position)."""
+
+    def __getitem__(self, index):
+        d = super().__getitem__(index)
+        return {"A": d["LR"], "B": d["HR"], "flags": d["flags"], "A_path": d["LR_path"], "B_path": d["HR_path"]}

@@ -27,7 +27,7 @@ IMAGE_KEYS = ("LR", "HR", "A", "B", "ref")
 
 class _Slot:
     def __init__(self):
-        self.pinned, self.dev_u8, self.dev_flags, self.out = {}, {}, None, {}
+        self.pinned, self.dev_u8, self.dev_flags, self.out = {}, {}, {}, {}
         self.ready = torch.cuda.Event()
         self.free = None           # recorded on the compute stream when the consumer moved on
         self.batch = None
@@ -79,21 +79,27 @@ class DeviceFeeder:
         with torch.cuda.stream(self.copy_stream):
             if slot.free is not None:
                 self.copy_stream.wait_event(slot.free)       # the step that consumed this slot's tensors is past
-            flags = batch.get("flags")
-            any_rot = 0
-            dflags = None
-            if flags is not None:
+            def device_flags(name):
+                """-> (device int32 flags or None, any rotation in the batch) for `flags` or a per-image `flags_<key>` entry."""
+                flags = batch.get(name)
+                if flags is None:
+                    return None, 0
                 f = _as_host_tensor(flags).to(torch.int32).contiguous()
-                any_rot = int(bool((f & 2).any()))
-                if slot.dev_flags is None or slot.dev_flags.numel() != f.numel():
-                    slot.dev_flags = torch.empty(f.numel(), dtype=torch.int32, device=self.device)
-                slot.dev_flags.copy_(f, non_blocking=False)  # a few bytes
-                dflags = slot.dev_flags
+                d = slot.dev_flags.get(name)
+                if d is None or d.numel() != f.numel():
+                    d = torch.empty(f.numel(), dtype=torch.int32, device=self.device)
+                    slot.dev_flags[name] = d
+                d.copy_(f, non_blocking=False)               # a few bytes
+                return d, int(bool((f & 2).any()))
+
+            shared = device_flags("flags")
             for key, val in batch.items():
                 if key not in IMAGE_KEYS:
-                    if key != "flags":
+                    if key != "flags" and not key.startswith("flags_"):
                         out[key] = val
                     continue
+                # unpaired datasets (mode: unaligned) carry one flag word per image: flags_A / flags_B
+                dflags, any_rot = device_flags("flags_" + key) if ("flags_" + key) in batch else shared
                 host = _as_host_tensor(val)
                 if host.dtype == torch.uint8:
                     if host.dim() != 4:
