@@ -63,6 +63,10 @@ def test_i2i_step_vs_reference_golden(case, tmp_path):
     TI.test_i2i_step_matches_reference_golden(case, tmp_path)
 
 
+def test_i2i_amp_policy_step(tmp_path):
+    TI.test_i2i_amp_bf16_step_tracks_the_fp32_oracle("pix2pix", tmp_path)
+
+
 def test_amp_policy_step(tmp_path):
     TS.test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, "discriminator_vgg")
 

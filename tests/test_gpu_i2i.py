@@ -101,3 +101,46 @@ def test_i2i_step_matches_oracle_at_256(kind, tmp_path):
     check_logs(model.get_current_log(), ref_log, 2e-4)
     diff = (model.fake_B.detach().cpu() - orc.fake_B.detach()).abs()
     assert diff.mean().item() <= 5e-5 and diff.max().item() <= 2e-3, (diff.mean().item(), diff.max().item())
+
+
+@pytest.mark.parametrize("kind", ["pix2pix", "cyclegan"])
+def test_i2i_amp_bf16_step_tracks_the_fp32_oracle(kind, tmp_path):
+    """`use_amp: true` as shipped by options/i2i/train_{pix2pix,cyclegan}.yml: bf16 matrix-core operands (every MFMA launch of
+    the generators and PatchGANs: 3x3 / 4x4-s2 tiles, the im2col GEMMs of the 4x4-s1 layers, the taps-in-K image layers and
+    all weight gradients), fp32 accumulation, InstanceNorm / BatchNorm / losses / Adam in fp32.  Two steps against the fp32
+    CPU oracle: the loss scalars within 3 % (bf16 resolution 2^-8 per operand), the generated image within 6e-2 (range 2)
+    and NOT bit-equal to an fp32 run."""
+    from oracle import i2i_oracle
+    from trainner_amd import hip, ops
+    kw = dict(model=kind, batch=2, crop=64, n_blocks=2, ngf=16, ndf=16, pixel_weight=100.0 if kind == "pix2pix" else 10.0,
+              lambda_identity=0.5 if kind == "cyclegan" else None)
+    try:
+        opt, model = build_i2i_model(dict(kw, amp=True), tmp_path)
+        assert model.amp and ops.MMA == hip.MMA_BF16
+        states = {}
+        for i, n in enumerate(model.model_names):
+            net = getattr(model, "net" + n)
+            states[n] = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, 500 + i)
+            net.load_state_dict(states[n])
+        common = dict(n_blocks=2, norm="instance", gan_type="vanilla", pixel_weight=kw["pixel_weight"])
+        if kind == "pix2pix":
+            orc = i2i_oracle.OraclePix2PixStep(states["G"], states["D"], **common)
+        else:
+            orc = i2i_oracle.OracleCycleGANStep(states["G_A"], states["G_B"], states["D_A"], states["D_B"], lambda_identity=0.5, **common)
+        worst = 0.0
+        for s in (1, 2):
+            A, B = detrand.uniform((2, 3, 64, 64), 95 + s, -1.0, 1.0), detrand.uniform((2, 3, 64, 64), 85 + s, -1.0, 1.0)
+            ref_log = orc.step(A, B)
+            model.feed_data({"A": A, "B": B, "A_path": ["a", "b"]})
+            model.optimize_parameters(s)
+            log = model.get_current_log()
+            assert list(log.keys()) == list(ref_log.keys())
+            for k, v in ref_log.items():
+                if k.startswith("D_"):
+                    assert abs(log[k] - v) <= 2e-2, (s, k, log[k], v)        # raw mean logits around 0
+                else:
+                    assert abs(log[k] - v) <= 0.03 * abs(v) + 1e-4, (s, k, log[k], v)
+            worst = max(worst, (model.fake_B.detach().cpu() - orc.fake_B.detach()).abs().max().item())
+        assert 1e-5 < worst < 6e-2, worst          # (two InstanceNorm-normalised ResNet blocks + tanh: range 2)
+    finally:
+        ops.MMA = hip.MMA_F32

@@ -112,6 +112,21 @@ int dispatch_conv(const ConvK &k, int tw, int nt, int tiles, hipStream_t s) {
     return nt == 2 ? launch_conv<MODE, 8, 2>(k, tiles, s) : launch_conv<MODE, 8, 1>(k, tiles, s);
 }
 
+// Tile width of a launch (MT = 2: 256-pixel tiles of 8 x 32, 16 x 16 or 32 x 8): the shape that covers the tile space with the
+// fewest padded pixels, the widest on ties (power-of-two sizes keep 8 x 32; a 66 x 66 reflection-padded grid takes 16 x 16:
+// 25 instead of 27 tiles per image).
+int conv_pick_tw(int sw, int sh) {
+    int best = 0;
+    int64_t best_area = 0;
+    for (int tw = 32; tw >= 8; tw >>= 1) {
+        if (tw > 8 && sw < tw) continue;                     // (narrow images: as before)
+        const int th = 256 / tw;
+        const int64_t area = (int64_t)tnr_cdiv(sw, tw) * tw * tnr_cdiv(sh, th) * th;
+        if (best == 0 || area < best_area) { best = tw; best_area = area; }
+    }
+    return best;
+}
+
 // Split-K factor of a launch.  Only plain epilogues (bias / activation / alpha) can be deferred to the reduce
 // launch, and only launches that leave most of the 512 workgroup slots empty while looping over >= 32 input
 // chunks are worth a second launch: the 512-channel discriminator layers at 16x16 and below.
@@ -179,7 +194,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
             break;
     }
     k.th_space = sh; k.tw_space = sw;
-    const int tw = sw >= 32 ? 32 : (sw >= 16 ? 16 : 8);
+    const int tw = conv_pick_tw(sw, sh);
     const int nt = d->Cout > 32 ? 2 : 1;
     // 32-cout 3x3 layers (the dense-block convs and their gradients): 4 M-tiles per wave (16x32 pixel
     // tile) so the weight slab and the fixed per-workgroup costs are amortised like in the 64-cout kernel
@@ -235,7 +250,7 @@ extern "C" int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d) {
     if (d == nullptr) return 0;
     int sh = d->Ho, sw = d->Wo;
     if (d->mode == TNR_DGRAD_4x4_S2) { sh = d->H; sw = d->W; }
-    const int tw = sw >= 32 ? 32 : (sw >= 16 ? 16 : 8);
+    const int tw = conv_pick_tw(sw, sh);
     const int nt = d->Cout > 32 ? 2 : 1;
     const bool big_m = (d->mode == TNR_CONV_3x3) && nt == 1 && tw == 32 && sh >= 16;
     const int th = (big_m ? 512 : 256) / tw;
