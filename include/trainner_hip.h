@@ -320,6 +320,17 @@ int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const fl
                      const float *beta, float *running_mean, float *running_var, int64_t *num_batches,
                      float momentum, float eps, float *save_mean, float *save_invstd, int32_t act,
                      float slope, void *ws, void *stream);
+/* tnr_bn_train_fwd that also records, in stat64[2 C] (fp64: batch mean, unbiased variance; may be NULL), the exact values of its
+ * running-statistics update, and tnr_bn_replay_running, which applies that update (and the batch counter increment) once more:
+ * the side effects of a second training-mode forward over the same batch with the same parameters.  The SR step shows the
+ * discriminator the real and the fake batch twice (generator stage sr_model.py:170-177 -> losses.py:398-403; discriminator stage
+ * :190-193 -> losses.py:471-478) between two discriminator updates: the engine keeps the first pass's activations and replays
+ * only these side effects instead of recomputing an identical forward (models/sr_model.py, HipNet.memoize).               */
+int tnr_bn_train_fwd_stats(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const float *gamma, const float *beta,
+                           float *running_mean, float *running_var, int64_t *num_batches, float momentum, float eps,
+                           float *save_mean, float *save_invstd, double *stat64, int32_t act, float slope, void *ws, void *stream);
+int tnr_bn_replay_running(float *running_mean, float *running_var, int64_t *num_batches, const double *stat64, int32_t C,
+                          float momentum, void *stream);
 int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int64_t pixels, int32_t C,
                      const float *gamma, const float *save_mean, const float *save_invstd, float mslope,
                      float *dgamma, float *dbeta, float acc_beta, void *ws, void *stream);

@@ -342,14 +342,32 @@ def fill(t, value=0.0):
     t.fill_(value)
 
 
+def bn_replay_running(running_mean, running_var, num_batches, stat64, momentum=0.1):
+    C = running_mean.numel()
+    running_mean.copy_(((1.0 - momentum) * running_mean.double() + momentum * stat64[:C]).float())
+    running_var.copy_(((1.0 - momentum) * running_var.double() + momentum * stat64[C:]).float())
+    if num_batches is not None:
+        num_batches += 1
+
+
 def bn_train_fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save_mean, save_invstd, momentum=0.1,
-                 eps=1e-5, act=ops.ACT_LRELU, slope=0.2):
+                 eps=1e-5, act=ops.ACT_LRELU, slope=0.2, stat64=None):
     zin = _nchw(z)
+    C = zin.shape[1]
+    n = zin.numel() / C
+    mean64 = zin.double().mean(dim=(0, 2, 3))
+    unb64 = zin.double().var(dim=(0, 2, 3), unbiased=False) * (n / max(n - 1, 1))
+    if stat64 is not None:
+        stat64[:C].copy_(mean64)
+        stat64[C:].copy_(unb64)
+    if running_mean is not None:          # the kernel's update: fp64 arithmetic, one rounding to fp32 (tnr_bn_replay_running repeats it)
+        running_mean.copy_(((1.0 - momentum) * running_mean.double() + momentum * mean64).float())
+        running_var.copy_(((1.0 - momentum) * running_var.double() + momentum * unb64).float())
     mean = zin.mean(dim=(0, 2, 3))
     var = zin.var(dim=(0, 2, 3), unbiased=False)
     save_mean.copy_(mean)
     save_invstd.copy_(1.0 / torch.sqrt(var + eps))
-    out = F.batch_norm(zin, running_mean, running_var, gamma.detach(), beta.detach(), True, momentum, eps)
+    out = F.batch_norm(zin, None, None, gamma.detach(), beta.detach(), True, momentum, eps)
     if num_batches is not None:
         num_batches += 1
     out = F.leaky_relu(out, slope) if act == ops.ACT_LRELU else (F.relu(out) if act == ops.ACT_RELU else out)
@@ -482,7 +500,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
 
 
-_NAMES = ["instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]
@@ -515,12 +533,13 @@ def chunked_bn(chunks):
             m, s = torch.empty_like(save_mean), torch.empty_like(save_invstd)
             rm = running_mean if keep else (None if running_mean is None else running_mean.clone())
             rv = running_var if keep else (None if running_var is None else running_var.clone())
-            bn_train_fwd(_split(z, i), _split(y, i), gamma, beta, rm, rv, num_batches if keep else None, m, s, **kw)
+            kw_i = kw if keep else {k: v for k, v in kw.items() if k != "stat64"}      # (replica 0's statistics are the ones kept)
+            bn_train_fwd(_split(z, i), _split(y, i), gamma, beta, rm, rv, num_batches if keep else None, m, s, **kw_i)
             per.append((m, s))
         stats[save_mean.data_ptr()] = (save_mean, per)      # holding save_mean keeps the key unique
 
     def bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, **kw):
-        _, per = stats.pop(save_mean.data_ptr())
+        _, per = stats[save_mean.data_ptr()]                 # (kept: a memoized forward's activations serve two backward passes)
         for i in range(chunks):
             bn_train_bwd(_split(gy, i), _split(y, i), _split(z, i), _split(gz, i), gamma, per[i][0], per[i][1],
                          dgamma=dgamma, dbeta=dbeta, acc_beta=acc_beta if i == 0 else 1.0, **kw)

@@ -63,6 +63,11 @@ def test_i2i_step_vs_reference_golden(case, tmp_path):
     TI.test_i2i_step_matches_reference_golden(case, tmp_path)
 
 
+@pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
+def test_discriminator_forward_memoization(tmp_path, monkeypatch, d_type):
+    TS.test_discriminator_forward_memoization_is_exact(tmp_path, monkeypatch, d_type)
+
+
 def test_i2i_amp_policy_step(tmp_path):
     TI.test_i2i_amp_bf16_step_tracks_the_fp32_oracle("pix2pix", tmp_path)
 

@@ -270,3 +270,40 @@ def test_dp_collectives_single_rank():
                "--master-port", str(29950 + os.getpid() % 40), worker], dict(env2, TNR_DP_BACKEND="abi"))
     assert abi["active"] is True and abi.get("abi") is True
     assert plain["logs"] == abi["logs"] and plain["w"] == abi["w"]
+
+
+@pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
+def test_discriminator_forward_memoization_is_exact(tmp_path, monkeypatch, d_type):
+    """engine.HipNet.memoize (on for SRModel's discriminator): the discriminator-stage forwards over the real / generated batch
+    reuse the generator stage's (same inputs, same discriminator weights) and only replay the BatchNorm running-statistics
+    update.  Three steps with and without it must agree BIT FOR BIT: logs, fake_H, every G / D weight and BatchNorm buffer."""
+    kw = dict(nb=1, batch=2, crop=64, d_nf=16, d_type=d_type)
+
+    def run(memo, sub):
+        monkeypatch.setenv("TNR_D_MEMO", "1" if memo else "0")
+        (tmp_path / sub).mkdir()
+        opt, model = build_engine_model(kw, tmp_path / sub)
+        assert model.netD.memoize == memo
+        g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+        d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+        load_initial(model, g, d, FX.vgg_state(77))
+        logs = []
+        for s in (1, 2, 3):
+            LR, HR = detrand.synthetic_pair(2, 64, 30 + s)
+            model.feed_data({"LR": LR, "HR": HR})
+            model.optimize_parameters(s)
+            logs.append(model.get_current_log())
+        gsd = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+        dsd = {k: v.detach().cpu() for k, v in model.netD.state_dict().items()}
+        return logs, model.fake_H.detach().cpu(), gsd, dsd
+
+    la, fa, ga, da = run(True, "memo")
+    lb, fb, gb, db = run(False, "plain")
+    assert la == lb
+    assert torch.equal(fa, fb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in da:
+        assert torch.equal(da[k], db[k]), k
+    if d_type == "discriminator_vgg":
+        assert int(da["features.3.num_batches_tracked"]) == 12          # 4 forwards per step, counted whether computed or replayed

@@ -115,7 +115,7 @@ __device__ __forceinline__ void bn_sum_partials(const double *partial, int nbloc
 
 __global__ void __launch_bounds__(256)
 bn_fwd_finalize_kernel(const double *partial, int nblocks, int C, int64_t pixels, float *running_mean, float *running_var,
-                       int64_t *num_batches, float momentum, float eps, float *save_mean, float *save_invstd) {
+                       int64_t *num_batches, float momentum, float eps, float *save_mean, float *save_invstd, double *stat64) {
     __shared__ double sh[8][2][33];
     partial += (size_t)blockIdx.y * nblocks * C * 2;       // statistics group (see bn_partial_kernel)
     save_mean += (size_t)blockIdx.y * C;
@@ -131,10 +131,14 @@ bn_fwd_finalize_kernel(const double *partial, int nblocks, int C, int64_t pixels
         if (var < 0) var = 0;
         save_mean[c] = (float)mean;
         save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = n > 1 ? var * n / (n - 1) : var;
         if (running_mean) {
-            const double unbiased = n > 1 ? var * n / (n - 1) : var;
             running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
             running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (stat64) {          // the exact values of the running-statistics update (tnr_bn_replay_running re-applies it)
+            stat64[c] = mean;
+            stat64[C + c] = unbiased;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
@@ -445,9 +449,10 @@ inline unsigned grid_for(int64_t n) {
 extern "C" int64_t tnr_bn_workspace_bytes(int32_t C) { return (int64_t)(RED_BLOCKS + 1) * C * 2 * sizeof(double); }
 extern "C" int64_t tnr_reduce_workspace_bytes(void) { return (int64_t)2048 * sizeof(double); }
 
-extern "C" int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const float *gamma, const float *beta,
-                                float *running_mean, float *running_var, int64_t *num_batches, float momentum, float eps,
-                                float *save_mean, float *save_invstd, int32_t act, float slope, void *ws, void *stream) {
+extern "C" int tnr_bn_train_fwd_stats(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const float *gamma, const float *beta,
+                                      float *running_mean, float *running_var, int64_t *num_batches, float momentum, float eps,
+                                      float *save_mean, float *save_invstd, double *stat64, int32_t act, float slope, void *ws,
+                                      void *stream) {
     TNR_REQUIRE(z.ptr && y.ptr && gamma && beta && save_mean && save_invstd && ws, "bn_fwd: null pointer");
     TNR_REQUIRE((C % 4) == 0 && C <= 1024 && (256 % (C / 4) == 0 || C / 4 > 0), "bn_fwd: unsupported C %d", C);
     TNR_REQUIRE(C / 4 <= 256, "bn_fwd: C too large");
@@ -458,10 +463,39 @@ extern "C" int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t 
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblocks), dim3(256), lds, s, z.ptr, z.ctot, z.coff, nullptr, 0, 0, nullptr, 0,
                        0, nullptr, 0.f, pixels, C, ppb, partial);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(tnr_cdiv(C, 32)), dim3(256), 0, s, partial, nblocks, C, pixels,
-                       running_mean, running_var, num_batches, momentum, eps, save_mean, save_invstd);
+                       running_mean, running_var, num_batches, momentum, eps, save_mean, save_invstd, stat64);
     hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, z.ptr, z.ctot, z.coff, y.ptr,
                        y.ctot, y.coff, pixels, C, gamma, beta, save_mean, save_invstd, act, slope);
     return tnr_check_launch("bn_train_fwd");
+}
+
+extern "C" int tnr_bn_train_fwd(tnr_view z, tnr_view y, int64_t pixels, int32_t C, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, int64_t *num_batches, float momentum, float eps,
+                                float *save_mean, float *save_invstd, int32_t act, float slope, void *ws, void *stream) {
+    return tnr_bn_train_fwd_stats(z, y, pixels, C, gamma, beta, running_mean, running_var, num_batches, momentum, eps, save_mean,
+                                  save_invstd, nullptr, act, slope, ws, stream);
+}
+
+namespace {
+__global__ void bn_replay_kernel(float *running_mean, float *running_var, int64_t *num_batches, const double *stat64, int C, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * stat64[c]);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * stat64[C + c]);
+    }
+    if (c == 0 && num_batches) *num_batches += 1;
+}
+}  // namespace
+
+// The side effects of ONE MORE training-mode forward over the same batch (running statistics momentum update, batch counter),
+// from the statistics tnr_bn_train_fwd_stats recorded: a forward pass whose result is already known (same input, same
+// parameters: the discriminator sees the real / fake batch twice per SR step, sr_model.py:170-177,190-193) is not recomputed.
+extern "C" int tnr_bn_replay_running(float *running_mean, float *running_var, int64_t *num_batches, const double *stat64, int32_t C,
+                                     float momentum, void *stream) {
+    TNR_REQUIRE(running_mean && running_var && stat64 && C > 0, "bn_replay_running: bad arguments");
+    hipLaunchKernelGGL(bn_replay_kernel, dim3(tnr_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean, running_var, num_batches,
+                       stat64, C, momentum);
+    return tnr_check_launch("bn_replay_running");
 }
 
 extern "C" int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int64_t pixels, int32_t C,
@@ -502,7 +536,7 @@ extern "C" int tnr_instnorm_fwd(tnr_view z, tnr_view y, int32_t N, int64_t pixel
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(nblocks, N), dim3(256), lds, s, z.ptr, z.ctot, z.coff, nullptr, 0, 0, nullptr, 0,
                        0, nullptr, 0.f, pixels, C, ppb, partial);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(tnr_cdiv(C, 32), N), dim3(256), 0, s, partial, nblocks, C, pixels,
-                       nullptr, nullptr, nullptr, 0.f, eps, save_mean, save_invstd);
+                       nullptr, nullptr, nullptr, 0.f, eps, save_mean, save_invstd, nullptr);
     int64_t gx = tnr_cdiv64(pixels * (C / 4), 256);
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(bn_fwd_apply_kernel, dim3((unsigned)gx, N), dim3(256), 0, s, z.ptr, z.ctot, z.coff, y.ptr,

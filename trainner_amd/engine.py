@@ -109,8 +109,18 @@ class _NetFn(torch.autograd.Function):
         # (grad mode is always off inside Function.forward; needs_input_grad already accounts for it)
         need_param_grad = any(ctx.needs_input_grad[2:])
         need_graph = ctx.needs_input_grad[1] or need_param_grad
-        out, saved = net.engine_forward(x, save=need_graph)
-        ctx.net, ctx.saved, ctx.need_param_grad = net, saved, need_param_grad
+        memo = net._memo_lookup(x) if (net.memoize and net.training) else None
+        if memo is not None and memo[1] is not None:
+            # same input values, same parameters as an earlier forward of this step: its output and saved activations ARE this
+            # forward's; only the side effects of running it again (BatchNorm running statistics) are replayed
+            out, saved = memo
+            net.replay_forward_side_effects(saved)
+            out = out.detach()
+        else:
+            out, saved = net.engine_forward(x, save=need_graph or (net.memoize and net.training))
+            if net.memoize and net.training:
+                net._memo_store(x, out, saved)
+        ctx.net, ctx.saved, ctx.need_param_grad = net, (saved if need_graph else None), need_param_grad
         return out
 
     @staticmethod
@@ -130,7 +140,36 @@ class _NetFn(torch.autograd.Function):
 class HipNet(torch.nn.Module):
     """Base class of the engine's networks: flat parameters + the autograd bridge."""
 
+    # Forward memoization (off by default; the SR model switches it on for its discriminator): a training-mode forward whose
+    # input tensor (same storage, same version counter) and parameter version match an earlier forward is not recomputed --
+    # output and saved activations are shared, backward passes only read them.  SRModel.optimize_parameters shows the
+    # discriminator the real batch and the generated batch twice between two discriminator updates (generator stage, then
+    # discriminator stage on `fake.detach()`): 2 of its 4 forward passes per step are such repeats.  Entries hold a reference
+    # to their input (its address cannot be recycled while the entry lives) and die with the parameter version.
+    memoize = False
+
+    def _memo_key(self, x):
+        fp = self.flat_params()
+        return (fp.version, fp.flat._version), (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version)
+
+    def _memo_lookup(self, x):
+        ver, key = self._memo_key(x)
+        if self._memo_ver != ver:
+            self._memo, self._memo_ver = {}, ver
+        hit = self._memo.get(key)
+        return None if hit is None else (hit[1], hit[2])
+
+    def _memo_store(self, x, out, saved):
+        ver, key = self._memo_key(x)
+        if self._memo_ver != ver:
+            self._memo, self._memo_ver = {}, ver
+        self._memo[key] = (x.detach(), out, saved)        # (detached alias: pins the storage, not the autograd graph)
+
+    def replay_forward_side_effects(self, saved):
+        """Hook: what a repeated training-mode forward would change besides its outputs (BatchNorm running statistics)."""
+
     def _init_engine(self):
+        self._memo, self._memo_ver = {}, None
         self._flat = FlatParams(self)
         self._packer = None
         self._dense_packer = None

@@ -60,7 +60,7 @@ class Discriminator_VGG(HipNet):
         dev, sl, act = x.device, self.slope, self.act
         x4 = View(new_act(N, S, S, 4, dev))
         ops.nchw_to_nhwc(x, x4, Cpad=4)
-        cur, acts = x4, []
+        cur, acts, bn_stats = x4, [], []
         for conv, bn in self._ops:
             m = conv.mod
             Ho = cur.H // m.stride
@@ -74,9 +74,11 @@ class Discriminator_VGG(HipNet):
                 y = View(new_act(N, Ho, Ho, m.out_channels, dev))
                 mean = torch.empty(m.out_channels, dtype=torch.float32, device=dev)
                 invstd = torch.empty(m.out_channels, dtype=torch.float32, device=dev)
+                st = torch.empty(2 * m.out_channels, dtype=torch.float64, device=dev) if (save and self.memoize) else None
                 ops.bn_train_fwd(z, y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 mean, invstd, momentum=bn.momentum, eps=bn.eps, act=act, slope=sl)
+                                 mean, invstd, momentum=bn.momentum, eps=bn.eps, act=act, slope=sl, stat64=st)
                 acts.append((cur, z, y, mean, invstd))
+                bn_stats.append((bn, st))
             cur = y
         feat = torch.empty((N, self.final_nc, cur.H, cur.W), dtype=torch.float32, device=dev)   # NCHW flatten order
         ops.nhwc_to_nchw(cur, feat)
@@ -85,8 +87,16 @@ class Discriminator_VGG(HipNet):
         ops.linear_fwd(feat.view(N, -1), l0.weight, l0.bias, hid, act=ops.ACT_LRELU, slope=0.2)
         out = torch.empty((N, 1), dtype=torch.float32, device=dev)
         ops.linear_fwd(hid, l1.weight, l1.bias, out)
-        saved = dict(acts=acts, feat=feat, hid=hid, last=cur) if save else None
+        saved = dict(acts=acts, feat=feat, hid=hid, last=cur, bn_stats=bn_stats) if save else None
         return out, saved
+
+    def replay_forward_side_effects(self, saved):
+        """A repeated training-mode forward over the same batch moves every BatchNorm's running statistics once more (with the
+        same batch statistics) and counts one more batch: exactly what tnr_bn_replay_running applies."""
+        for bn, st in saved["bn_stats"]:
+            if st is None:
+                raise RuntimeError("memoized forward without recorded BatchNorm statistics")
+            ops.bn_replay_running(bn.running_mean, bn.running_var, bn.num_batches_tracked, st, momentum=bn.momentum)
 
     def engine_backward(self, sv, gout, need_input_grad, need_param_grad):
         W, sl = need_param_grad, self.slope

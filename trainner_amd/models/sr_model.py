@@ -7,6 +7,7 @@ HIP-engine networks (single autograd node each), the losses are HIP kernels, cli
 flat buffers and gradients are exchanged with RCCL when WORLD_SIZE > 1.
 """
 import logging
+import os
 from collections import OrderedDict
 
 import torch
@@ -30,6 +31,9 @@ class SRModel(BaseModel):
                 self.model_names.append("D")
                 self.netD = networks.define_D(opt).to(self.device)
                 self.netD.train()
+                # D(real) and D(fake) are evaluated in the generator stage AND in the discriminator stage with unchanged
+                # discriminator weights (sr_model.py:170-177,190-193): the second evaluation reuses the first (engine.HipNet.memoize)
+                self.netD.memoize = os.environ.get("TNR_D_MEMO", "1") != "0"
                 opt_D_nets.append(self.netD)
             self.setup_atg()
         self.load()

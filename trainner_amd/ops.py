@@ -583,13 +583,21 @@ def fill(t, value=0.0):
 # batch norm / linear
 # ----------------------------------------------------------------------------------------------
 def bn_train_fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save_mean, save_invstd,
-                 momentum=0.1, eps=1e-5, act=ACT_LRELU, slope=0.2):
+                 momentum=0.1, eps=1e-5, act=ACT_LRELU, slope=0.2, stat64=None):
+    """stat64: optional fp64 [2 C] tensor that receives the batch mean / unbiased variance of the running-statistics update
+    (bn_replay_running re-applies it)."""
     lib = hip.load()
     ws = WS.get("bn", lib.tnr_bn_workspace_bytes(z.C), z.buf.device)
-    hip.check(lib.tnr_bn_train_fwd(z.c(), y.c(), z.pixels, z.C, gamma.data_ptr(), beta.data_ptr(),
-                                   hip.ptr(running_mean), hip.ptr(running_var), hip.ptr(num_batches), momentum, eps,
-                                   save_mean.data_ptr(), save_invstd.data_ptr(), act, slope, ws.data_ptr(),
-                                   hip.stream()), "bn_train_fwd")
+    hip.check(lib.tnr_bn_train_fwd_stats(z.c(), y.c(), z.pixels, z.C, gamma.data_ptr(), beta.data_ptr(),
+                                         hip.ptr(running_mean), hip.ptr(running_var), hip.ptr(num_batches), momentum, eps,
+                                         save_mean.data_ptr(), save_invstd.data_ptr(), hip.ptr(stat64), act, slope, ws.data_ptr(),
+                                         hip.stream()), "bn_train_fwd")
+
+
+def bn_replay_running(running_mean, running_var, num_batches, stat64, momentum=0.1):
+    """The side effects of one more training-mode forward over the same batch (running statistics, batch counter)."""
+    hip.check(hip.load().tnr_bn_replay_running(running_mean.data_ptr(), running_var.data_ptr(), hip.ptr(num_batches), stat64.data_ptr(),
+                                               running_mean.numel(), momentum, hip.stream()), "bn_replay_running")
 
 
 def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2):
