@@ -22,6 +22,65 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+YAML = """
+name: bench_{model}
+use_tb_logger: false
+model: {model}
+scale: 1
+gpu_ids: [0]
+use_amp: {amp}
+pool_size: {pool}
+datasets:
+  train:
+    name: synthetic
+    mode: aligned
+    outputs: AB
+    dataroot_A: /tmp/none_a
+    dataroot_B: /tmp/none_b
+    znorm: true
+    n_workers: 0
+    batch_size: {batch}
+    virtual_batch_size: {batch}
+    preprocess: crop
+    crop_size: {crop}
+    input_nc: 3
+    output_nc: 3
+path:
+  root: {root}
+network_G:
+  which_model_G: resnet_net
+  n_blocks: 9
+  ngf: 64
+  norm_type: instance
+network_D:
+  which_model_D: patchgan
+  in_nc: {d_in}
+  nf: 64
+train:
+  optim_G: adam
+  lr_G: 2e-4
+  beta1_G: 0.5
+  optim_D: adam
+  lr_D: 2e-4
+  beta1_D: 0.5
+  lr_scheme: Linear
+  fixed_niter: 25000
+  niter_decay: 25000
+  pixel_criterion: l1
+  pixel_weight: {pixel_weight}
+  gan_type: vanilla
+  gan_weight: 1
+  gan_opt:
+    form: standard
+{idt}  manual_seed: 0
+  niter: 50000
+  val_freq: 5000
+logger:
+  print_freq: 200
+  save_checkpoint_freq: 5e3
+"""
+
+
 def g_fwd_flop(size=256, ngf=64, nb=9, nc=3):
     s = size
     f = 2 * s * s * 49 * nc * ngf                                   # c7s1-64
@@ -65,18 +124,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--amp", action="store_true")
     args = ap.parse_args()
-    from oracle import ref_harness          # (only its YAML writer: test infrastructure shared with the parity tests)
     from trainner_amd import hip, ops
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     hip.require_device()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp(prefix="tnr_bench_i2i_")
-    yml = ref_harness.i2i_yaml(name="bench_" + args.model, model=args.model, batch=args.batch, crop=args.size, n_blocks=9, ngf=64,
-                               ndf=64, pixel_weight=100.0 if args.model == "pix2pix" else 10.0,
-                               lambda_identity=0.5 if args.model == "cyclegan" else None,
-                               pool_size=50 if args.model == "cyclegan" else 0, lr_scheme="Linear", out_root=root,
-                               gpu_ids="[0]", amp=args.amp)
+    cyc = args.model == "cyclegan"
+    yml = os.path.join(root, "bench.yml")
+    with open(yml, "w") as f:          # the reference's options/i2i/train_{pix2pix,cyclegan}.yml with the ResNet generator
+        f.write(YAML.format(model=args.model, amp="true" if args.amp else "false", pool=50 if cyc else 0, batch=args.batch, crop=args.size,
+                            root=root, d_in=3 if cyc else 6, pixel_weight=10 if cyc else 100,
+                            idt="  lambda_identity: 0.5\n" if cyc else ""))
     torch.manual_seed(1234)
     model = create_model(options.parse(yml, is_train=True), verbose=False)
     g = torch.Generator().manual_seed(7)
