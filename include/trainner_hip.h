@@ -102,6 +102,10 @@ typedef struct tnr_conv_desc {
      * they enter the matrix core, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 epilogue and storage -- the engine's
      * `use_amp: true` policy (base_model.py:736-744 autocasts the convolutions to half precision).               */
     int32_t mma;
+    /* border handling of the TNR_CONV_3x3 mode: 0 = zero padding (nn.Conv2d padding 1), 1 = nn.ReflectionPad2d(1) in front of
+     * an unpadded convolution (the ResnetGenerator's residual blocks, ResNet_arch.py:118-146): the stager reads row -1 as row 1
+     * and row H as row H - 2, so the reflection-padded tensor is never materialised.                                      */
+    int32_t pad_mode;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -117,6 +121,7 @@ typedef struct tnr_wgrad_desc {
     float alpha, beta;
     float *ws; int64_t ws_bytes;                   /* >= tnr_wgrad_workspace_bytes()                  */
     int32_t mma;                                   /* TNR_MMA_F32 | TNR_MMA_BF16 (see tnr_conv_desc)   */
+    int32_t pad_mode;                              /* TNR_CONV_3x3: 0 zero padding, 1 reflection (tnr_conv_desc) */
 } tnr_wgrad_desc;
 
 typedef struct tnr_pack_item {

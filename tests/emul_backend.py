@@ -92,7 +92,7 @@ def _mm(t):
 
 
 def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
+         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False):
     xin = _mm(_nchw(x))
     w = None if wp.kind == ops.PACK_DENSE_DGRAD else _mm(wp.w.detach())
     if wp.kind == ops.PACK_DENSE_DGRAD:
@@ -101,7 +101,7 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
         xi = _fit(xin, w.shape[1])
         if mode == ops.CONV_3x3_UP2:
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
-        out = F.conv2d(xi, w, None, padding=1)
+        out = F.conv2d(F.pad(xi, (1, 1, 1, 1), mode="reflect"), w, None) if reflect else F.conv2d(xi, w, None, padding=1)
     elif wp.kind == ops.PACK_FWD_S2D:
         out = F.conv2d(_fit(xin, w.shape[1]), w, None, stride=2, padding=1)
     elif wp.kind in (ops.PACK_DGRAD_3x3, ops.PACK_C4_DGRAD3):
@@ -174,7 +174,7 @@ def wgrad_thin(big, small4, dw, db, flip, alpha=1.0, beta=1.0):
         db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
 
 
-def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
+def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0, reflect=False):
     k = 4 if mode == ops.CONV_4x4_S2 else 3
     xin, gin_raw = _mm(_nchw(x)), _nchw(g)
     gin = _mm(gin_raw)
@@ -184,6 +184,8 @@ def wgrad(x, g, dw, db=None, mode=ops.CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0
             out = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), w0, None, padding=1)
         elif mode == ops.CONV_4x4_S2:
             out = F.conv2d(xin, w0, None, stride=2, padding=1)
+        elif reflect:
+            out = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w0, None)
         else:
             out = F.conv2d(xin, w0, None, padding=1)
         (gw,) = torch.autograd.grad(out, w0, gin)
@@ -497,7 +499,7 @@ def conv_chain(stages):
 def wgrad_group(items, mode=ops.CONV_3x3):
     for it in items:
         wgrad(it["x"], it["g"], it["dw"], it.get("db"), mode=mode, cin_begin=it.get("cin_begin", 0),
-              alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0))
+              alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0), reflect=it.get("reflect", False))
 
 
 _NAMES = ["bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",

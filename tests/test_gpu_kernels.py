@@ -910,3 +910,27 @@ def test_bias_grad_column_sum(shape):
     db = torch.full((C,), 2.0, device=DEV)
     ops.bias_grad(ops.View(buf, 4, C), db, alpha=0.5, beta=1.0)
     close(db.cpu(), 2.0 + 0.5 * g.double().sum(dim=(0, 2, 3)).float(), tol=2e-6, what="bias_grad")
+
+
+@pytest.mark.parametrize("case", [(2, 20, 37, 64, 64), (1, 64, 64, 256, 256), (2, 9, 33, 32, 96)])
+def test_conv3x3_reflection_borders(case):
+    """tnr_conv_desc.pad_mode / tnr_wgrad_desc.pad_mode = 1: ReflectionPad2d(1) + conv3x3 (the ResnetGenerator's residual blocks,
+    ResNet_arch.py:118-146) with the reflection done by the stagers of the forward and weight-gradient MFMA kernels."""
+    ops = _ops()
+    N, H, W, Cin, Cout = case
+    x = rnd(N, Cin, H, W, seed=701)
+    w = rnd(Cout, Cin, 3, 3, seed=702, lo=-0.05, hi=0.05)
+    b = rnd(Cout, seed=703)
+    g = rnd(N, Cout, H, W, seed=704)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), wr, br)
+    ref.backward(g)
+    wp, _ = pack(ops, w.to(DEV), ops.PACK_FWD)
+    xb = ops.View(nhwc_buf(x))
+    y = torch.zeros((N, H, W, Cout), device=DEV)
+    ops.conv(xb, wp, ops.View(y), bias=b.to(DEV), reflect=True)
+    close(to_nchw(y, 0, Cout), ref.detach(), what="reflect conv")
+    dw, db = torch.zeros((Cout, Cin, 3, 3), device=DEV), torch.zeros(Cout, device=DEV)
+    ops.wgrad(xb, ops.View(nhwc_buf(g)), dw, db, beta=0.0, reflect=True)
+    close(dw.cpu(), wr.grad, tol=5e-5, what="reflect wgrad")
+    close(db.cpu(), br.grad, tol=5e-5, what="reflect bias grad")

@@ -40,6 +40,7 @@ struct ConvK {
     int ksplit;              // split-K factor (1: none); split s writes its partial sums to y + s * split_stride
     size_t split_stride;
     int bf;                  // operands rounded to bf16 in front of the matrix core (tnr_conv_desc.mma)
+    int reflect;             // TNR_CONV_3x3: rows / columns -1 and H / W are read as 1 and H - 2 / W - 2 (ReflectionPad2d(1))
     int coh_from;            // chain kernel: first input channel another workgroup of THIS launch may have written; chunks below it
                              // were complete before the launch and take ordinary (L2-cached) loads
 };
@@ -157,6 +158,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 Y >>= 1;
                 X >>= 1;
             } else {
+                if (MODE == TNR_CONV_3x3 && a.reflect) {       // (tiles hanging over the image reflect far rows out of range: masked below)
+                    Y = Y < 0 ? -Y : (Y >= a.H ? 2 * a.H - 2 - Y : Y);
+                    X = X < 0 ? -X : (X >= a.W ? 2 * a.W - 2 - X : X);
+                }
                 ok = ok & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
             }
             in_off[it] = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;

@@ -262,7 +262,7 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
         k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
         k.th_space = d->Ho; k.tw_space = d->Wo;
-        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16;
+        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16; k.reflect = d->pad_mode == 1;
         TNR_REQUIRE(d->mma == d0.mma, "conv_chain: stage %d: all stages share one matrix-core precision", i);
         c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
         // input channels below coh_from were complete before the launch (no earlier stage writes them): cached loads

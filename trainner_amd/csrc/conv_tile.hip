@@ -210,6 +210,8 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     const int ksplit = conv_ksplit(d, tiles);
     k.bf = d->mma == TNR_MMA_BF16;
     k.coh_from = 0;
+    k.reflect = d->pad_mode == 1;
+    TNR_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->mode == TNR_CONV_3x3 && d->H >= 2 && d->W >= 2), "conv: pad_mode 1 (reflection) is for TNR_CONV_3x3");
     k.ksplit = 1;
     k.split_stride = 0;
     SplitRedK red;

@@ -28,6 +28,7 @@ struct WgK {
     int N, H, W, Ho, Wo;
     int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits, njobs;
     int bf;                       // operands rounded to bf16 (tnr_wgrad_desc.mma); one setting per launch
+    int reflect;                  // TNR_CONV_3x3: x is read with ReflectionPad2d(1) borders (tnr_wgrad_desc.pad_mode); per launch
     WgJob job[TNR_WGRAD_GROUP_MAX];
 };
 
@@ -191,6 +192,10 @@ wgrad_tile_kernel(const WgK ga) {
                     c = vb * 32 + (c4 & 7) * 4;
                     Y = ty0 + hr - 1;
                     X = tx0 + hc - 1;
+                    if (ga.reflect) {
+                        Y = Y < 0 ? -Y : (Y >= a.H ? 2 * a.H - 2 - Y : Y);
+                        X = X < 0 ? -X : (X >= a.W ? 2 * a.W - 2 - X : X);
+                    }
                     ok = (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
                 }
                 if (i < X_ITEMS && ok && c < a.Cin) {
@@ -616,6 +621,9 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
     k.tiles_x = p0.tiles_x; k.tiles_y = p0.tiles_y; k.tiles_total = p0.tiles_total;
     k.tiles_per_split = p0.tiles_per_split; k.nsplits = p0.splits; k.njobs = n;
     k.bf = d0.mma == TNR_MMA_BF16;
+    k.reflect = d0.pad_mode == 1;
+    TNR_REQUIRE(d0.pad_mode == 0 || (d0.pad_mode == 1 && d0.mode == TNR_CONV_3x3 && d0.H >= 2 && d0.W >= 2), "wgrad: pad_mode 1 (reflection) is for TNR_CONV_3x3");
+    for (int i = 1; i < n; ++i) TNR_REQUIRE(descs[i].pad_mode == d0.pad_mode, "wgrad_group: layer %d: one border mode per launch", i);
     for (int i = 1; i < n; ++i) TNR_REQUIRE(descs[i].mma == d0.mma, "wgrad_group: layer %d: one matrix-core precision per launch", i);
     hipStream_t s = (hipStream_t)stream;
     int rc;

@@ -80,13 +80,16 @@ class ConvOp:
             return
         ops.conv(g, self.packer.get(self.i_d), gx, mode=self.mode_d, **epi)
 
-    def wgrad_item(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+    def wgrad_item(self, x, g, alpha=1.0, cin_begin=0, with_bias=True, reflect=False):
         """Descriptor of dW[:, cin_begin : cin_begin + x.C] (+ db) += alpha * (g (x) x) for ops.wgrad_group."""
         w = self.mod.weight
         db = self.mod.bias.grad if (with_bias and self.mod.bias is not None and cin_begin == 0) else None
-        return dict(x=x, g=g, dw=w.grad, db=db, cin_begin=cin_begin, alpha=alpha, beta=1.0)
+        return dict(x=x, g=g, dw=w.grad, db=db, cin_begin=cin_begin, alpha=alpha, beta=1.0, reflect=reflect)
 
-    def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True):
+    def wgrad(self, x, g, alpha=1.0, cin_begin=0, with_bias=True, reflect=False):
+        if reflect:           # ReflectionPad2d(1) in front of the layer (TNR_CONV_3x3 on the matrix cores only)
+            ops.wgrad_group([self.wgrad_item(x, g, alpha, cin_begin, with_bias, reflect=True)], mode=self.mode_f)
+            return
         if self.thin and ops.IMAGE_C4 and cin_begin == 0 and x.N == g.N and (x.H, x.W) == (g.H, g.W):
             m = self.mod
             db = m.bias.grad if (with_bias and m.bias is not None) else None

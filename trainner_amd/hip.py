@@ -37,7 +37,7 @@ class ConvDesc(C.Structure):
         ("r1", CView), ("r1_ch", c_i), ("beta1", c_f),
         ("r2", CView), ("alpha2", c_f),
         ("m", CView), ("m_lo", c_i), ("m_hi", c_i), ("m_slope", c_f),
-        ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i),
+        ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i), ("pad_mode", c_i),
     ]
 
 
@@ -48,7 +48,7 @@ class WgradDesc(C.Structure):
         ("mode", c_i),
         ("dw", c_p), ("cin_total", c_i), ("cin_begin", c_i),
         ("db", c_p), ("alpha", c_f), ("beta", c_f),
-        ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i),
+        ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i), ("pad_mode", c_i),
     ]
 
 

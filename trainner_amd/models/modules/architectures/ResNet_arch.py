@@ -7,9 +7,10 @@ ReflectionPad(3) + conv7x7(ngf -> out) + Tanh.  norm = InstanceNorm2d (no affine
 then carry a bias) or BatchNorm2d (train mode).  `self.model` is an nn.Sequential with the reference's child indices.
 
 Kernel mapping (all fp32 NHWC):
-  * residual blocks (>= 95 % of the FLOP): the reflection-padded tensor is materialised (tnr_pad2d) and the 3x3 implicit-GEMM
-    MFMA kernel runs over the padded grid (its own zero border only touches the cropped-away rim); backward = zero-embedded
-    gradient -> weight-gradient / data-gradient MFMA kernels -> adjoint of the reflection (tnr_unpad2d fold);
+  * residual blocks (>= 90 % of the FLOP): forward and weight gradient run the 3x3 MFMA kernels on the image grid with the
+    reflection done by the stager (tnr_conv_desc.pad_mode 1: row -1 is read as row 1, row H as row H - 2) -- no padded tensor;
+    the data-gradient is taken with respect to the padded input (zero-embedded gradient -> 3x3 data-gradient kernel on the
+    (H + 2) x (W + 2) grid) and folded back by the adjoint of the reflection (tnr_unpad2d);
   * stride-2 3x3 convolutions and the transposed convolutions: the 4x4 stride-2 MFMA kernels with the 3x3 taps zero-extended
     to 4x4 (3x3 s2 p1 == 4x4 s2 p1 with a zero fourth row / column; ConvTranspose2d(k3,s2,p1,op1) == the data-gradient of
     that convolution, its input gradient == the forward, its weight gradient == the weight gradient with roles swapped);
@@ -293,24 +294,17 @@ class ResnetGenerator(HipNet):
         blocks = []
         for (c1, n1), (c2, n2) in self._blocks:
             h, w_, C = cur.H, cur.W, cur.C
-            xp = View(new_act(N, h + 2, w_ + 2, C, dev))
-            ops.pad2d(cur, xp, 1, True)
-            zp = View(new_act(N, h + 2, w_ + 2, C, dev))
-            c1.fwd(xp, zp)
             z1 = View(new_act(N, h, w_, C, dev))
-            ops.unpad2d(zp, z1, 1, False)
+            c1.fwd(cur, z1, reflect=True)                          # ReflectionPad2d(1) + conv3x3: the stager reflects the borders
             h1 = View(new_act(N, h, w_, C, dev))
             s1 = self._norm_fwd(n1, z1, h1, R)
-            hp = View(new_act(N, h + 2, w_ + 2, C, dev))
-            ops.pad2d(h1, hp, 1, True)
-            c2.fwd(hp, zp)                                          # (zp is scratch: only its cropped centre is kept)
             z2 = View(new_act(N, h, w_, C, dev))
-            ops.unpad2d(zp, z2, 1, False)
+            c2.fwd(h1, z2, reflect=True)
             y2 = View(new_act(N, h, w_, C, dev))
             s2 = self._norm_fwd(n2, z2, y2, NONE)
             out = View(new_act(N, h, w_, C, dev))
             ops.add2(out, cur, y2)
-            blocks.append((xp, z1, h1, s1, hp, z2, y2, s2))
+            blocks.append((cur, z1, h1, s1, z2, y2, s2))
             cur = out
         for i, (p4, mod) in enumerate(zip(self._ups, self._up_mods)):
             z = View(new_act(N, cur.H * 2, cur.W * 2, mod.out_channels, dev))
@@ -371,24 +365,26 @@ class ResnetGenerator(HipNet):
             p4.conv(gz, g)
         # residual blocks
         for bi in range(len(blocks) - 1, -1, -1):
-            xp, z1, h1, s1, hp, z2, y2, s2 = blocks[bi]
+            xin, z1, h1, s1, z2, y2, s2 = blocks[bi]
             (c1, n1), (c2, n2) = self._blocks[bi]
             h, w_, C = z1.H, z1.W, z1.C
             gz2 = View(new_act(N, h, w_, C, dev))
             self._norm_bwd(n2, s2, g, y2, z2, gz2, False, Wg)
+            if Wg:
+                c2.wgrad(h1, gz2, reflect=True)                     # weight gradient over the reflected input, on the image grid
+            # data-gradient with respect to the PADDED input (the zero-embedded gradient through the 3x3 data-gradient kernel
+            # on the (h + 2) x (w + 2) grid), folded back by the adjoint of the reflection
             gzp = View(new_act(N, h + 2, w_ + 2, C, dev))
             ops.pad2d(gz2, gzp, 1, False)
-            if Wg:
-                c2.wgrad(hp, gzp)
             ghp = View(new_act(N, h + 2, w_ + 2, C, dev))
             c2.dgrad(gzp, ghp)
             gh1 = View(new_act(N, h, w_, C, dev))
             ops.unpad2d(ghp, gh1, 1, True)
             gz1 = View(new_act(N, h, w_, C, dev))
             self._norm_bwd(n1, s1, gh1, h1, z1, gz1, True, Wg)
-            ops.pad2d(gz1, gzp, 1, False)
             if Wg:
-                c1.wgrad(xp, gzp)
+                c1.wgrad(xin, gz1, reflect=True)
+            ops.pad2d(gz1, gzp, 1, False)
             c1.dgrad(gzp, ghp)
             gx = View(new_act(N, h, w_, C, dev))
             ops.unpad2d(ghp, gx, 1, True)

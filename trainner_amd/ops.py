@@ -236,7 +236,7 @@ MMA = hip.MMA_F32   # matrix-core operand precision of every MFMA launch below: 
 
 
 def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-               beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2):
+               beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.wp, d.KinP, d.KoutP = wp.t.data_ptr(), wp.KinP, wp.KoutP
@@ -255,6 +255,7 @@ def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, a
     d.m_hi = (y.C if m_hi is None else m_hi)
     d.m_slope = m_slope
     d.mma = MMA
+    d.pad_mode = 1 if reflect else 0          # TNR_CONV_3x3 only: ReflectionPad2d(1) borders instead of zeros
 
 
 IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel for <= 4-channel image layers (A/B switch)
@@ -359,7 +360,7 @@ def small_gemm_ok(x, y, k, stride, epi):
     kernel would be mostly padding and too few to fill the chip) and a plain epilogue."""
     if not SMALL_GEMM or y.pixels > 4096 or (y.pixels % 8) != 0 or (x.C % 4) != 0:
         return False
-    return not any(epi.get(n) is not None for n in ("r1", "r2", "mask"))
+    return not any(epi.get(n) is not None for n in ("r1", "r2", "mask")) and not epi.get("reflect")
 
 
 def conv_small(x, wp_col, y, k, stride, pad=1, **epi):
@@ -390,7 +391,7 @@ def conv_col(x, wp_col, y, k, stride=1, pad=1, **epi):
 WGRAD_GROUP_MAX = 8
 
 
-def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta):
+def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.g = g.c()
@@ -400,11 +401,12 @@ def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta):
     d.db = hip.ptr(db)
     d.alpha, d.beta = alpha, beta
     d.mma = MMA
+    d.pad_mode = 1 if reflect else 0
 
 
-def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0):
+def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0, reflect=False):
     """dw (OIHW, full tensor) += alpha * sum g (x) x over input channels [cin_begin, cin_begin+x.C)."""
-    wgrad_group([dict(x=x, g=g, dw=dw, db=db, cin_begin=cin_begin, alpha=alpha, beta=beta)], mode=mode)
+    wgrad_group([dict(x=x, g=g, dw=dw, db=db, cin_begin=cin_begin, alpha=alpha, beta=beta, reflect=reflect)], mode=mode)
 
 
 def wgrad_group(items, mode=CONV_3x3):
@@ -416,7 +418,7 @@ def wgrad_group(items, mode=CONV_3x3):
     descs = (WgradDesc * n)()
     for d, it in zip(descs, items):
         _wgrad_desc(d, it["x"], it["g"], it["dw"], it.get("db"), mode, it.get("cin_begin", 0),
-                    it.get("alpha", 1.0), it.get("beta", 1.0))
+                    it.get("alpha", 1.0), it.get("beta", 1.0), it.get("reflect", False))
     dev = items[0]["x"].buf.device
     for i, d in enumerate(descs):
         need = lib.tnr_wgrad_workspace_bytes(C.byref(d))
