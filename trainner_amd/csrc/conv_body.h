@@ -41,8 +41,6 @@ struct ConvK {
     size_t split_stride;
     int bf;                  // operands rounded to bf16 in front of the matrix core (tnr_conv_desc.mma)
     int reflect;             // TNR_CONV_3x3: rows / columns -1 and H / W are read as 1 and H - 2 / W - 2 (ReflectionPad2d(1))
-    int coh_from;            // chain kernel: first input channel another workgroup of THIS launch may have written; chunks below it
-                             // were complete before the launch and take ordinary (L2-cached) loads
 };
 
 #ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps, 8 per body call */
@@ -120,12 +118,20 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     const int nchunks = S2D ? 4 * nck : nck;
 
     // per-lane A offsets (dwords) of the MT M-tiles this wave owns
+    // M-tile mi of a wave starts 32 pixels after M-tile mi - 1: with TW == 32 that is exactly one tile row further (a compile-time
+    // LDS offset from one base register); narrower tiles keep one offset per M-tile
     int aoff[MT];
+    if constexpr (TW == 32) {
+        const int base = ((wave * MT) * WT + li) * PST + half * 4;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int p = (wave * MT + mi) * 32 + li;
-        const int r = p / TW, c = p - r * TW;
-        aoff[mi] = (r * WT + c) * PST + half * 4;
+        for (int mi = 0; mi < MT; ++mi) aoff[mi] = base + mi * WT * PST;
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int p = (wave * MT + mi) * 32 + li;
+            const int r = p / TW, c = p - r * TW;
+            aoff[mi] = (r * WT + c) * PST + half * 4;
+        }
     }
     const int boff = li * PST + half * 4;
 
@@ -144,7 +150,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     constexpr int IN_ITEMS = HT * WT * 4, IN_IT = (IN_ITEMS + 255) / 256;
     constexpr int W_ITEMS = NTAPS * NC * 4, W_IT = (W_ITEMS + 255) / 256;
     int in_off[IN_IT];   // element offset into x (without the chunk's channel offset), -1 = zero fill
-    int w_off[W_IT];     // element offset into the packed weights (without chunk offset), -1 = zero fill
+    // packed-weight items: item `it` of a thread is row (tid >> 2) + 64 it of the [tap][cout] slab, i.e. the SAME cout (NC divides
+    // 64 ... or 64 divides NC) and tap t0 + it * (64 / NC) -- one base offset and a uniform stride instead of W_IT offsets
+    static_assert(NC == 32 || NC == 64, "weight staging plan assumes 32 or 64 output channels per block");
+    int w_base;          // element offset of item 0 (without chunk offset), -1 = this thread's cout is beyond KoutP
     if (!S2D && !IMG4) {
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
@@ -167,14 +176,12 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             in_off[it] = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
         }
     }
-#pragma unroll
-    for (int it = 0; it < W_IT; ++it) {
-        const int i = tid + it * 256;
-        const int row = i >> 2, q = i & 3;
+    const int w_tap_stride = (64 / NC) * a.KoutP * (S2D ? 4 * a.KinP : a.KinP);     // wave-uniform
+    {
+        const int row = tid >> 2, q = tid & 3;
         const int t = row / NC, co = row - t * NC;
         const int cog = cb * NC + co;
-        const bool ok = (i < W_ITEMS) & (cog < a.KoutP);
-        w_off[it] = ok ? ((t * a.KoutP + cog) * (S2D ? 4 * a.KinP : a.KinP) + q * 4) : -1;
+        w_base = (cog < a.KoutP) ? ((t * a.KoutP + cog) * (S2D ? 4 * a.KinP : a.KinP) + q * 4) : -1;
     }
     f32x4 rin[IN_IT], rw[W_IT];
 
@@ -213,10 +220,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 if (off != -1) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)(off + c0));
             } else if (COH) {   // invalid items read past the end of the buffer: the hardware range check returns 0
                 const unsigned bo = (off >= 0 && c0 + q * 4 < a.Cin) ? (unsigned)(off + c0) * 4u : 0xfffffff0u;
-                if (c0 >= a.coh_from)       // (chunk-uniform) channels produced inside this launch: system-coherent, past L2
-                    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
-                else
-                    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
             } else if (off >= 0 && c0 + q * 4 < a.Cin) {
                 v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
             }
@@ -225,7 +229,8 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (w_off[it] >= 0) v = *reinterpret_cast<const f32x4 *>(wbase + (size_t)w_off[it] + (S2D ? pp * a.KinP : 0) + c0);
+            if (w_base >= 0 && tid + it * 256 < W_ITEMS)
+                v = *reinterpret_cast<const f32x4 *>(wbase + (size_t)(w_base + it * w_tap_stride) + (S2D ? pp * a.KinP : 0) + c0);
             rw[it] = v;
         }
     };

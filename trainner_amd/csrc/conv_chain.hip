@@ -265,22 +265,6 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16; k.reflect = d->pad_mode == 1;
         TNR_REQUIRE(d->mma == d0.mma, "conv_chain: stage %d: all stages share one matrix-core precision", i);
         c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
-        // input channels below coh_from were complete before the launch (no earlier stage writes them): cached loads
-#ifndef TNR_CHAIN_NCLOAD
-#define TNR_CHAIN_NCLOAD 1
-#endif
-        k.coh_from = 0;
-        if (TNR_CHAIN_NCLOAD) {
-            int lo = 1 << 30;
-            for (int j = 0; j < i; ++j) {
-                const tnr_conv_desc *e = &stages[j];
-                if (e->y.ptr == d->x.ptr && e->y.coff + e->Cout > d->x.coff && e->y.coff < d->x.coff + d->Cin) {
-                    const int first = e->y.coff > d->x.coff ? e->y.coff - d->x.coff : 0;
-                    if (first < lo) lo = first;
-                }
-            }
-            k.coh_from = lo / TNR_CK * TNR_CK;
-        }
     }
     for (int i = n; i < TNR_CHAIN_MAX; ++i) { c.st[i] = c.st[0]; c.wait_chunk[i] = -1; }
     int cap = 0;

@@ -209,7 +209,6 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     // split-K for launches that cannot fill the chip (see tnr_conv_workspace_bytes)
     const int ksplit = conv_ksplit(d, tiles);
     k.bf = d->mma == TNR_MMA_BF16;
-    k.coh_from = 0;
     k.reflect = d->pad_mode == 1;
     TNR_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->mode == TNR_CONV_3x3 && d->H >= 2 && d->W >= 2), "conv: pad_mode 1 (reflection) is for TNR_CONV_3x3");
     k.ksplit = 1;
