@@ -34,7 +34,7 @@ def main():
 
     for name, fn in (("5 launches", per_layer), ("1 chain launch", lambda: ops.conv_chain(st)),
                      ("chain, first 4 stages", lambda: ops.conv_chain(st[:4])), ("4 launches", lambda: [ops.conv(**{k: v for k, v in d.items() if k != "fresh_from"}) for d in st[:4]])):
-        us = timeit(fn, reps=20)
+        us = timeit(fn)
         f = fl if "4" not in name else sum(2.0 * N * H * W * 9 * ci * co for ci, co in shapes[:4])
         print("%-24s %8.1f us  %6.1f TFLOP/s" % (name, us, f / us / 1e6))
     print("chain error flag:", ops.chain_error_flag())

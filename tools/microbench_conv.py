@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from trainner_amd import ops  # noqa: E402
 
 
-def timeit(fn, reps=20):
+def timeit(fn, reps=int(os.environ.get("TNR_REPS", "20"))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

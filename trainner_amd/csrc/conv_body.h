@@ -26,6 +26,21 @@ constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | 
 #define TNR_COH_STORE_AUX TNR_AUX_SC0_SC1
 #endif
 
+// LDS refill without bank conflicts.  A thread's staging item is one float4 = 4 channels of one LDS row (a pixel of the input
+// tile / a [tap][cout] row of the weight slab); a quad of lanes covers a row's 16 channels (one 64-byte global read).  With the
+// 20-dword row stride a ds_write_b128 is processed 8 lanes (two rows) at a time: rows r and r + 1 overlap in 4 banks (36 > 32
+// dwords) -- every refill write took two passes and, worse, the burst of 15 writes per lane delayed the co-resident workgroup's
+// fragment reads (ablation: the refill costs 8 % of the matrix pipe).  Rows r and r + 4 are 80 dwords apart = bank offset 16:
+// disjoint.  So the quads of a wave are dealt rows in the order 0 4 1 5 2 6 3 7 inside every block of 8 rows.
+__device__ __forceinline__ int tnr_stage_row(int i) {      // staging item -> LDS row
+#ifndef TNR_LDS_NOPERM
+    const int Q = i >> 2, k = Q & 7;
+    return (Q & ~7) | ((k >> 1) + ((k & 1) << 2));
+#else
+    return i >> 2;
+#endif
+}
+
 struct ConvK {
     const float *x; int x_ct, x_co;
     int N, H, W, Cin;
@@ -147,8 +162,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // depend on the chunk (except the parity of the space-to-depth view), so they are computed once.
     // Loads of chunk k+1 are issued into registers BEFORE the MFMA phase of chunk k and written to
     // LDS after it (issue-early / write-late): HBM/L2 latency hides under ~10-20k cycles of MFMA.
-    constexpr int IN_ITEMS = HT * WT * 4, IN_IT = (IN_ITEMS + 255) / 256;
-    constexpr int W_ITEMS = NTAPS * NC * 4, W_IT = (W_ITEMS + 255) / 256;
+    // (item ranges rounded up to whole blocks of 8 rows: tnr_stage_row permutes inside a block; rows beyond the tile are skipped)
+    constexpr int IN_ROWS = HT * WT, IN_ITEMS = ((IN_ROWS + 7) / 8) * 8 * 4, IN_IT = (IN_ITEMS + 255) / 256;
+    constexpr int W_ROWS = NTAPS * NC, W_ITEMS = W_ROWS * 4, W_IT = (W_ITEMS + 255) / 256;
+    static_assert(W_ROWS % 8 == 0, "weight slab rows come in blocks of 8");
     int in_off[IN_IT];   // element offset into x (without the chunk's channel offset), -1 = zero fill
     // packed-weight items: item `it` of a thread is row (tid >> 2) + 64 it of the [tap][cout] slab, i.e. the SAME cout (NC divides
     // 64 ... or 64 divides NC) and tap t0 + it * (64 / NC) -- one base offset and a uniform stride instead of W_IT offsets
@@ -158,10 +175,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int i = tid + it * 256;
-            const int pix = i >> 2, q = i & 3;
+            const int pix = tnr_stage_row(i), q = i & 3;
             const int hr = pix / WT, hc = pix - hr * WT;
             int Y = ty0 + hr - (P11 ? 0 : 1), X = tx0 + hc - (P11 ? 0 : 1);
-            bool ok = i < IN_ITEMS;
+            bool ok = pix < IN_ROWS;
             if (UP) {
                 ok = ok & (Y >= 0) & (Y < 2 * a.H) & (X >= 0) & (X < 2 * a.W);
                 Y >>= 1;
@@ -178,14 +195,16 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     }
     const int w_tap_stride = (64 / NC) * a.KoutP * (S2D ? 4 * a.KinP : a.KinP);     // wave-uniform
     {
-        const int row = tid >> 2, q = tid & 3;
+        const int row = tnr_stage_row(tid), q = tid & 3;     // (+ 64 rows per further item: the permutation acts inside blocks of 8)
         const int t = row / NC, co = row - t * NC;
         const int cog = cb * NC + co;
         w_base = (cog < a.KoutP) ? ((t * a.KoutP + cog) * (S2D ? 4 * a.KinP : a.KinP) + q * 4) : -1;
     }
     f32x4 rin[IN_IT], rw[W_IT];
 
-    auto load_chunk = [&](int chunk) {
+    // one staging item (k < IN_IT: input-tile item k, else weight item k - IN_IT) of input chunk `chunk` -> registers
+    constexpr int N_ITEMS = IN_IT + W_IT;
+    auto load_item = [&](int chunk, int k) {
         int c0, pp = 0;
         if (S2D) {
             pp = chunk / nck;
@@ -193,24 +212,24 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         } else {
             c0 = chunk * CK;
         }
-#pragma unroll
-        for (int it = 0; it < IN_IT; ++it) {
+        if (k < IN_IT) {
+            const int it = k;
             const int i = tid + it * 256;
             const int q = i & 3;
             int off;
             if (S2D) {
-                const int pix = i >> 2;
+                const int pix = tnr_stage_row(i);
                 const int hr = pix / WT, hc = pix - hr * WT;
                 const int Y = 2 * (ty0 + hr) - 1 + (pp >> 1), X = 2 * (tx0 + hc) - 1 + (pp & 1);
-                const bool ok = (i < IN_ITEMS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                const bool ok = (pix < IN_ROWS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
                 off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
             } else if (IMG4) {
                 // virtual channels 16*chunk + 4*q .. +3 = the 4 image channels of tap t = 4*chunk + q
-                const int pix = i >> 2;
+                const int pix = tnr_stage_row(i);
                 const int hr = pix / WT, hc = pix - hr * WT;
                 const int t = chunk * 4 + q;
                 const int Y = ty0 + hr + t / 3 - 1, X = tx0 + hc + t % 3 - 1;
-                const bool ok = (i < IN_ITEMS) & (t < 9) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                const bool ok = (pix < IN_ROWS) & (t < 9) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
                 off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co - c0) : -1;   // (+ c0 below cancels: whole pixel)
             } else {
                 off = in_off[it];
@@ -225,25 +244,29 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)off + c0);
             }
             rin[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < W_IT; ++it) {
+        } else {
+            const int it = k - IN_IT;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (w_base >= 0 && tid + it * 256 < W_ITEMS)
                 v = *reinterpret_cast<const f32x4 *>(wbase + (size_t)(w_base + it * w_tap_stride) + (S2D ? pp * a.KinP : 0) + c0);
             rw[it] = v;
         }
     };
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < N_ITEMS; ++k) load_item(chunk, k);
+    };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int it = 0; it < IN_IT; ++it) {
             const int i = tid + it * 256;
-            if (i < IN_ITEMS) *reinterpret_cast<f32x4 *>(s_in + (i >> 2) * PST + (i & 3) * 4) = rin[it];
+            const int row = tnr_stage_row(i);
+            if (row < IN_ROWS) *reinterpret_cast<f32x4 *>(s_in + row * PST + (i & 3) * 4) = rin[it];
         }
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * 256;
-            if (i < W_ITEMS) *reinterpret_cast<f32x4 *>(s_w + (i >> 2) * PST + (i & 3) * 4) = rw[it];
+            if (i < W_ITEMS) *reinterpret_cast<f32x4 *>(s_w + tnr_stage_row(i) * PST + (i & 3) * 4) = rw[it];
         }
     };
 
@@ -256,26 +279,43 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     TNR_STAMP(4);
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         TNR_PH_T(ph0);
+#ifdef TNR_PRIO_REFILL
+        __builtin_amdgcn_s_setprio(TNR_PRIO_REFILL);
+#endif
+#ifndef TNR_ABL_NOBARRIER   /* (ablation builds: timing only, results invalid) */
         __syncthreads();  // previous chunk's fragments are consumed
+#endif
         TNR_PH_T(ph1);
 #ifdef TNR_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         TNR_PH_T(ph2);
+#ifndef TNR_ABL_NOSTORE
         store_chunk();
+#endif
 #ifdef TNR_TIMELINE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         TNR_PH_T(ph2b);
         if (chunk == c_begin + 1) wait.drain();
         TNR_PH_T(ph3);
+#ifndef TNR_ABL_NOBARRIER
         __syncthreads();
+#endif
         TNR_PH_T(ph4);
         if (chunk == c_begin + 1) wait.publish();
         if (chunk == c_begin) TNR_STAMP(1);
         if (chunk + 1 < c_end && chunk + 1 == wait_chunk) wait();
         TNR_PH_T(ph4b);
-        if (chunk + 1 < c_end) load_chunk(chunk + 1);    // in flight during the MFMA phase below
+        // The loads of chunk k+1 are in flight during the MFMA phase below.  They are NOT pushed through the memory-instruction
+        // queue in one burst in front of it (a wave issues in order: its first fragment reads and MFMAs would sit behind 15
+        // vector-memory instructions, with the co-resident workgroup's loads in the same queue) but handed out over the first
+        // three MFMA steps, a third each (measured, dense-block chain: 983.8 us burst, 955.7 one per step, 950.4 a third per
+        // step, 978.3 all in step 0; -DTNR_NO_LOAD_SPREAD restores the burst)
+        const bool have_next = chunk + 1 < c_end;
+#if !defined(TNR_ABL_NOLOAD) && defined(TNR_NO_LOAD_SPREAD)
+        if (have_next) load_chunk(chunk + 1);
+#endif
         TNR_PH_T(ph5);
         // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
         // 8-channel group: MT + NT ds_read_b128 feeding 4*MT*NT MFMAs (>= 1024 matrix-core cycles).  The
@@ -284,6 +324,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         // would otherwise sink the reads next to their first use).  All steps are unrolled: every LDS
         // address is a per-lane base + compile-time offset.
         constexpr int KG = CK / 8, NSTEP = NTAPS * KG;
+#if defined(TNR_PRIO_EPI) || defined(TNR_PRIO_REFILL)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if constexpr (BF) {
             // a step = one tap: 2 (MT + NT) ds_read_b128 into the raw set, converted to bf16x8 AFTER the MFMAs of the
             // previous tap were issued (the reads had a whole MFMA group to land), MT*NT MFMAs of k = 16
@@ -332,6 +375,16 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
                 if (t + 1 < NTAPS) fetch_raw(t + 1);
+#if !defined(TNR_NO_LOAD_SPREAD) && !defined(TNR_ABL_NOLOAD)
+                {
+                    constexpr int SPREAD_TAPS = NTAPS < 3 ? NTAPS : 3;
+                    constexpr int IPT = (N_ITEMS + SPREAD_TAPS - 1) / SPREAD_TAPS;      // staging items issued per tap
+                    if (have_next) {
+#pragma unroll
+                        for (int k = t * IPT; k < (t + 1) * IPT && k < N_ITEMS; ++k) load_item(chunk + 1, k);
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
@@ -379,6 +432,20 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP; ++s_) {
             if (s_ + 1 < NSTEP) fetch(s_ + 1, (s_ + 1) & 1);
+#if !defined(TNR_NO_LOAD_SPREAD) && !defined(TNR_ABL_NOLOAD)
+            {
+#ifdef TNR_LOAD_SPREAD_IPS
+                constexpr int IPS = TNR_LOAD_SPREAD_IPS;
+#else
+                constexpr int SPREAD_STEPS = NSTEP < 3 ? NSTEP : 3;
+                constexpr int IPS = (N_ITEMS + SPREAD_STEPS - 1) / SPREAD_STEPS;     // staging items issued per MFMA step
+#endif
+                if (have_next) {
+#pragma unroll
+                    for (int k = s_ * IPS; k < (s_ + 1) * IPS && k < N_ITEMS; ++k) load_item(chunk + 1, k);
+                }
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             mma(s_ & 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -521,6 +588,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // workgroup barrier: the first version transposed through the operand LDS (64 ds_write_b32 + 16 ds_read_b128
     // per lane between two __syncthreads()); at a stage boundary of the chain kernel that was 14 % of the time.
     TNR_STAMP(2);
+#ifdef TNR_PRIO_EPI
+    __builtin_amdgcn_s_setprio(TNR_PRIO_EPI);          // (experiment) the tile's stores / the next pass's first fetch ahead of the co-resident wave's MFMAs
+#endif
     const int qa = li >> 2, qb = li & 3;               // quad index a (channel quad), position b inside the quad
     const bool b0 = (qb & 1) != 0, b1 = (qb & 2) != 0;
     auto quad_transpose = [&](float &v0, float &v1, float &v2, float &v3) {
