@@ -9,6 +9,8 @@
 // and wgrad_reduce sums the slabs in a fixed order (deterministic split-K) into the OIHW gradient.
 // The 4x4 s2 convolution is handled in its space-to-depth form (2x2 taps over 4*Cin virtual
 // channels), exactly like conv_tile.hip.
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -56,6 +58,16 @@ struct WgCfg {
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 
+// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>) (register arrays need constant indices)
+template <int B, class F, int... I>
+__device__ __forceinline__ void wg_static_for_seq(F &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, B + I>{}), ...);          // one flat fold: nothing for the inliner to give up on
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void wg_static_for(F &&f) {
+    wg_static_for_seq<B>(f, std::make_integer_sequence<int, (E > B ? E - B : 0)>{});
+}
+
 // BF: operands rounded to bf16 in front of the matrix core (tnr_wgrad_desc.mma = TNR_MMA_BF16).  The reduction index of
 // this GEMM is the pixel: a 16-pixel tile row is exactly the k = 16 of one v_mfma_f32_32x32x16_bf16 (lane-half h supplies
 // pixels h, 2 + h, .., 14 + h: the same 8 values it feeds to 8 fp32 k-steps), so a row costs J MFMAs instead of 8 J.
@@ -94,7 +106,7 @@ wgrad_tile_kernel(const WgK ga) {
         const float *x; int x_ct, x_co; int N, H, W, Cin;
         const float *g; int g_ct, g_co; int Ho, Wo, Cout;
         float *ws; int KoutP, KinVP, cinp32; float *dbp;
-        int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits;
+        int tiles_x, tiles_y, tiles_total, tiles_per_split, nsplits, reflect;
     } a;
     a.x = ga.job[ji].x; a.x_ct = ga.job[ji].x_ct; a.x_co = ga.job[ji].x_co;
     a.N = ga.N; a.H = ga.H; a.W = ga.W; a.Cin = ga.job[ji].Cin;
@@ -103,7 +115,7 @@ wgrad_tile_kernel(const WgK ga) {
     a.ws = ga.job[ji].ws; a.KoutP = ga.job[ji].KoutP; a.KinVP = ga.job[ji].KinVP; a.cinp32 = ga.job[ji].cinp32;
     a.dbp = ga.job[ji].dbp;
     a.tiles_x = ga.tiles_x; a.tiles_y = ga.tiles_y; a.tiles_total = ga.tiles_total;
-    a.tiles_per_split = ga.tiles_per_split; a.nsplits = ga.nsplits;
+    a.tiles_per_split = ga.tiles_per_split; a.nsplits = ga.nsplits; a.reflect = ga.reflect;
     const int local = (int)blockIdx.y - ga.job[ji].job_begin;
     const int ncib = ga.job[ji].ncib;
     const int cob = local / ncib, cib = local - cob * ncib;
@@ -146,15 +158,19 @@ wgrad_tile_kernel(const WgK ga) {
     constexpr int BATCH = PIPE ? N_IT : 8;
     constexpr int NBATCH = (N_IT + BATCH - 1) / BATCH;
     f32x4 rr[BATCH];
-    auto load_batch = [&](int tile, int batch) {
+    // staging item k (a compile-time index at every call site) of batch `batch` of the pixel tile at (n, ty0, tx0) -> rr[k]
+    struct TileAt { int n, ty0, tx0; };
+    auto tile_at = [&](int tile) __attribute__((always_inline)) {
         int q = tile;
         const int tx = q % a.tiles_x;
         q /= a.tiles_x;
         const int ty = q % a.tiles_y;
-        const int n = q / a.tiles_y;
-        const int ty0 = ty * THG, tx0 = tx * TWG;
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
+        return TileAt{q / a.tiles_y, ty * THG, tx * TWG};
+    };
+    auto load_item = [&](const TileAt &ta, int batch, auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        const int n = ta.n, ty0 = ta.ty0, tx0 = ta.tx0;
+        {
             const int it = batch * BATCH + k;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (it < G_IT) {
@@ -192,7 +208,7 @@ wgrad_tile_kernel(const WgK ga) {
                     c = vb * 32 + (c4 & 7) * 4;
                     Y = ty0 + hr - 1;
                     X = tx0 + hc - 1;
-                    if (ga.reflect) {
+                    if (a.reflect) {
                         Y = Y < 0 ? -Y : (Y >= a.H ? 2 * a.H - 2 - Y : Y);
                         X = X < 0 ? -X : (X >= a.W ? 2 * a.W - 2 - X : X);
                     }
@@ -205,6 +221,26 @@ wgrad_tile_kernel(const WgK ga) {
             }
             rr[k] = v;
         }
+    };
+    auto load_batch = [&](int tile, int batch) __attribute__((always_inline)) {
+        const TileAt ta = tile_at(tile);
+        wg_static_for<0, BATCH>([&](auto kc) __attribute__((always_inline)) { load_item(ta, batch, kc); });
+    };
+    // PIPE: the loads of tile i+1 fly during the MFMA phase of tile i, issued as one burst in front of it.  Handing them out over
+    // the first MFMA groups instead (what pays in conv_body.h: -3 % per dense-block chain) was measured here and LOSES: grouped
+    // 32-cout jobs 104 -> 134 us, 192 -> 64: 491 -> 518 us, weight gradients 99 -> 116 ms per step (the staging index arithmetic
+    // moves into the k-loop; the 256-register classes spill).  Kept behind -DTNR_WG_SPREAD_ALL for the record.
+#if defined(TNR_WG_SPREAD_ALL) && !defined(TNR_NO_LOAD_SPREAD)
+    constexpr bool SPREAD = PIPE;
+#else
+    constexpr bool SPREAD = false;
+#endif
+    constexpr int SPREAD_N = 3, IPG = (BATCH + SPREAD_N - 1) / SPREAD_N;
+    auto load_group = [&](int tile, auto gc) __attribute__((always_inline)) {          // group g of SPREAD_N: items [g IPG, (g + 1) IPG) of batch 0
+        constexpr int g = decltype(gc)::value;
+        constexpr int k0 = g * IPG < BATCH ? g * IPG : BATCH, k1 = (g + 1) * IPG < BATCH ? (g + 1) * IPG : BATCH;
+        const TileAt ta = tile_at(tile);
+        wg_static_for<k0, k1>([&](auto kc) __attribute__((always_inline)) { load_item(ta, 0, kc); });
     };
     auto store_batch = [&](int batch) {
 #pragma unroll
@@ -226,7 +262,7 @@ wgrad_tile_kernel(const WgK ga) {
             __syncthreads();  // previous tile's fragments are consumed
             store_batch(0);
             __syncthreads();
-            if (tile + 1 < t_end) load_batch(tile + 1, 0);  // in flight during the MFMA phase below
+            if (!SPREAD && tile + 1 < t_end) load_batch(tile + 1, 0);  // in flight during the MFMA phase below
         } else {
             load_batch(tile, 0);
             __syncthreads();
@@ -277,6 +313,17 @@ wgrad_tile_kernel(const WgK ga) {
 #pragma unroll
                     for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
                     if (r + 1 < ROWS) read_row();
+                    if constexpr (SPREAD) {
+                        if (tile + 1 < t_end) {
+                            if constexpr (ROWS >= SPREAD_N) {
+                                if (r == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
+                                if (r == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
+                                if (r == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
+                            } else if (r == 0) {
+                                load_batch(tile + 1, 0);
+                            }
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca, cb[j], acc[j], 0, 0, 0);
@@ -299,6 +346,13 @@ wgrad_tile_kernel(const WgK ga) {
                     fa[nxt] = smem[go + goff];
 #pragma unroll
                     for (int j = 0; j < J; ++j) fb[nxt][j] = smem[xo[j] + xoff];
+                    if constexpr (SPREAD) {
+                        if (r == 0 && tile + 1 < t_end) {
+                            if (k == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
+                            if (k == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
+                            if (k == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     bsum += fa[cur];
 #pragma unroll
