@@ -432,7 +432,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
         for (int s_ = 0; s_ < NSTEP; ++s_) {
             if (s_ + 1 < NSTEP) fetch(s_ + 1, (s_ + 1) & 1);
-#if !defined(TNR_NO_LOAD_SPREAD) && !defined(TNR_ABL_NOLOAD)
+#if !defined(TNR_NO_LOAD_SPREAD) && !defined(TNR_ABL_NOLOAD) && !defined(TNR_LOAD_INTERLEAVE)
             {
 #ifdef TNR_LOAD_SPREAD_IPS
                 constexpr int IPS = TNR_LOAD_SPREAD_IPS;
@@ -446,9 +446,33 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 }
             }
 #endif
+#ifdef TNR_LOAD_INTERLEAVE      /* (experiment) one staging load in the shadow of every other MFMA of the step instead of in front of them */
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                constexpr int SP = NSTEP < 3 ? NSTEP : 3, IP = (N_ITEMS + SP - 1) / SP;
+                int m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) {
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s_ & 1][mi][j], fb[s_ & 1][nn][j], acc[mi][nn], 0, 0, 0);
+                            const int k = s_ * IP + (m >> 1);
+                            if (have_next && (m & 1) == 0 && (m >> 1) < IP && k < N_ITEMS) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                load_item(chunk + 1, k);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            ++m;
+                        }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
             __builtin_amdgcn_sched_barrier(0);
             mma(s_ & 1);
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         }
 #ifdef TNR_TIMELINE
@@ -693,6 +717,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             }
             if (!(ok[set] && co_ok[nn])) continue;
             const int co = co_n[nn];
+#ifdef TNR_ABL_NOEPISTORE      /* (ablation build: keeps the value alive without the store traffic; results invalid) */
+            if (v[0] == 1.2345e30f) a.y[0] = v[1] + v[2] + v[3];
+            continue;
+#endif
             if (COH) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tnr_u32x4, v), y_rs,
                                                        (int)((unsigned)(pixi[set] * a.y_ct + a.y_co + co) * 4u), 0, TNR_COH_STORE_AUX);

@@ -59,7 +59,11 @@ struct ChainWait {
             publish();
         }
         const int t = threadIdx.x;
+#ifdef TNR_ABL_NOWAIT          /* (ablation build: no neighbour polling; results invalid) */
+        if (t < 0) {
+#else
         if (t < 9 && t != 4) {
+#endif
             const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
             if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) {
                 const unsigned *p = progress + ((size_t)n * tiles_y + yy) * tiles_x + xx;
