@@ -35,8 +35,6 @@ class DPGroup:
         self._pending = []
         self._abi = None                         # (lib, communicator handle) when TNR_DP_BACKEND=abi
         if self.active:
-            from . import ops
-            ops.COLLECTIVES_IN_FLIGHT = True     # see ops.conv_chain
             if os.environ.get("TNR_DP_BACKEND", "torch") == "abi" and torch.cuda.is_available():
                 self._init_abi()
 
@@ -118,7 +116,9 @@ class DPGroup:
             dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group)
             seg.mul_(1.0 / self.world_size)
             return
-        ev = torch.cuda.Event()
+        from . import ops
+        ops.COLLECTIVES_IN_FLIGHT = True       # until wait(): RCCL kernels may share the CUs with whatever is launched meanwhile
+        ev = torch.cuda.Event()                # (ops.conv_chain then falls back to one launch per layer: it needs its whole grid co-resident)
         ev.record(torch.cuda.current_stream(flat_grad.device))
         with torch.cuda.stream(side):
             side.wait_event(ev)
@@ -150,6 +150,8 @@ class DPGroup:
         for ev in self._pending:
             cur.wait_event(ev)
         self._pending = []
+        from . import ops
+        ops.COLLECTIVES_IN_FLIGHT = False      # everything launched from here on starts after the collectives finished
 
 
 class BucketSchedule:

@@ -83,7 +83,10 @@ class SRModel(BaseModel):
             l_g_gan = self.adversarial(self.fake_H, self.var_ref, netD=self.netD, stage="generator", fsfilter=self.f_high)
             self.log_dict["l_g_gan"] = l_g_gan.detach()
             l_g_total = l_g_total + (l_g_gan if self.accumulations == 1 else l_g_gan / self.accumulations)
-        self._arm_bucket_schedule([self.netG])     # G's gradient buckets all-reduce while backward runs
+        # G's gradients (67 MB: ~1 ms of xGMI time) are NOT all-reduced while its backward runs: with RCCL kernels on the CUs the
+        # dense-block chain kernel has to fall back to one launch per layer (it needs its whole grid co-resident), which costs the
+        # trunk's backward more (~8 ms) than the overlap could hide.  They go out in one sweep at the optimizer step (_sync_gradients);
+        # D, which has no chain launches and the larger buffer (110 MB), keeps the overlapped schedule (backward_D).
         self.calc_gradients(l_g_total)
 
     def backward_D(self):

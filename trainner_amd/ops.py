@@ -284,9 +284,9 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
 
 CHAIN_MAX = 6
 CONV_CHAIN = os.environ.get("TNR_CONV_CHAIN", "1") != "0"     # 0: one launch per layer (A/B switch)
-COLLECTIVES_IN_FLIGHT = False   # set by dp.py when gradient buckets are all-reduced on a side stream during backward:
-                                # a chain launch needs every workgroup of its grid co-resident, which RCCL kernels
-                                # sharing the CUs could delay -> multi-GPU runs keep one launch per layer
+COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket handed to RCCL on the side stream until the compute
+                                # stream has waited for all of them: a chain launch needs every workgroup of its grid
+                                # co-resident, which RCCL kernels sharing the CUs could delay -> one launch per layer meanwhile
 _chain_epoch = {}
 
 
