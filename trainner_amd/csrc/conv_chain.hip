@@ -17,6 +17,10 @@
 // stage-major, so a waited-for tile always belongs to a running workgroup at an earlier program point.
 #include <stddef.h>
 #include "conv_body.h"
+#ifdef TNR_CONV_DL_EXPERIMENT     /* tools/build_variant.py dl -DTNR_CONV_DL_EXPERIMENT: LDS-DMA staging experiment, conv_body_dl.h */
+#include "conv_body_dl.h"
+#include <cstdlib>
+#endif
 
 namespace {
 
@@ -96,7 +100,7 @@ __device__ __forceinline__ ConvK chain_stage(int s, int *wait_chunk) {
 #endif
 }
 
-template <bool BF>
+template <bool BF, int DL = 0>
 __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int pend_tile = -1;          // wave-uniform
@@ -159,7 +163,12 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
                 int txo = tx, tyo = ty, no = n;
                 asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(no));
                 TNR_STAMP_CALL(calls++);
-                conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true, BF>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
+#ifdef TNR_CONV_DL_EXPERIMENT
+                if constexpr (DL != 0)      // (TNR_CONV_DL=2) LDS-DMA staging, conv_body_dl.h
+                    conv_tile_body_dk8<1, 4, true>(st, cb, txo, tyo, no, smem, (tnr_lds_float *)smem, cb == 0 ? wait_chunk : -1, w);
+                else
+#endif
+                    conv_tile_body<TNR_CONV_3x3, 32, 1, 4, true, BF>(st, cb, txo, tyo, no, 0, smem, cb == 0 ? wait_chunk : -1, w);
             }
             // this tile's stage-s output is on its way to memory: published from inside the next tile body
             // (every stage has >= 2 input chunks, so the previous pending tile has been published by now)
@@ -194,6 +203,10 @@ int chain_capacity(int *out) {
                                 (int)chain_lds()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)chain_lds()) != hipSuccess ||
+#ifdef TNR_CONV_DL_EXPERIMENT
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds()) != hipSuccess ||
+#endif
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel<false>, 256, chain_lds()) != hipSuccess) {
             tnr_set_error("conv_chain: cannot size the grid");
             return TNR_ELAUNCH;
@@ -276,6 +289,16 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     if (rc != TNR_OK) return rc;
     const int grid = c.tiles < cap ? c.tiles : cap;
     c.dyn = (c.tiles == cap && (c.tiles & 1) == 0 && d0.N >= 2 && (d0.N & 1) == 0) ? 1 : 0;   // whole images per population
+#ifdef TNR_CONV_DL_EXPERIMENT
+    const char *dl_env = std::getenv("TNR_CONV_DL");
+    int dl = (dl_env != nullptr && d0.mma != TNR_MMA_BF16) ? dl_env[0] - '0' : 0;
+    for (int i = 0; i < n; ++i)
+        if (c.st[i].Cin != c.st[i].KinP || c.st[i].reflect) dl = 0;
+    static_assert(Dk8Geom<1, 4>::LDS_BYTES <= chain_lds(), "the LDS-DMA form fits the chain's LDS allocation");
+    if (dl == 2)
+        hipLaunchKernelGGL((conv_chain_kernel<false, 2>), dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    else
+#endif
     if (d0.mma == TNR_MMA_BF16)
         hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else

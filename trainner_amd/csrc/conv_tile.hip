@@ -19,6 +19,10 @@
 // This file: the one-launch-per-layer kernel (optionally split along K, with a reduce launch) and the host
 // side of tnr_conv_forward.  The device body is conv_body.h; conv_chain.hip runs it for several layers per launch.
 #include "conv_body.h"
+#ifdef TNR_CONV_DL_EXPERIMENT     /* tools/build_variant.py dl -DTNR_CONV_DL_EXPERIMENT: the LDS-DMA staging experiments, conv_body_dl.h */
+#include "conv_body_dl.h"
+#include <cstdlib>
+#endif
 
 namespace {
 
@@ -227,6 +231,17 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
         tiles *= ksplit;
     }
     int rc;
+#ifdef TNR_CONV_DL_EXPERIMENT
+    const char *dl_env = std::getenv("TNR_CONV_DL");     // (experiment switch, read per call so that one process can compare both paths)
+    const int dl = dl_env != nullptr ? dl_env[0] - '0' : 0;      // 1: 8-wave / 16-channel form, 2: 4-wave / 8-channel form
+    if (dl == 1 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_dl_ok(k)) return launch_conv3x3_dl<0>(k, s);
+    if (dl == 4 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_dl_ok(k)) return launch_conv3x3_dl<2>(k, s);     // 4: form 1 with two loader waves
+    if (dl == 5 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_dl_ok(k)) return launch_conv3x3_dl<4>(k, s);     // 5: four loader waves
+    if (dl == 2 && d->mode == TNR_CONV_3x3 && tw == 32 && conv3x3_dl_ok(k)) {
+        if (big_m) return launch_conv3x3_dk8<1, 4>(k, tiles, s);
+        if (nt == 2) return launch_conv3x3_dk8<2, 2>(k, tiles, s);
+    }
+#endif
     if (big_m) {
         rc = launch_conv<TNR_CONV_3x3, 32, 1, 4>(k, (int)tiles, s);
     } else {
