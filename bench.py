@@ -239,6 +239,9 @@ def main():
     ap.add_argument("--amp", action="store_true",
                     help="variant: `use_amp: true` = bf16 matrix-core operands, fp32 accumulate (reported as dtype bf16 with its own "
                          "roofline; the headline run is fp32)")
+    ap.add_argument("--mma", choices=["f32", "bf16x3"], default=os.environ.get("TNR_MMA", "f32"),
+                    help="fp32 arithmetic of the per-layer convolution kernels: f32 = v_mfma_f32_32x32x2_f32 (headline); bf16x3 = operands "
+                         "split exactly into three bf16 values, six partial products on the bf16 matrix core, fp32 accumulate (variant)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
@@ -250,6 +253,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ["TNR_MMA"] = args.mma          # read by trainner_amd.ops at import
     from trainner_amd import hip, ops
     dry = args.dry_run_cpu
     if dry:
@@ -371,6 +375,11 @@ def main():
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "world_size_observed": model.dp.world_size,
+                       "mma": ("bf16 operands (use_amp)" if args.amp else
+                               "fp32 matrix core (v_mfma_f32_32x32x2_f32)" if args.mma == "f32" else
+                               "VARIANT bf16x3: per-layer convolutions split fp32 operands exactly into 3 bf16 values, 6 of 9 partial "
+                               "products, fp32 accumulate (error vs fp64 <= the fp32 matrix-core path's); chain and weight-gradient "
+                               "kernels on the fp32 matrix core"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of

@@ -62,6 +62,7 @@ enum {
 
 #define TNR_MMA_F32 0
 #define TNR_MMA_BF16 1
+#define TNR_MMA_BF16X3 2
 
 typedef struct tnr_view {
     float *ptr;
@@ -100,7 +101,10 @@ typedef struct tnr_conv_desc {
     /* matrix-core operand precision: TNR_MMA_F32 = v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: the default, bit
      * parity class of the CPU reference); TNR_MMA_BF16 = activations and weights rounded to bf16 (round-to-nearest-even) as
      * they enter the matrix core, v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 epilogue and storage -- the engine's
-     * `use_amp: true` policy (base_model.py:736-744 autocasts the convolutions to half precision).               */
+     * `use_amp: true` policy (base_model.py:736-744 autocasts the convolutions to half precision);
+     * TNR_MMA_BF16X3 = fp32 arithmetic on the bf16 matrix core: every operand is split EXACTLY into three bf16 values
+     * (hi + mid + lo = x), the six largest of the nine partial products (each exact) are accumulated in fp32 -- the dropped
+     * ones are below 2^-24 of the product, i.e. below fp32 rounding -- at 6/16 of the fp32 matrix-core cycles.      */
     int32_t mma;
     /* border handling of the TNR_CONV_3x3 mode: 0 = zero padding (nn.Conv2d padding 1), 1 = nn.ReflectionPad2d(1) in front of
      * an unpadded convolution (the ResnetGenerator's residual blocks, ResNet_arch.py:118-146): the stager reads row -1 as row 1

@@ -753,6 +753,117 @@ def test_bf16_operand_mode(monkeypatch):
     close(rb_[..., nf:nf + gc].permute(0, 3, 1, 2), x1, what="bf16 chain stage 0")
 
 
+def test_bf16x3_split_operand_mode(monkeypatch):
+    """TNR_MMA_BF16X3: fp32 arithmetic on the bf16 matrix core -- every operand split EXACTLY into hi + mid + lo (three bf16
+    values), the six largest of the nine exact partial products accumulated in fp32.  Not a reduced-precision mode: on every
+    geometry (3x3 forward with fused epilogue in a channel window, 64-cout and 32-cout tile classes, nearest-x2 stager, 4x4 s2
+    forward, both data-gradients, the taps-in-K image kernel, reflection borders, the im2col / split-K route, the dense-block
+    chain instantiation) the result must pass the fp32 kernels' own tolerance AND its error against an fp64 reference must not
+    exceed 1.5 x the fp32 matrix-core path's error on the same inputs (+ 2e-7 of the output scale)."""
+    from trainner_amd import hip
+    ops = _ops()
+    worst = []
+
+    def both(name, launch, ref64):
+        err = {}
+        for mma in (hip.MMA_F32, hip.MMA_BF16X3):
+            monkeypatch.setattr(ops, "MMA", mma)
+            got = launch().double()
+            err[mma] = (got - ref64).abs().max().item()
+        scale = ref64.abs().max().item()
+        worst.append((name, err[hip.MMA_F32] / scale, err[hip.MMA_BF16X3] / scale))
+        assert err[hip.MMA_BF16X3] <= 2e-5 * (scale + 1.0), (name, err)
+        assert err[hip.MMA_BF16X3] <= 1.5 * err[hip.MMA_F32] + 2e-7 * scale, (name, err)
+
+    d = torch.double
+    # 3x3 forward, window of a wider buffer, bias + LeakyReLU + residual; 32-cout and 64-cout tile classes, large K
+    for (N, H, W, Cin, Cout, seed) in ((2, 20, 37, 96, 32, 1), (1, 24, 40, 192, 64, 2), (1, 16, 32, 512, 128, 3)):
+        x, w = rnd(N, Cin, H, W, seed=seed), rnd(Cout, Cin, 3, 3, seed=seed + 10, lo=-0.2, hi=0.2)
+        b, r = rnd(Cout, seed=seed + 20), rnd(N, Cout, H, W, seed=seed + 30)
+        ref = F.leaky_relu(F.conv2d(x.to(d), w.to(d), b.to(d), padding=1), 0.2) * 0.5 + r.to(d)
+        xb, rb = nhwc_buf(x, 512, 0), nhwc_buf(r)
+        wp, _k = pack(ops, w.to(DEV), ops.PACK_FWD)
+
+        def launch():
+            yb = torch.full((N, H, W, 192), -3.0, device=DEV)
+            ops.conv(ops.View(xb, 0, Cin), wp, ops.View(yb, 32, Cout), bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.5, r1=ops.View(rb))
+            return to_nchw(yb, 32, Cout)
+        both("conv3x3 %d->%d" % (Cin, Cout), launch, ref)
+    # nearest-x2 stager
+    w2, x2 = rnd(64, 64, 3, 3, seed=5, lo=-0.2, hi=0.2), rnd(1, 64, 12, 20, seed=6)
+    wp2, _k2 = pack(ops, w2.to(DEV), ops.PACK_FWD)
+
+    def up2():
+        y2 = torch.zeros(1, 24, 40, 64, device=DEV)
+        ops.conv(ops.View(nhwc_buf(x2)), wp2, ops.View(y2), mode=ops.CONV_3x3_UP2)
+        return to_nchw(y2, 0, 64)
+    both("up2", up2, F.conv2d(F.interpolate(x2.to(d), scale_factor=2.0, mode="nearest"), w2.to(d), None, padding=1))
+    # 4x4 s2 forward and its data-gradient, 3x3 data-gradient
+    w4, x4, g4 = rnd(64, 32, 4, 4, seed=7, lo=-0.2, hi=0.2), rnd(2, 32, 16, 24, seed=8), rnd(2, 64, 8, 12, seed=9)
+    wp4, _k4 = pack(ops, w4.to(DEV), ops.PACK_FWD_S2D)
+    wd4, _k5 = pack(ops, w4.to(DEV), ops.PACK_DGRAD_S2)
+
+    def s2():
+        y4 = torch.zeros(2, 8, 12, 64, device=DEV)
+        ops.conv(ops.View(nhwc_buf(x4)), wp4, ops.View(y4), mode=ops.CONV_4x4_S2)
+        return to_nchw(y4, 0, 64)
+
+    def ds2():
+        gx4 = torch.zeros(2, 16, 24, 32, device=DEV)
+        ops.conv(ops.View(nhwc_buf(g4)), wd4, ops.View(gx4), mode=ops.DGRAD_4x4_S2)
+        return to_nchw(gx4, 0, 32)
+    both("4x4s2", s2, F.conv2d(x4.to(d), w4.to(d), None, stride=2, padding=1))
+    both("dgrad4x4s2", ds2, F.conv_transpose2d(g4.to(d), w4.to(d), None, stride=2, padding=1))
+    w3, g3 = rnd(32, 96, 3, 3, seed=12, lo=-0.2, hi=0.2), rnd(2, 32, 20, 37, seed=10)
+    wd3, _k6 = pack(ops, w3.to(DEV), ops.PACK_DGRAD_3x3)
+
+    def d3():
+        gx3 = torch.zeros(2, 20, 37, 96, device=DEV)
+        ops.conv(ops.View(nhwc_buf(g3)), wd3, ops.View(gx3))
+        return to_nchw(gx3, 0, 96)
+    both("dgrad3x3", d3, F.conv_transpose2d(g3.to(d), w3.to(d), None, padding=1))
+    # reflection borders
+    wr, xr = rnd(64, 64, 3, 3, seed=14, lo=-0.2, hi=0.2), rnd(2, 64, 20, 37, seed=15)
+    wpr, _k7 = pack(ops, wr.to(DEV), ops.PACK_FWD)
+
+    def refl():
+        yr = torch.zeros(2, 20, 37, 64, device=DEV)
+        ops.conv(ops.View(nhwc_buf(xr)), wpr, ops.View(yr), reflect=True)
+        return to_nchw(yr, 0, 64)
+    both("reflect", refl, F.conv2d(F.pad(xr.to(d), (1, 1, 1, 1), mode="reflect"), wr.to(d), None))
+    # small-spatial route: im2col + 1x1 GEMM with split-K
+    ws_, xs = rnd(96, 256, 3, 3, seed=16, lo=-0.05, hi=0.05), rnd(2, 256, 8, 8, seed=17)
+    wps, _k8 = pack(ops, ws_.to(DEV), ops.PACK_COL_FWD)
+
+    def small():
+        ys = torch.zeros(2, 8, 8, 96, device=DEV)
+        ops.conv_small(ops.View(nhwc_buf(xs)), wps, ops.View(ys), 3, 1)
+        return to_nchw(ys, 0, 96)
+    both("im2col splitk", small, F.conv2d(xs.to(d), ws_.to(d), None, padding=1))
+    # the chain kernel's split-operand instantiation (ops.conv_chain keeps the chain on the fp32 matrix core unless CHAIN_X3)
+    monkeypatch.setattr(ops, "CHAIN_X3", True)
+    nf, gc = 64, 32
+    cw = [rnd(gc, nf + k * gc, 3, 3, seed=70 + k, lo=-0.05, hi=0.05) for k in range(2)]
+    p = ops.WeightPacker(DEV)
+    idx = [p.add(wk.to(DEV), ops.PACK_FWD) for wk in cw]
+    p.run()
+    x0 = rnd(2, nf, 40, 72, seed=90)
+    x1 = F.leaky_relu(F.conv2d(x0.to(d), cw[0].to(d), None, padding=1), 0.2)
+    x2_ = F.leaky_relu(F.conv2d(torch.cat([x0.to(d), x1], 1), cw[1].to(d), None, padding=1), 0.2)
+
+    def chain():
+        buf = torch.zeros((2, 40, 72, nf + 2 * gc), device=DEV)
+        buf[..., :nf] = x0.permute(0, 2, 3, 1).to(DEV)
+        st = [dict(x=ops.View(buf, 0, nf + gc * k), wp=p.get(idx[k]), y=ops.View(buf, nf + gc * k, gc), act=ops.ACT_LRELU, slope=0.2,
+                   fresh_from=(nf + gc * (k - 1) if k else None)) for k in range(2)]
+        ops.conv_chain(st)
+        torch.cuda.synchronize()
+        return to_nchw(buf, nf, 2 * gc)
+    both("chain", chain, torch.cat([x1, x2_], 1))
+    assert ops.chain_error_flag() == 0
+    print("\nbf16x3 vs fp32 matrix core, max error / scale against fp64:", ["%s %.1e %.1e" % w_ for w_ in worst])
+
+
 @pytest.mark.parametrize("case", [(7, 1, 3, True, 3, 64, 2, 20, 28), (7, 1, 3, True, 64, 3, 1, 16, 24), (4, 1, 1, False, 32, 48, 2, 9, 13),
                                   (4, 1, 1, False, 64, 1, 1, 12, 12), (3, 2, 1, False, 8, 12, 2, 10, 14), (3, 1, 1, True, 16, 8, 1, 7, 9)])
 def test_generic_conv_family(case):

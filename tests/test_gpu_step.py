@@ -100,6 +100,17 @@ def test_step_matches_reference_golden(case, tmp_path):
         assert e < T["bn"], ("D running stats", k, e)
 
 
+@pytest.mark.parametrize("case", ["esrgan_nb1_crop64", "esrgan_nb23_crop128", "esrgan_nb23_crop512_b2"])
+def test_step_matches_reference_golden_bf16x3(case, tmp_path, monkeypatch):
+    """TNR_MMA=bf16x3 (per-layer convolutions on the bf16 matrix core with exactly split fp32 operands, include/trainner_hip.h
+    TNR_MMA_BF16X3) is an fp32 mode: the reference goldens must be met with the SAME bounds as on the fp32 matrix core."""
+    from trainner_amd import hip, ops
+    monkeypatch.setattr(ops, "FP32_MMA", hip.MMA_BF16X3)
+    monkeypatch.setattr(ops, "MMA", hip.MMA_BF16X3)
+    test_step_matches_reference_golden(case, tmp_path)
+    assert ops.MMA == hip.MMA_BF16X3
+
+
 @pytest.mark.timeout(420)
 def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
     """ESRGAN RRDBNet-23 + Discriminator_VGG(512) + VGG19, 128 -> 512, batch 1: two live steps."""

@@ -18,6 +18,24 @@ __device__ __forceinline__ tnr_bf16x8 tnr_pack_bf16(const f32x4 lo, const f32x4 
     }
     return r;
 }
+// fp32 on the bf16 matrix core, exactly split: x = hi + mid + lo with three bf16 values (8 + 8 + 8 significand bits; every
+// residual is computed exactly in fp32).  A product a b = sum of 9 partial products a_i b_j, each EXACT in the fp32 accumulator's
+// input; the three smallest (mid lo, lo mid, lo lo: <= 2^-24 |a b| together) are dropped -- below the rounding error of one fp32
+// multiply-add.  Six v_mfma_f32_32x32x16_bf16 (k = 16) replace sixteen v_mfma_f32_32x32x2_f32: 192 instead of 1024 matrix-core
+// cycles per 32 x 32 x 16 block.  (tnr_conv_desc.mma = TNR_MMA_BF16X3.)
+__device__ __forceinline__ void tnr_split_bf16x3(const f32x4 q0, const f32x4 q1, tnr_bf16x8 (&out)[3]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? q0[i] : q1[i - 4];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        out[0][i] = h;
+        out[1][i] = m;
+        out[2][i] = (__bf16)r2;
+    }
+}
 constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | sc1 (bit 4) = system-coherent
 #ifndef TNR_COH_LOAD_AUX
 #define TNR_COH_LOAD_AUX TNR_AUX_SC0_SC1
@@ -96,7 +114,7 @@ __device__ unsigned long long tnr_phase[8192 * 8 * 8];
 //            and HBM keep fp32, so staging, layouts and the epilogue are unchanged; per tap ONE v_mfma_f32_32x32x16_bf16
 //            per 32x32 tile replaces EIGHT v_mfma_f32_32x32x2_f32 (lane-half h supplies channels 4h..4h+3 of both
 //            8-channel groups = 8 of the 16 k-values; the k-order inside an MFMA is free as long as A and B agree).
-template <int MODE, int TW, int NT, int MT, bool COH, bool BF, class WaitFn>
+template <int MODE, int TW, int NT, int MT, bool COH, int BF, class WaitFn>
 __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, const int tx, const int ty, const int n,
                                                const int par, float *smem, const int wait_chunk, WaitFn &&wait,
                                                const int ksplit = 1, const int split = 0) {
@@ -334,8 +352,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         if constexpr (BF) {
             // a step = one tap: 2 (MT + NT) ds_read_b128 into the raw set, converted to bf16x8 AFTER the MFMAs of the
             // previous tap were issued (the reads had a whole MFMA group to land), MT*NT MFMAs of k = 16
+            constexpr int NS = BF == 2 ? 3 : 1;      // operand splits (TNR_MMA_BF16X3: hi, mid, lo)
             f32x4 ra[MT][2], rb[NT][2];
-            tnr_bf16x8 ca[MT], cb_[NT];
+            tnr_bf16x8 ca[MT][NS], cb_[NT][NS];
             auto tap_off = [&](int t, int &tapoff, int &woff) {
                 int pos_y, pos_x;
                 if (DG2) {
@@ -370,9 +389,15 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             };
             auto convert = [&]() {
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) ca[mi] = tnr_pack_bf16(ra[mi][0], ra[mi][1]);
+                for (int mi = 0; mi < MT; ++mi) {
+                    if constexpr (BF == 2) tnr_split_bf16x3(ra[mi][0], ra[mi][1], ca[mi]);
+                    else ca[mi][0] = tnr_pack_bf16(ra[mi][0], ra[mi][1]);
+                }
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) cb_[nn] = tnr_pack_bf16(rb[nn][0], rb[nn][1]);
+                for (int nn = 0; nn < NT; ++nn) {
+                    if constexpr (BF == 2) tnr_split_bf16x3(rb[nn][0], rb[nn][1], cb_[nn]);
+                    else cb_[nn][0] = tnr_pack_bf16(rb[nn][0], rb[nn][1]);
+                }
             };
             fetch_raw(0);
             convert();
@@ -380,11 +405,23 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             for (int t = 0; t < NTAPS; ++t) {
                 if (t + 1 < NTAPS) fetch_raw(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BF == 2) {
+                    // the six kept partial products, smallest first; the MT * NT accumulators in between keep dependent MFMAs apart
+                    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
+                    for (int p = 0; p < 6; ++p)
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn)
-                        acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi], cb_[nn], acc[mi][nn], 0, 0, 0);
+                        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                            for (int nn = 0; nn < NT; ++nn)
+                                acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][TA[p]], cb_[nn][TB[p]], acc[mi][nn], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn)
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][0], cb_[nn][0], acc[mi][nn], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < NTAPS) convert();
             }

@@ -100,7 +100,7 @@ __device__ __forceinline__ ConvK chain_stage(int s, int *wait_chunk) {
 #endif
 }
 
-template <bool BF, int DL = 0>
+template <int BF, int DL = 0>
 __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int pend_tile = -1;          // wave-uniform
@@ -199,15 +199,17 @@ int chain_capacity(int *out) {
             tnr_set_error("conv_chain: cannot query the device");
             return TNR_ELAUNCH;
         }
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)chain_lds()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)chain_lds()) != hipSuccess ||
 #ifdef TNR_CONV_DL_EXPERIMENT
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)chain_lds()) != hipSuccess ||
 #endif
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel<false>, 256, chain_lds()) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)chain_lds()) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel<0>, 256, chain_lds()) != hipSuccess) {
             tnr_set_error("conv_chain: cannot size the grid");
             return TNR_ELAUNCH;
         }
@@ -279,7 +281,7 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
         k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
         k.th_space = d->Ho; k.tw_space = d->Wo;
-        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma == TNR_MMA_BF16; k.reflect = d->pad_mode == 1;
+        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = d->pad_mode == 1;
         TNR_REQUIRE(d->mma == d0.mma, "conv_chain: stage %d: all stages share one matrix-core precision", i);
         c.wait_chunk[i] = fresh_from[i] < 0 ? -1 : fresh_from[i] / TNR_CK;
     }
@@ -291,17 +293,19 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     c.dyn = (c.tiles == cap && (c.tiles & 1) == 0 && d0.N >= 2 && (d0.N & 1) == 0) ? 1 : 0;   // whole images per population
 #ifdef TNR_CONV_DL_EXPERIMENT
     const char *dl_env = std::getenv("TNR_CONV_DL");
-    int dl = (dl_env != nullptr && d0.mma != TNR_MMA_BF16) ? dl_env[0] - '0' : 0;
+    int dl = (dl_env != nullptr && d0.mma == TNR_MMA_F32) ? dl_env[0] - '0' : 0;
     for (int i = 0; i < n; ++i)
         if (c.st[i].Cin != c.st[i].KinP || c.st[i].reflect) dl = 0;
     static_assert(Dk8Geom<1, 4>::LDS_BYTES <= chain_lds(), "the LDS-DMA form fits the chain's LDS allocation");
     if (dl == 2)
-        hipLaunchKernelGGL((conv_chain_kernel<false, 2>), dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+        hipLaunchKernelGGL((conv_chain_kernel<0, 2>), dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else
 #endif
-    if (d0.mma == TNR_MMA_BF16)
-        hipLaunchKernelGGL(conv_chain_kernel<true>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    if (d0.mma == TNR_MMA_BF16X3)
+        hipLaunchKernelGGL(conv_chain_kernel<2>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+    else if (d0.mma == TNR_MMA_BF16)
+        hipLaunchKernelGGL(conv_chain_kernel<1>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else
-        hipLaunchKernelGGL(conv_chain_kernel<false>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+        hipLaunchKernelGGL(conv_chain_kernel<0>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     return tnr_check_launch("conv_chain");
 }

@@ -26,7 +26,7 @@
 
 namespace {
 
-template <int MODE, int TW, int NT, int MT, bool BF>
+template <int MODE, int TW, int NT, int MT, int BF>
 __global__ void __launch_bounds__(256, 2) conv_tile_kernel(const ConvK a) {
     TNR_STAMP_CALL(0);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const SplitRedK
     }
 }
 
-template <int MODE, int TW, int NT, int MT, bool BF>
+template <int MODE, int TW, int NT, int MT, int BF>
 int launch_conv_t(const ConvK &k, int tiles, hipStream_t s) {
     constexpr int TH = 128 * MT / TW;
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
@@ -106,7 +106,8 @@ int launch_conv_t(const ConvK &k, int tiles, hipStream_t s) {
 
 template <int MODE, int TW, int NT, int MT = 2>
 int launch_conv(const ConvK &k, int tiles, hipStream_t s) {
-    return k.bf ? launch_conv_t<MODE, TW, NT, MT, true>(k, tiles, s) : launch_conv_t<MODE, TW, NT, MT, false>(k, tiles, s);
+    if (k.bf == 2) return launch_conv_t<MODE, TW, NT, MT, 2>(k, tiles, s);
+    return k.bf ? launch_conv_t<MODE, TW, NT, MT, 1>(k, tiles, s) : launch_conv_t<MODE, TW, NT, MT, 0>(k, tiles, s);
 }
 
 template <int MODE>
@@ -212,7 +213,8 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     // split-K for launches that cannot fill the chip (see tnr_conv_workspace_bytes)
     const int ksplit = conv_ksplit(d, tiles);
-    k.bf = d->mma == TNR_MMA_BF16;
+    TNR_REQUIRE(d->mma >= TNR_MMA_F32 && d->mma <= TNR_MMA_BF16X3, "conv: bad mma %d", d->mma);
+    k.bf = d->mma;
     k.reflect = d->pad_mode == 1;
     TNR_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->mode == TNR_CONV_3x3 && d->H >= 2 && d->W >= 2), "conv: pad_mode 1 (reflection) is for TNR_CONV_3x3");
     k.ksplit = 1;

@@ -17,7 +17,7 @@ c_l = C.c_int64
 c_p = C.c_void_p
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
-MMA_F32, MMA_BF16 = 0, 1
+MMA_F32, MMA_BF16, MMA_BF16X3 = 0, 1, 2
 CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2, CONV_1x1, CONV_3x3_C4 = 0, 1, 2, 3, 4, 5
 PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2, PACK_COL_FWD, PACK_COL_DGRAD3 = 0, 1, 2, 3, 4, 5
 PACK_C4_FWD, PACK_C4_DGRAD3 = 6, 7

@@ -304,7 +304,7 @@ class BaseModel:
         self.amp = bool(self.opt.get("use_amp"))
         self.cast = nullcontext
         self.amp_scaler = None
-        ops.MMA = hip.MMA_BF16 if self.amp else hip.MMA_F32
+        ops.MMA = hip.MMA_BF16 if self.amp else ops.FP32_MMA
         if self.amp:
             logger.info("AMP enabled: bf16 matrix-core operands, fp32 accumulation and master weights.")
 

@@ -232,7 +232,11 @@ class ConvProfile:
 
 
 PROFILE = None      # set to a ConvProfile() to time launches
-MMA = hip.MMA_F32   # matrix-core operand precision of every MFMA launch below: hip.MMA_F32 (default) | hip.MMA_BF16 (`use_amp: true`)
+# matrix-core arithmetic of every MFMA launch below.  hip.MMA_F32: v_mfma_f32_32x32x2_f32; hip.MMA_BF16X3: fp32 operands split
+# exactly into three bf16 values, six partial products on the bf16 matrix core, fp32 accumulate (fp32-level accuracy at 6/16 of the
+# matrix-core cycles; TNR_MMA=bf16x3); hip.MMA_BF16: operands ROUNDED to bf16 (`use_amp: true`, set by BaseModel.setup_amp)
+FP32_MMA = {"f32": hip.MMA_F32, "bf16x3": hip.MMA_BF16X3}[os.environ.get("TNR_MMA", "f32").lower()]
+MMA = FP32_MMA
 
 
 def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
@@ -283,6 +287,7 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
 
 
 CHAIN_MAX = 6
+CHAIN_X3 = os.environ.get("TNR_CHAIN_X3", "0") == "1"   # TNR_MMA=bf16x3 also inside tnr_conv_chain (measured slower there: DESIGN 9)
 CONV_CHAIN = os.environ.get("TNR_CONV_CHAIN", "1") != "0"     # 0: one launch per layer (A/B switch)
 COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket handed to RCCL on the side stream until the compute
                                 # stream has waited for all of them: a chain launch needs every workgroup of its grid
@@ -308,6 +313,8 @@ def conv_chain(stages):
     for i, st in enumerate(stages):
         kw = {k: v for k, v in st.items() if k != "fresh_from"}
         _conv_desc(descs[i], **kw)
+        if descs[i].mma == hip.MMA_BF16X3 and not CHAIN_X3:
+            descs[i].mma = hip.MMA_F32      # (the chain's 16 x 32 x 32-cout tile has 4 A fragments to split per B fragment: no gain yet)
         ff = st.get("fresh_from")
         fresh[i] = -1 if ff is None else ff
         flops += 2.0 * st["y"].pixels * 9 * min(st["x"].C, st["wp"].KinP) * st["y"].C
@@ -400,7 +407,7 @@ def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
     d.dw, d.cin_total, d.cin_begin = dw.data_ptr(), dw.shape[1], cin_begin
     d.db = hip.ptr(db)
     d.alpha, d.beta = alpha, beta
-    d.mma = MMA
+    d.mma = hip.MMA_F32 if MMA == hip.MMA_BF16X3 else MMA      # (the weight-gradient kernel has no split-operand form yet)
     d.pad_mode = 1 if reflect else 0
 
 
