@@ -377,9 +377,9 @@ def main():
                        "world_size_observed": model.dp.world_size,
                        "mma": ("bf16 operands (use_amp)" if args.amp else
                                "fp32 matrix core (v_mfma_f32_32x32x2_f32)" if args.mma == "f32" else
-                               "VARIANT bf16x3: per-layer convolutions split fp32 operands exactly into 3 bf16 values, 6 of 9 partial "
-                               "products, fp32 accumulate (error vs fp64 <= the fp32 matrix-core path's); chain and weight-gradient "
-                               "kernels on the fp32 matrix core"),
+                               "VARIANT bf16x3: convolutions (per-layer and chain, forward and data-gradient) split fp32 operands exactly "
+                               "into 3 bf16 values, 6 of 9 partial products, fp32 accumulate (error vs fp64 <= the fp32 matrix-core "
+                               "path's); weight-gradient kernels on the fp32 matrix core"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of

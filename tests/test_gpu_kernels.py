@@ -840,7 +840,7 @@ def test_bf16x3_split_operand_mode(monkeypatch):
         ops.conv_small(ops.View(nhwc_buf(xs)), wps, ops.View(ys), 3, 1)
         return to_nchw(ys, 0, 96)
     both("im2col splitk", small, F.conv2d(xs.to(d), ws_.to(d), None, padding=1))
-    # the chain kernel's split-operand instantiation (ops.conv_chain keeps the chain on the fp32 matrix core unless CHAIN_X3)
+    # the chain kernel's split-operand instantiation
     monkeypatch.setattr(ops, "CHAIN_X3", True)
     nf, gc = 64, 32
     cw = [rnd(gc, nf + k * gc, 3, 3, seed=70 + k, lo=-0.05, hi=0.05) for k in range(2)]

@@ -399,11 +399,42 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                     else cb_[nn][0] = tnr_pack_bf16(rb[nn][0], rb[nn][1]);
                 }
             };
-            fetch_raw(0);
-            convert();
+            // 16 x 32 tiles in the split-operand mode (MT = 4: 5 fragments = 40 raw + 60 split registers per tap beside 64
+            // accumulators and the staging registers): the raw fragments of tap t+1 are NOT kept across the MFMAs of tap t;
+            // they are read and split AFTER them, one fragment at a time with the next one's reads in flight (the LDS
+            // latency this exposes is covered by the co-resident workgroup; keeping them cost 76 spill slots in the chain).
+            constexpr bool JIT = (BF == 2) && (MT >= 4);
+            auto fetch_split = [&](int t) {
+                int tapoff, woff;
+                tap_off(t, tapoff, woff);
+                constexpr int NF = MT + NT;
+                f32x4 raw[2][2];
+                auto rd = [&](int i, int slot) {
+                    const float *src = i < NT ? s_w + woff + i * 32 * PST : s_in + aoff[i - NT] + tapoff;
+                    raw[slot][0] = *reinterpret_cast<const f32x4 *>(src);
+                    raw[slot][1] = *reinterpret_cast<const f32x4 *>(src + 8);
+                };
+                rd(0, 0);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    if (i + 1 < NF) rd(i + 1, (i + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (BF == 2) {
+                        if (i < NT) tnr_split_bf16x3(raw[i & 1][0], raw[i & 1][1], cb_[i]);
+                        else tnr_split_bf16x3(raw[i & 1][0], raw[i & 1][1], ca[i - NT]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (JIT) {
+                fetch_split(0);
+            } else {
+                fetch_raw(0);
+                convert();
+            }
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                if (t + 1 < NTAPS) fetch_raw(t + 1);
+                if (!JIT && t + 1 < NTAPS) fetch_raw(t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (BF == 2) {
                     // the six kept partial products, smallest first; the MT * NT accumulators in between keep dependent MFMAs apart
@@ -423,7 +454,10 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                             acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][0], cb_[nn][0], acc[mi][nn], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < NTAPS) convert();
+                if (t + 1 < NTAPS) {
+                    if constexpr (JIT) fetch_split(t + 1);
+                    else convert();
+                }
             }
         } else {
         f32x4 fa[2][MT], fb[2][NT];

@@ -287,7 +287,7 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
 
 
 CHAIN_MAX = 6
-CHAIN_X3 = os.environ.get("TNR_CHAIN_X3", "0") == "1"   # TNR_MMA=bf16x3 also inside tnr_conv_chain (measured slower there: DESIGN 9)
+CHAIN_X3 = os.environ.get("TNR_CHAIN_X3", "1") == "1"   # TNR_MMA=bf16x3 also inside tnr_conv_chain (A/B switch)
 CONV_CHAIN = os.environ.get("TNR_CONV_CHAIN", "1") != "0"     # 0: one launch per layer (A/B switch)
 COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket handed to RCCL on the side stream until the compute
                                 # stream has waited for all of them: a chain launch needs every workgroup of its grid
@@ -314,7 +314,7 @@ def conv_chain(stages):
         kw = {k: v for k, v in st.items() if k != "fresh_from"}
         _conv_desc(descs[i], **kw)
         if descs[i].mma == hip.MMA_BF16X3 and not CHAIN_X3:
-            descs[i].mma = hip.MMA_F32      # (the chain's 16 x 32 x 32-cout tile has 4 A fragments to split per B fragment: no gain yet)
+            descs[i].mma = hip.MMA_F32
         ff = st.get("fresh_from")
         fresh[i] = -1 if ff is None else ff
         flops += 2.0 * st["y"].pixels * 9 * min(st["x"].C, st["wp"].KinP) * st["y"].C
