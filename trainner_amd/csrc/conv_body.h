@@ -36,6 +36,28 @@ __device__ __forceinline__ void tnr_split_bf16x3(const f32x4 q0, const f32x4 q1,
         out[2][i] = (__bf16)r2;
     }
 }
+typedef float tnr_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tnr_bf16x4 __attribute__((ext_vector_type(4)));
+// the same split for one staging item (4 channels): three 8-byte pieces for the hi / mid / lo planes of an LDS row
+__device__ __forceinline__ void tnr_split4_bf16x3(const f32x4 v, tnr_f32x2 (&out)[3]) {
+    tnr_bf16x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 hh = (__bf16)v[i];
+        const float r1 = v[i] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[i] = hh;
+        m[i] = mm;
+        l[i] = (__bf16)(r1 - (float)mm);
+    }
+    out[0] = __builtin_bit_cast(tnr_f32x2, h);
+    out[1] = __builtin_bit_cast(tnr_f32x2, m);
+    out[2] = __builtin_bit_cast(tnr_f32x2, l);
+}
+#ifndef TNR_X3_REFILL
+#define TNR_X3_REFILL 1     /* TNR_MMA_BF16X3: 1 = the input tile is split when it is written to LDS, 0 = at every fragment read */
+#endif
+constexpr int TNR_X3_ROW = 24;     // floats per input-tile row in that form: three planes (hi, mid, lo) of 16 bf16
 constexpr int TNR_AUX_SC0_SC1 = 17;   // raw-buffer cache policy: sc0 (bit 0) | sc1 (bit 4) = system-coherent
 #ifndef TNR_COH_LOAD_AUX
 #define TNR_COH_LOAD_AUX TNR_AUX_SC0_SC1
@@ -131,8 +153,14 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     constexpr int NC = NT * 32;
     constexpr int PST = TNR_PST, CK = TNR_CK;
 
-    float *s_in = smem;                 // HT*WT*PST
-    float *s_w = smem + HT * WT * PST;  // NTAPS*NC*PST
+    // X3R (TNR_MMA_BF16X3, TNR_X3_REFILL): the input tile lives in LDS already split -- a row (pixel) is three 32-byte planes
+    // (hi, mid, lo) of 16 bf16; lane-half h reads the 16-byte slot h of a plane = channels 8h .. 8h+7, stored at slot
+    // h ^ ((row >> 2) & 1) (rows r and r + 4 share their banks at the 96-byte stride).  An input element is split ONCE per tile
+    // instead of once per tap and M-tile; the weight slab stays fp32 (split at the fragment read: one fragment per tap and N-tile).
+    constexpr bool X3R = (BF == 2) && (TNR_X3_REFILL != 0);
+    constexpr int ROWA = X3R ? TNR_X3_ROW : PST;
+    float *s_in = smem;                  // HT*WT*ROWA
+    float *s_w = smem + HT * WT * ROWA;  // NTAPS*NC*PST
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
@@ -167,6 +195,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         }
     }
     const int boff = li * PST + half * 4;
+    int apix[MT];        // X3R: tile-row index (pixel of the halo tile) of this lane's row of M-tile mi
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        if constexpr (TW == 32) {
+            apix[mi] = (wave * MT + mi) * WT + li;
+        } else {
+            const int p = (wave * MT + mi) * 32 + li;
+            const int r = p / TW, c = p - r * TW;
+            apix[mi] = r * WT + c;
+        }
+    }
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -279,6 +318,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         for (int it = 0; it < IN_IT; ++it) {
             const int i = tid + it * 256;
             const int row = tnr_stage_row(i);
+            if constexpr (X3R) {
+                if (row < IN_ROWS) {
+                    tnr_f32x2 pc[3];
+                    tnr_split4_bf16x3(rin[it], pc);
+                    const int q = i & 3;
+                    float *dst = s_in + row * ROWA + 4 * ((q >> 1) ^ ((row >> 2) & 1)) + 2 * (q & 1);
+                    *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+                }
+            } else
             if (row < IN_ROWS) *reinterpret_cast<f32x4 *>(s_in + row * PST + (i & 3) * 4) = rin[it];
         }
 #pragma unroll
@@ -333,10 +383,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
         const bool have_next = chunk + 1 < c_end;
 #if !defined(TNR_ABL_NOLOAD) && defined(TNR_NO_LOAD_SPREAD)
         if (have_next) load_chunk(chunk + 1);
+        constexpr bool X3_SPREAD = false;
 #elif !defined(TNR_ABL_NOLOAD)
         // (bf16 operand mode: a chunk's MFMA phase is 16x shorter and the launch is HBM-bound -- every cycle of head start counts:
         // 119.1 img/s with the burst, 111.2 with the loads spread over the taps)
-        if (BF && have_next) load_chunk(chunk + 1);
+#ifndef TNR_X3_SPREAD
+#define TNR_X3_SPREAD 0     /* split-operand form: next-chunk loads as one burst in front of the MFMA phase (0; measured: chain 99 ms/step) or handed out over the first three taps as in the fp32 loop (1: 109 ms) */
+#endif
+        constexpr bool X3_SPREAD = X3R && (TNR_X3_SPREAD != 0) && NTAPS >= 3;
+        if (BF && !X3_SPREAD && have_next) load_chunk(chunk + 1);
+#else
+        constexpr bool X3_SPREAD = false;
 #endif
         TNR_PH_T(ph5);
         // ---- MFMA over taps x 16 channels, software-pipelined one step deep.  A step is one tap x one
@@ -349,7 +406,93 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #if defined(TNR_PRIO_EPI) || defined(TNR_PRIO_REFILL)
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if constexpr (BF) {
+        if constexpr (X3R) {
+            // a step = one tap.  A fragments come out of LDS ready (3 ds_read_b128 per M-tile: hi, mid, lo); the B fragment(s)
+            // are read raw and split after the MFMAs of the previous tap.  The M-tiles form two groups: the fragments of group g
+            // for tap t+1 are loaded right after the MFMAs of group g for tap t were issued, with the other group's MFMAs
+            // (>= 384 matrix-core cycles) covering the LDS latency -- one register set, no raw A registers.
+            constexpr int NG = (MT >= 2) ? 2 : 1, G0 = MT / NG;
+            tnr_bf16x8 ca[MT][3], cb_[NT][3];
+            f32x4 rb[NT][2];
+            auto tap_pos = [&](int t, int &pix, int &woff) {
+                int pos_y, pos_x;
+                if (DG2) {
+                    pos_y = 1 + py - (t >> 1);
+                    pos_x = 1 + px - (t & 1);
+                } else if (S2D) {
+                    pos_y = t >> 1;
+                    pos_x = t & 1;
+                } else if (P11) {
+                    pos_y = 0;
+                    pos_x = 0;
+                } else {
+                    pos_y = t / 3;
+                    pos_x = t - pos_y * 3;
+                }
+                pix = pos_y * WT + pos_x;
+                woff = t * NC * PST + li * PST + half * 8;      // channels 8 half .. 8 half + 7 of the row: the k-order of the A planes
+            };
+            auto load_a = [&](int t, int m0, int m1) {
+                int pix, woff;
+                tap_pos(t, pix, woff);
+#pragma unroll
+                for (int mi = m0; mi < m1; ++mi) {
+                    const int pp = apix[mi] + pix;
+                    const float *src = s_in + pp * ROWA + 4 * (half ^ ((pp >> 2) & 1));
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) ca[mi][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+                }
+            };
+            auto read_b = [&](int t) {
+                int pix, woff;
+                tap_pos(t, pix, woff);
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) {
+                    rb[nn][0] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
+                    rb[nn][1] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + 4);
+                }
+            };
+            auto split_b = [&]() {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) tnr_split_bf16x3(rb[nn][0], rb[nn][1], cb_[nn]);
+            };
+            auto mma_group = [&](int m0, int m1) {
+                // the six kept partial products, smallest first; the accumulators of the group keep dependent MFMAs apart
+                constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int mi = m0; mi < m1; ++mi)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn)
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][TA[p]], cb_[nn][TB[p]], acc[mi][nn], 0, 0, 0);
+            };
+            read_b(0);
+            load_a(0, 0, MT);
+            split_b();
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                if (t + 1 < NTAPS) read_b(t + 1);
+                if constexpr (X3_SPREAD) {      // a third of the next chunk's global loads per tap, in front of its MFMAs (as in the fp32 loop)
+                    constexpr int IPS = (N_ITEMS + 2) / 3;
+                    if (have_next && t < 3) {
+#pragma unroll
+                        for (int k = t * IPS; k < (t + 1) * IPS && k < N_ITEMS; ++k) load_item(chunk + 1, k);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(0, G0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) load_a(t + 1, 0, G0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (NG == 2) mma_group(G0, MT);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < NTAPS) {
+                    if (NG == 2) load_a(t + 1, G0, MT);
+                    split_b();
+                }
+            }
+        } else if constexpr (BF) {
             // a step = one tap: 2 (MT + NT) ds_read_b128 into the raw set, converted to bf16x8 AFTER the MFMAs of the
             // previous tap were issued (the reads had a whole MFMA group to land), MT*NT MFMAs of k = 16
             constexpr int NS = BF == 2 ? 3 : 1;      // operand splits (TNR_MMA_BF16X3: hi, mid, lo)

@@ -185,11 +185,13 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
 
 constexpr int CH_TH = 16, CH_TW = 32;
 constexpr int CH_CU_KEYS = 16 * 128;   // (xcc, se, sh, cu) keys of chain_kernel's per-CU arrival counters
-constexpr size_t chain_lds() {
-    constexpr size_t lds_main = (size_t)((CH_TH + 2) * (CH_TW + 2) + 9 * 32) * TNR_PST * sizeof(float);
-    constexpr size_t lds_epi = (size_t)4 * 4 * 32 * 32 * sizeof(float);
+constexpr size_t chain_lds(int bf = 0) {
+    // (the split-operand form keeps the input tile as three bf16 planes: 96-byte rows, conv_body.h)
+    const size_t lds_main = (size_t)((CH_TH + 2) * (CH_TW + 2) * ((bf == 2 && TNR_X3_REFILL != 0) ? TNR_X3_ROW : TNR_PST) + 9 * 32 * TNR_PST) * sizeof(float);
+    const size_t lds_epi = (size_t)4 * 4 * 32 * 32 * sizeof(float);
     return lds_main > lds_epi ? lds_main : lds_epi;
 }
+static_assert(chain_lds(2) <= 80 * 1024, "two chain workgroups per CU");
 
 int chain_capacity(int *out) {
     static int cap = 0;
@@ -208,7 +210,7 @@ int chain_capacity(int *out) {
                                 (int)chain_lds()) != hipSuccess ||
 #endif
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)chain_lds()) != hipSuccess ||
+                                (int)chain_lds(2)) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv_chain_kernel<0>, 256, chain_lds()) != hipSuccess) {
             tnr_set_error("conv_chain: cannot size the grid");
             return TNR_ELAUNCH;
@@ -216,6 +218,11 @@ int chain_capacity(int *out) {
         // LDS allows two workgroups per CU; never trust a larger answer (the progress waits need every
         // workgroup of the grid to be resident at once)
         if (per_cu > 2) per_cu = 2;
+        int per_cu_x3 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_x3, conv_chain_kernel<2>, 256, chain_lds(2)) != hipSuccess || per_cu_x3 < per_cu) {
+            tnr_set_error("conv_chain: the split-operand form does not reach %d workgroups per CU (%d)", per_cu, per_cu_x3);
+            return TNR_ELAUNCH;
+        }
         if (per_cu < 1 || cus < 1) {
             tnr_set_error("conv_chain: kernel does not fit a CU");
             return TNR_ELAUNCH;
@@ -302,7 +309,7 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     else
 #endif
     if (d0.mma == TNR_MMA_BF16X3)
-        hipLaunchKernelGGL(conv_chain_kernel<2>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
+        hipLaunchKernelGGL(conv_chain_kernel<2>, dim3(grid), dim3(256), chain_lds(2), (hipStream_t)stream, c);
     else if (d0.mma == TNR_MMA_BF16)
         hipLaunchKernelGGL(conv_chain_kernel<1>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else
