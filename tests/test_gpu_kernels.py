@@ -840,6 +840,23 @@ def test_bf16x3_split_operand_mode(monkeypatch):
         ops.conv_small(ops.View(nhwc_buf(xs)), wps, ops.View(ys), 3, 1)
         return to_nchw(ys, 0, 96)
     both("im2col splitk", small, F.conv2d(xs.to(d), ws_.to(d), None, padding=1))
+    # weight gradients: every workgroup tile class (32 x 32/64/96/128 pixel-split and shared-pixel, 64 x 64, strided)
+    monkeypatch.setattr(ops, "WGRAD_X3", True)
+    for (mode, Nn, Hh, Ww, ci, co) in (("3x3", 2, 32, 32, 32, 32), ("3x3", 1, 32, 48, 64, 32), ("3x3", 2, 16, 16, 96, 32),
+                                       ("3x3", 1, 24, 32, 128, 32), ("3x3", 2, 16, 32, 192, 64), ("s2", 2, 16, 32, 64, 64)):
+        xx = rnd(Nn, ci, Hh, Ww, seed=11)
+        k = 3 if mode == "3x3" else 4
+        ww = rnd(co, ci, k, k, seed=12).to(d).requires_grad_(True)
+        yy = F.conv2d(xx.to(d), ww, None, padding=1) if mode == "3x3" else F.conv2d(xx.to(d), ww, None, stride=2, padding=1)
+        gg = rnd(*yy.shape, seed=13)
+        (rw,) = torch.autograd.grad(yy, ww, gg.to(d))
+        xg, ggb = nhwc_buf(xx), nhwc_buf(gg)
+
+        def wg():
+            dw, db = torch.zeros(co, ci, k, k, device=DEV), torch.zeros(co, device=DEV)
+            ops.wgrad(ops.View(xg), ops.View(ggb), dw, db, mode=ops.CONV_3x3 if mode == "3x3" else ops.CONV_4x4_S2, beta=0.0)
+            return dw.cpu()
+        both("wgrad %s %d->%d" % (mode, ci, co), wg, rw.detach())
     # the chain kernel's split-operand instantiation
     monkeypatch.setattr(ops, "CHAIN_X3", True)
     nf, gc = 64, 32

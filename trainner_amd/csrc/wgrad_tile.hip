@@ -71,7 +71,7 @@ __device__ __forceinline__ void wg_static_for(F &&f) {
 // BF: operands rounded to bf16 in front of the matrix core (tnr_wgrad_desc.mma = TNR_MMA_BF16).  The reduction index of
 // this GEMM is the pixel: a 16-pixel tile row is exactly the k = 16 of one v_mfma_f32_32x32x16_bf16 (lane-half h supplies
 // pixels h, 2 + h, .., 14 + h: the same 8 values it feeds to 8 fp32 k-steps), so a row costs J MFMAs instead of 8 J.
-template <int MODE, int A_T, int B_T, int THG, bool BF>
+template <int MODE, int A_T, int B_T, int THG, int BF>
 __global__ void __launch_bounds__(256, (WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD))
 wgrad_tile_kernel(const WgK ga) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
@@ -285,7 +285,61 @@ wgrad_tile_kernel(const WgK ga) {
             int xo[J];
 #pragma unroll
             for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
-            if constexpr (BF) {
+            if constexpr (BF == 2) {
+                // TNR_MMA_BF16X3: fp32 operands split exactly into three bf16 values as they leave LDS (conv_body.h has the
+                // arithmetic), six MFMAs per output tile and tile row.  The J tiles of a wave are taken two at a time: the raw
+                // values of the next pair are read while the current pair's 12 MFMAs run -- 2 x 8 raw + 2 x 12 split registers
+                // beside the J accumulators, whatever J is.
+                constexpr int NP = (J + 1) / 2;
+                constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+                float ra[8], rb[2][2][8];
+                wg_bf16x8 ca[3], cb[2][3];
+                auto split8 = [&](const float (&v)[8], wg_bf16x8 (&out)[3]) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const __bf16 h = (__bf16)v[i];
+                        const float r1 = v[i] - (float)h;
+                        const __bf16 m = (__bf16)r1;
+                        out[0][i] = h;
+                        out[1][i] = m;
+                        out[2][i] = (__bf16)(r1 - (float)m);
+                    }
+                };
+                auto read_pair = [&](int jp, int set) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = 2 * jp + q < J ? 2 * jp + q : J - 1;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) rb[set][q][kk] = smem[xo[j] + 2 * kk * CIB];
+                    }
+                };
+#pragma unroll 1
+                for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) ra[kk] = smem[go + 2 * kk * COB];
+                    read_pair(0, 0);
+                #pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) bsum += ra[kk];
+                    split8(ra, ca);
+#pragma unroll
+                    for (int jp = 0; jp < NP; ++jp) {
+                        if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
+                        split8(rb[jp & 1][0], cb[0]);
+                        if (2 * jp + 1 < J) split8(rb[jp & 1][1], cb[1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int p = 0; p < 6; ++p) {
+                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[0][TB[p]], acc[2 * jp], 0, 0, 0);
+                            if (2 * jp + 1 < J)
+                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    go += TWG * COB;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
+                }
+            } else if constexpr (BF) {
                 float ra[8], rb[8][J];
                 wg_bf16x8 ca, cb[J];
                 auto read_row = [&]() {
@@ -555,7 +609,7 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     return 0;
 }
 
-template <int MODE, int A_T, int B_T, int THG, bool BF>
+template <int MODE, int A_T, int B_T, int THG, int BF>
 int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
@@ -578,7 +632,8 @@ int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
 
 template <int MODE, int A_T, int B_T, int THG>
 int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
-    return k.bf ? launch_wgrad_t<MODE, A_T, B_T, THG, true>(k, jobs, s) : launch_wgrad_t<MODE, A_T, B_T, THG, false>(k, jobs, s);
+    if (k.bf == 2) return launch_wgrad_t<MODE, A_T, B_T, THG, 2>(k, jobs, s);
+    return k.bf ? launch_wgrad_t<MODE, A_T, B_T, THG, 1>(k, jobs, s) : launch_wgrad_t<MODE, A_T, B_T, THG, 0>(k, jobs, s);
 }
 
 template <int MODE>
@@ -674,7 +729,8 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
     k.N = d0.N; k.H = d0.H; k.W = d0.W; k.Ho = d0.Ho; k.Wo = d0.Wo;
     k.tiles_x = p0.tiles_x; k.tiles_y = p0.tiles_y; k.tiles_total = p0.tiles_total;
     k.tiles_per_split = p0.tiles_per_split; k.nsplits = p0.splits; k.njobs = n;
-    k.bf = d0.mma == TNR_MMA_BF16;
+    TNR_REQUIRE(d0.mma >= TNR_MMA_F32 && d0.mma <= TNR_MMA_BF16X3, "wgrad: bad mma %d", d0.mma);
+    k.bf = d0.mma;
     k.reflect = d0.pad_mode == 1;
     TNR_REQUIRE(d0.pad_mode == 0 || (d0.pad_mode == 1 && d0.mode == TNR_CONV_3x3 && d0.H >= 2 && d0.W >= 2), "wgrad: pad_mode 1 (reflection) is for TNR_CONV_3x3");
     for (int i = 1; i < n; ++i) TNR_REQUIRE(descs[i].pad_mode == d0.pad_mode, "wgrad_group: layer %d: one border mode per launch", i);

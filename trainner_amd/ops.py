@@ -396,6 +396,7 @@ def conv_col(x, wp_col, y, k, stride=1, pad=1, **epi):
 
 
 WGRAD_GROUP_MAX = 8
+WGRAD_X3 = os.environ.get("TNR_WGRAD_X3", "1") == "1"   # TNR_MMA=bf16x3 also in the weight-gradient kernel (A/B switch)
 
 
 def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
@@ -407,7 +408,7 @@ def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
     d.dw, d.cin_total, d.cin_begin = dw.data_ptr(), dw.shape[1], cin_begin
     d.db = hip.ptr(db)
     d.alpha, d.beta = alpha, beta
-    d.mma = hip.MMA_F32 if MMA == hip.MMA_BF16X3 else MMA      # (the weight-gradient kernel has no split-operand form yet)
+    d.mma = hip.MMA_F32 if (MMA == hip.MMA_BF16X3 and not WGRAD_X3) else MMA
     d.pad_mode = 1 if reflect else 0
 
 
