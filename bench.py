@@ -242,6 +242,7 @@ def main():
     ap.add_argument("--mma", choices=["f32", "bf16x3"], default=os.environ.get("TNR_MMA", "f32"),
                     help="fp32 arithmetic of the per-layer convolution kernels: f32 = v_mfma_f32_32x32x2_f32 (headline); bf16x3 = operands "
                          "split exactly into three bf16 values, six partial products on the bf16 matrix core, fp32 accumulate (variant)")
+    ap.add_argument("--no-variant", action="store_true", help="skip the second (bf16x3) measurement")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
@@ -362,6 +363,37 @@ def main():
                              "mfma_view": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                              "traffic_source": (traffic_src or "") + " -- fp32 run; bf16 operand mode moves the same bytes"})
 
+    # second measurement in the same process: the same step with TNR_MMA_BF16X3 (fp32 operands split exactly into three bf16
+    # values, six exact partial products per multiply on the bf16 matrix core, fp32 accumulate -- error against fp64 not above
+    # the fp32 matrix-core kernels', tests/test_gpu_kernels.py::test_bf16x3_split_operand_mode).  Reported beside the headline,
+    # which stays on v_mfma_f32_32x32x2_f32.
+    variant = None
+    if not args.amp and args.mma == "f32" and not args.no_variant and not args.no_roofline and feeder is None and not dry:
+        ops.MMA = ops.FP32_MMA = hip.MMA_BF16X3
+        for _ in range(2):
+            step += 1
+            model.feed_data(data)
+            model.optimize_parameters(step)
+        barrier()
+        tv = time.perf_counter()
+        for _ in range(args.steps):
+            step += 1
+            model.feed_data(data)
+            model.optimize_parameters(step)
+        barrier()
+        dtv = time.perf_counter() - tv
+        if world > 1:
+            t = torch.tensor([dtv], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dtv = float(t.item())
+        ops.MMA = ops.FP32_MMA = hip.MMA_F32
+        if ops.chain_error_flag():
+            raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
+        variant = {"mma": "bf16x3: fp32 operands split exactly into 3 bf16 values, 6 of 9 exact partial products on the bf16 matrix "
+                          "core, fp32 accumulate (convolutions, data- and weight-gradients); same step, same process",
+                   "value": round(args.batch * world * args.steps / dtv, 3), "unit": "HR img/s",
+                   "ms_per_step": round(1e3 * dtv / args.steps, 2), "steps": args.steps, "warmup": 2, "dtype": "f32 (bf16x3 split operands)"}
+
     if rank == 0:
         imgs = args.batch * world * args.steps
         memo = bool(getattr(getattr(model, "netD", None), "memoize", False)) and args.netd == "discriminator_vgg"
@@ -387,6 +419,7 @@ def main():
             "step_tflops": round((FLOP_PER_IMG - (2 * D_FWD_FLOP_PER_IMG if memo else 0.0)) * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
             "d_forward_memoized": memo,
             "roofline": roof,
+            "variant_bf16x3": variant,
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
         if feeder is not None:
