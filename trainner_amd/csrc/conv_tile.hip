@@ -19,9 +19,10 @@
 // This file: the one-launch-per-layer kernel (optionally split along K, with a reduce launch) and the host
 // side of tnr_conv_forward.  The device body is conv_body.h; conv_chain.hip runs it for several layers per launch.
 #include "conv_body.h"
+#include "conv_x3w8.h"
+#include <cstdlib>
 #ifdef TNR_CONV_DL_EXPERIMENT     /* tools/build_variant.py dl -DTNR_CONV_DL_EXPERIMENT: the LDS-DMA staging experiments, conv_body_dl.h */
 #include "conv_body_dl.h"
-#include <cstdlib>
 #endif
 
 namespace {
@@ -234,6 +235,10 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
         tiles *= ksplit;
     }
     int rc;
+    {   // TNR_MMA_BF16X3, 64-cout 3x3 layers: the 8-wave kernel with both operands pre-split in LDS (conv_x3w8.h; TNR_X3_W8=0: off)
+        static const bool w8 = [] { const char *e = std::getenv("TNR_X3_W8"); return e == nullptr || e[0] != '0'; }();
+        if (w8 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_x3w8_ok(k)) return launch_conv3x3_x3w8(k, s);
+    }
 #ifdef TNR_CONV_DL_EXPERIMENT
     const char *dl_env = std::getenv("TNR_CONV_DL");     // (experiment switch, read per call so that one process can compare both paths)
     const int dl = dl_env != nullptr ? dl_env[0] - '0' : 0;      // 1: 8-wave / 16-channel form, 2: 4-wave / 8-channel form
