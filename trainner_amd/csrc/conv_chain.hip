@@ -17,6 +17,7 @@
 // stage-major, so a waited-for tile always belongs to a running workgroup at an earlier program point.
 #include <stddef.h>
 #include "conv_body.h"
+#include "conv_epilogue.h"
 #ifdef TNR_CONV_DL_EXPERIMENT     /* tools/build_variant.py dl -DTNR_CONV_DL_EXPERIMENT: LDS-DMA staging experiment, conv_body_dl.h */
 #include "conv_body_dl.h"
 #include <cstdlib>
@@ -183,6 +184,172 @@ __global__ void __launch_bounds__(256, 2) conv_chain_kernel(const ChainK c) {
         __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- TNR_MMA_BF16X3, 8-wave form (see conv_x3w8.h for the idea): ONE workgroup of 8 waves per CU, tile 32 x 32 pixels x 32 output
+// channels per pass, input tile 34 x 34 pixels and weight slab 9 x 32 rows both pre-split in LDS (96-byte rows of three bf16 planes:
+// 138 624 B), wave w owns tile rows 4 w .. 4 w + 3 (four M-tiles).  Same hand-off protocol as conv_chain_kernel (system-coherent input
+// loads and output stores, per-tile progress counters, publish deferred to chunk 1, neighbour wait in front of the first chunk that
+// reads the previous stage's channels); the tile grid is 32 x 32, so a 128 x 128 x 16 batch is exactly one tile per CU.  Arithmetic
+// (split, kept partial products, chunk and tap order) is that of conv_tile_body<.., BF = 2>: bit-identical results.
+struct CX3 {
+    static constexpr int TW = 32, TH = 32, MT = 4, NT = 1, HT = TH + 2, WT = TW + 2, NC = 32, ROW = TNR_X3_ROW;
+    static constexpr int IN_ROWS = HT * WT, W_ROWS = 9 * NC;
+    static constexpr size_t LDS_BYTES = (size_t)(IN_ROWS + W_ROWS) * ROW * sizeof(float);
+};
+
+__device__ __forceinline__ void chain_x3w8_body(const ConvK a, const int cb, const int tx, const int ty, const int n, float *smem,
+                                                const int wait_chunk, const ChainWait &wait) {
+    using G = CX3;
+    constexpr int MT = G::MT, NT = G::NT, WT = G::WT, NC = G::NC, ROW = G::ROW;
+    float *s_in = smem, *s_w = smem + G::IN_ROWS * ROW;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+    const int ty0 = ty * G::TH, tx0 = tx * G::TW;
+    const int nchunks = a.KinP / TNR_CK;
+
+    constexpr int IN_IT = (G::IN_ROWS * 4 + 511) / 512, W_IT = (G::W_ROWS * 4 + 511) / 512;
+    int in_off[IN_IT], w_off[W_IT];      // element offsets without the chunk's channel offset, -1: zero fill
+#pragma unroll
+    for (int it = 0; it < IN_IT; ++it) {
+        const int i = tid + it * 512, row = i >> 2, q = i & 3;
+        const int hr = row / WT, hc = row - hr * WT;
+        const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+        const bool ok = (row < G::IN_ROWS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+        in_off[it] = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < W_IT; ++it) {
+        const int i = tid + it * 512, row = i >> 2, q = i & 3;
+        const int t = row / NC, co = row - t * NC;
+        const int cog = cb * NC + co;
+        w_off[it] = (row < G::W_ROWS && cog < a.KoutP) ? ((t * a.KoutP + cog) * a.KinP + q * 4) : -1;
+    }
+    f32x4 rin[IN_IT], rw[W_IT];
+    auto load_chunk = [&](int chunk) {
+        const int c0 = chunk * TNR_CK;
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) {       // system-coherent: the channels may have been written by another CU in this launch
+            const unsigned bo = in_off[it] >= 0 ? (unsigned)(in_off[it] + c0) * 4u : 0xfffffff0u;      // (past the end: the range check returns 0)
+            rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (w_off[it] >= 0) v = *reinterpret_cast<const f32x4 *>(a.wp + (size_t)w_off[it] + c0);
+            rw[it] = v;
+        }
+    };
+    auto store_item = [&](float *base, int i, int rows, const f32x4 v) {
+        const int row = i >> 2, q = i & 3;
+        if (row < rows) {
+            tnr_f32x2 pc[3];
+            tnr_split4_bf16x3(v, pc);
+            float *dst = base + row * ROW + 4 * ((q >> 1) ^ ((row >> 2) & 1)) + 2 * (q & 1);
+            *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
+            *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
+            *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < IN_IT; ++it) store_item(s_in, tid + it * 512, G::IN_ROWS, rin[it]);
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) store_item(s_w, tid + it * 512, G::W_ROWS, rw[it]);
+    };
+
+    const int apix0 = (wave * MT) * WT + li;                        // M-tile mi: + mi * WT
+    const int boff = li * ROW + 4 * (half ^ ((li >> 2) & 1));       // row t * 32 + li: bit 2 is that of li
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][0][r] = 0.f;
+    tnr_bf16x8 ca[MT][3], cb_[2][3];
+    auto load_a = [&](int t, int m0, int m1) {
+#pragma unroll
+        for (int mi = m0; mi < m1; ++mi) {
+            const int pp = apix0 + mi * WT + (t / 3) * WT + (t % 3);
+            const float *src = s_in + pp * ROW + 4 * (half ^ ((pp >> 2) & 1));
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) ca[mi][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+        }
+    };
+    auto load_b = [&](int t, int set) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) cb_[set][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_w + boff + t * NC * ROW + 8 * sp);
+    };
+    auto mma = [&](int m0, int m1, int set) {
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int mi = m0; mi < m1; ++mi)
+                acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][TA[p]], cb_[set][TB[p]], acc[mi][0], 0, 0, 0);
+    };
+
+    if (wait_chunk == 0) wait();
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        store_chunk();
+        if (chunk == 1) wait.drain();
+        __syncthreads();
+        if (chunk == 1) wait.publish();
+        if (chunk + 1 < nchunks) {
+            if (chunk + 1 == wait_chunk) wait();
+            load_chunk(chunk + 1);
+        }
+        load_b(0, 0);
+        load_a(0, 0, MT);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t + 1 < 9) load_b(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 2, t & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) load_a(t + 1, 0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(2, 4, t & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < 9) load_a(t + 1, 2, 4);
+        }
+    }
+    conv_epilogue_dpp<TNR_CONV_3x3, G::TW, NT, MT, true>(a, acc, cb, n, ty0, tx0, 0, wave, li, half, y_rs);
+}
+
+__global__ void __launch_bounds__(512, 1) conv_chain_x3w8_kernel(const ChainK c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int pend_tile = -1;
+    unsigned pend_value = 0;
+    for (int s = 0; s < c.nstages; ++s) {
+        int wait_chunk;
+        const ConvK st = chain_stage(s, &wait_chunk);
+        const int ncb = st.KoutP >> 5;
+        for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+            int q = tile;
+            const int tx = q % c.tiles_x;
+            q /= c.tiles_x;
+            const int ty = q % c.tiles_y;
+            const int n = q / c.tiles_y;
+            const ChainWait w{c.progress, c.base + (unsigned)s, n, ty, tx, c.tiles_x, c.tiles_y, c.err, &pend_tile, pend_value};
+            for (int cb = 0; cb < ncb; ++cb) {
+                int txo = tx, tyo = ty, no = n;
+                asm volatile("" : "+s"(txo), "+s"(tyo), "+s"(no));
+                chain_x3w8_body(st, cb, txo, tyo, no, smem, cb == 0 ? wait_chunk : -1, w);
+            }
+            pend_tile = tile;
+            pend_value = c.base + (unsigned)s + 1u;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pend_tile >= 0 && threadIdx.x == 0)
+        __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int CH_TH = 16, CH_TW = 32;
 constexpr int CH_CU_KEYS = 16 * 128;   // (xcc, se, sh, cu) keys of chain_kernel's per-CU arrival counters
 constexpr size_t chain_lds(int bf = 0) {
@@ -308,8 +475,35 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
         hipLaunchKernelGGL((conv_chain_kernel<0, 2>), dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else
 #endif
-    if (d0.mma == TNR_MMA_BF16X3)
+    if (d0.mma == TNR_MMA_BF16X3) {
+        // the 8-wave form (TNR_CHAIN_X3W8=1): 32 x 32 tiles, one workgroup per CU
+        static const bool w8 = [] { const char *e = std::getenv("TNR_CHAIN_X3W8"); return e != nullptr && e[0] == '1'; }();
+        bool ok8 = w8;
+        for (int i = 0; i < n; ++i) ok8 = ok8 && c.st[i].Cin == c.st[i].KinP && !c.st[i].reflect;
+        if (ok8) {
+            static int cus = 0;
+            if (cus == 0) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(conv_chain_x3w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)CX3::LDS_BYTES) != hipSuccess || cus < 1) {
+                    cus = 0;
+                    tnr_set_error("conv_chain: cannot set up the 8-wave form");
+                    return TNR_ELAUNCH;
+                }
+            }
+            ChainK c8 = c;
+            c8.tiles_x = tnr_cdiv(d0.Wo, CX3::TW);
+            c8.tiles_y = tnr_cdiv(d0.Ho, CX3::TH);
+            c8.tiles = c8.tiles_x * c8.tiles_y * d0.N;
+            c8.dyn = 0;
+            const int grid8 = c8.tiles < cus ? c8.tiles : cus;
+            constexpr size_t lds8 = CX3::LDS_BYTES;
+            hipLaunchKernelGGL(conv_chain_x3w8_kernel, dim3(grid8), dim3(512), lds8, (hipStream_t)stream, c8);
+            return tnr_check_launch("conv_chain_x3w8");
+        }
         hipLaunchKernelGGL(conv_chain_kernel<2>, dim3(grid), dim3(256), chain_lds(2), (hipStream_t)stream, c);
+    }
     else if (d0.mma == TNR_MMA_BF16)
         hipLaunchKernelGGL(conv_chain_kernel<1>, dim3(grid), dim3(256), chain_lds(), (hipStream_t)stream, c);
     else
