@@ -104,7 +104,8 @@ typedef struct tnr_conv_desc {
      * `use_amp: true` policy (base_model.py:736-744 autocasts the convolutions to half precision);
      * TNR_MMA_BF16X3 = fp32 arithmetic on the bf16 matrix core: every operand is split EXACTLY into three bf16 values
      * (hi + mid + lo = x), the six largest of the nine partial products (each exact) are accumulated in fp32 -- the dropped
-     * ones are below 2^-24 of the product, i.e. below fp32 rounding -- at 6/16 of the fp32 matrix-core cycles.  Accepted by
+     * ones are below 2^-23 of the product by construction (2^-28 on average: less than fp32 rounding) -- at 6/16 of the fp32
+     * matrix-core cycles.  Accepted by
      * tnr_conv_forward, tnr_conv_chain and tnr_wgrad / tnr_wgrad_group.  Finite inputs only: an infinite operand splits into
      * inf + NaN (the fp32 matrix core would deliver inf or NaN there as well); operands below 2^-110 lose their low split.  */
     int32_t mma;
