@@ -366,9 +366,9 @@ def main():
     # second measurement in the same process: the same step with TNR_MMA_BF16X3 (fp32 operands split exactly into three bf16
     # values, six exact partial products per multiply on the bf16 matrix core, fp32 accumulate -- error against fp64 not above
     # the fp32 matrix-core kernels', tests/test_gpu_kernels.py::test_bf16x3_split_operand_mode).  Reported beside the headline,
-    # which stays on v_mfma_f32_32x32x2_f32.
+    # which stays on v_mfma_f32_32x32x2_f32.  (1 GPU only: the N > 1 runs are the scaling measurement and carry nothing extra.)
     variant = None
-    if not args.amp and args.mma == "f32" and not args.no_variant and not args.no_roofline and feeder is None and not dry:
+    if world == 1 and not args.amp and args.mma == "f32" and not args.no_variant and not args.no_roofline and feeder is None and not dry:
         ops.MMA = ops.FP32_MMA = hip.MMA_BF16X3
         for _ in range(2):
             step += 1
