@@ -58,6 +58,12 @@ def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 
 
+def test_step_vs_reference_golden_split_operand_mode(tmp_path, monkeypatch):
+    """TNR_MMA=bf16x3 is an fp32 mode: the host logic (setup_amp keeps ops.FP32_MMA, the chain / weight-gradient policies in
+    ops.py, descriptors carrying mma = 2) runs the same step; the stand-in backend computes fp32 for it, as the contract says."""
+    TS.test_step_matches_reference_golden_bf16x3("esrgan_nb1_crop64", tmp_path, monkeypatch)
+
+
 @pytest.mark.parametrize("case", TI.I2I_CASES)
 def test_i2i_step_vs_reference_golden(case, tmp_path):
     TI.test_i2i_step_matches_reference_golden(case, tmp_path)
