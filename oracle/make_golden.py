@@ -33,6 +33,9 @@ CASES = {
     # BASELINE.json configs[1] at its real resolution with batch 2: Discriminator_VGG(512)'s BatchNorm reduces over
     # more than one image (the 4x4 layer: 32 positions), RRDBNet-23, all losses, one step
     "esrgan_nb23_crop512_b2": dict(yaml=dict(nb=23, batch=2, crop=512, d_nf=64), steps=1, seed=51),
+    # the same at batch 4: BatchNorm statistics and the relativistic batch means over FOUR images at the benchmark resolution
+    # (~27 GB RSS in the build container)
+    "esrgan_nb23_crop512_b4": dict(yaml=dict(nb=23, batch=4, crop=512, d_nf=64), steps=1, seed=81),
     # SURVEY.md 8(d) parity metric K = 10: ten consecutive G+D steps at reduced size, batch 4
     "esrgan_nb2_crop64_k10": dict(yaml=dict(nb=2, batch=4, crop=64, d_nf=16), steps=10, seed=61),
     # Real-ESRGAN's discriminator: network_D: unet -> UNetDiscriminator, per-pixel logits, 2 steps

@@ -225,3 +225,52 @@ def test_i2i_training_step_through_the_feeder(kind, tmp_path):
         model.optimize_parameters(step)
     log = model.get_current_log()
     assert step == 2 and len(log) >= 4 and all(np.isfinite(v) for v in log.values())
+
+
+@pytest.mark.gpu
+def test_memoized_discriminator_with_gradient_accumulation_through_the_feeder(tmp_path, monkeypatch):
+    """DeviceFeeder refills its two persistent slot buffers with a raw kernel, so batches k and k + 2 share the same
+    tensor address AND version counter; with virtual_batch_size = 3 x batch_size the discriminator's parameters do not move
+    for three micro-steps.  A forward memo keyed on (storage, version, parameter version) alone would hand batch k's logits
+    and saved activations to batch k + 2.  The memo is emptied at the start of every optimize_parameters: six micro-steps
+    (two optimizer steps) with and without memoization must agree bit for bit."""
+    import test_gpu_step as TS
+    from oracle import detrand
+    from trainner_amd.data.feeder import DeviceFeeder
+    rng = np.random.RandomState(5)
+    batches = [{"HR": rng.randint(0, 256, (2, 64, 64, 3), dtype=np.uint8), "flags": np.zeros(2, np.int64)} for _ in range(6)]
+    for b in batches:
+        b["LR"] = np.ascontiguousarray(b["HR"][:, ::4, ::4])
+
+    def run(memo, sub):
+        monkeypatch.setenv("TNR_D_MEMO", "1" if memo else "0")
+        (tmp_path / sub).mkdir()
+        yml_kw = dict(nb=1, batch=2, crop=64, d_nf=16)
+        from oracle import ref_harness
+        from trainner_amd.models import create_model
+        from trainner_amd.options import options
+        yml = ref_harness.esrgan_yaml(name="accum", out_root=str(tmp_path / sub), gpu_ids="[0]", **yml_kw)
+        txt = open(yml).read().replace("virtual_batch_size: 2", "virtual_batch_size: 6")
+        open(yml, "w").write(txt)
+        model = create_model(options.parse(yml, is_train=True), verbose=False)
+        assert model.accumulations == 3 and model.netD.memoize == memo
+        g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+        d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+        TS.load_initial(model, g, d, TS.FX.vgg_state(77))
+        logs = []
+        ptrs = set()
+        for s, data in enumerate(DeviceFeeder(batches), 1):
+            ptrs.add(data["HR"].data_ptr())
+            model.feed_data(data)
+            model.optimize_parameters(s)
+            logs.append(model.get_current_log())
+        assert len(ptrs) == 2                                  # two slots: batches k and k + 2 really share a buffer
+        return logs, {k: v.detach().cpu() for k, v in model.netD.state_dict().items()}, {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+
+    la, da, ga = run(True, "memo")
+    lb, db, gb = run(False, "plain")
+    assert la == lb
+    for k in da:
+        assert torch.equal(da[k], db[k]), k
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k

@@ -116,7 +116,7 @@ def test_i2i_amp_bf16_step_tracks_the_fp32_oracle(kind, tmp_path):
               lambda_identity=0.5 if kind == "cyclegan" else None)
     try:
         opt, model = build_i2i_model(dict(kw, amp=True), tmp_path)
-        assert model.amp and ops.MMA == hip.MMA_BF16
+        assert model.amp and ops.MMA == ops.FP32_MMA          # the bf16 region covers the training step only
         states = {}
         for i, n in enumerate(model.model_names):
             net = getattr(model, "net" + n)
@@ -143,4 +143,4 @@ def test_i2i_amp_bf16_step_tracks_the_fp32_oracle(kind, tmp_path):
             worst = max(worst, (model.fake_B.detach().cpu() - orc.fake_B.detach()).abs().max().item())
         assert 1e-5 < worst < 6e-2, worst          # (two InstanceNorm-normalised ResNet blocks + tanh: range 2)
     finally:
-        ops.MMA = hip.MMA_F32
+        ops.MMA = ops.FP32_MMA

@@ -65,6 +65,7 @@ def check_logs(log, ref_log, tol=2e-4, d_tol=None):
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
                                   "esrgan_nb2_crop64_k10",       # K = 10 consecutive G+D steps
                                   "esrgan_nb23_crop512_b2",      # BASELINE configs[1] resolution, batch 2: BN over > 1 image
+                                  "esrgan_nb23_crop512_b4",      # the same at batch 4: BN + relativistic means over 4 images
                                   "esrgan_nb1_unet"])            # network_D: unet (Real-ESRGAN's U-Net discriminator)
 def test_step_matches_reference_golden(case, tmp_path):
     fx = FX.load(case)
@@ -148,18 +149,21 @@ def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
     kw = dict(nb=2, batch=2, crop=64, d_nf=16, d_type=d_type)
     try:
         opt, model = build_engine_model(dict(kw, amp=True), tmp_path)
-        assert model.amp and ops.MMA == hip.MMA_BF16
+        assert model.amp and ops.MMA == ops.FP32_MMA          # the bf16 region covers the training step only
         g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
         d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
         f = FX.vgg_state(77)
         load_initial(model, g, d, f)
         orc = O.OracleSRStep(g, d, f, arch="rrdb_net", nb=2, d_size=64, d_nf=16, d_arch="unet" if d_type == "unet" else "discriminator_vgg")
         worst = 0.0
+        seen = []
+        model.netG.register_forward_pre_hook(lambda m, i: seen.append(ops.MMA))
         for s in (1, 2, 3):
             LR, HR = detrand.synthetic_pair(2, 64, 40 + s)
             ref_log = orc.step(LR, HR)
             model.feed_data({"LR": LR, "HR": HR})
             model.optimize_parameters(s)
+            assert seen[-1] == hip.MMA_BF16 and ops.MMA == ops.FP32_MMA     # bf16 operands inside the step, restored after it
             log = model.get_current_log()
             for k in ("pix-l1", "fea-vgg19-l1", "l_g_gan", "l_d_real", "l_d_fake"):
                 assert abs(log[k] - ref_log[k]) <= 0.03 * abs(ref_log[k]) + 1e-5, (s, k, log[k], ref_log[k])
@@ -167,8 +171,10 @@ def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
             worst = max(worst, (got - ref).abs().max().item())
             assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
         assert 1e-5 < worst < 2e-2, worst                  # bf16-sized differences: neither fp32-exact nor broken
+        model.test()                                       # validation forwards run in fp32 like the reference's (sr_model.py:269-277)
+        assert seen[-1] == ops.FP32_MMA
     finally:
-        ops.MMA = hip.MMA_F32                                # the precision is process-wide: restore for the other tests
+        ops.MMA = ops.FP32_MMA                                # the precision is process-wide: restore for the other tests
 
 
 def test_validation_forward_and_self_ensemble(tmp_path):

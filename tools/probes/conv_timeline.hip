@@ -5,6 +5,7 @@
 #include "../../trainner_amd/csrc/conv_tile.hip"
 #include "../../trainner_amd/csrc/conv_chain.hip"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 static void run(int Cin, int Cout, int N, int H, int W) {
@@ -75,6 +76,7 @@ static void run_chain(int N, int H, int W) {
         d[k].y.ptr = k < 4 ? buf : out; d[k].y.ctot = k < 4 ? 192 : 64; d[k].y.coff = k < 4 ? cin : 0;
         d[k].Ho = H; d[k].Wo = W; d[k].Cout = cout; d[k].mode = TNR_CONV_3x3; d[k].bias = bias; d[k].act = k < 4 ? 1 : 0;
         d[k].slope = 0.2f; d[k].alpha = 1.f;
+        d[k].mma = getenv("TNR_PROBE_MMA") ? atoi(getenv("TNR_PROBE_MMA")) : 0;     // 0 fp32 matrix core, 1 bf16 operands, 2 bf16x3
         fresh[k] = k ? cin - gc : -1;
     }
     const int64_t wsb = tnr_conv_chain_workspace_bytes(&d[0]);
@@ -122,6 +124,7 @@ static void run_chain(int N, int H, int W) {
 
 int main() {
     run_chain(16, 128, 128);
+    if (getenv("TNR_PROBE_MMA")) return 0;
     run(160, 32, 16, 128, 128);
     run(64, 32, 16, 128, 128);
     run(192, 64, 16, 128, 128);

@@ -26,8 +26,9 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_body.h"),
-                                                        os.path.join(HERE, "..", "include", "trainner_hip.h")]
+    import glob
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+        [os.path.join(HERE, "..", "include", "trainner_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

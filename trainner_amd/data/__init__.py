@@ -26,7 +26,9 @@ def create_dataset(dataset_opt):
 
 
 class _RankShard(tud.Sampler):
-    """rank-strided subset of a (shuffled) index permutation; same permutation on every rank (seeded per epoch)."""
+    """rank-strided subset of a (shuffled) index permutation; same permutation on every rank (seeded per epoch).  Every pass
+    over the sampler is a new epoch (the reference's DataLoader(shuffle=True) reshuffles per epoch, data/__init__.py:27-46):
+    the epoch counter advances by itself, identically on all ranks; set_epoch() still pins it (resume)."""
 
     def __init__(self, n, rank, world, shuffle, seed=0):
         self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
@@ -39,6 +41,7 @@ class _RankShard(tud.Sampler):
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
             idx = torch.randperm(self.n, generator=g).tolist()
+            self.epoch += 1
         else:
             idx = list(range(self.n))
         idx = idx[:len(idx) - len(idx) % self.world]

@@ -28,6 +28,7 @@ IMAGE_KEYS = ("LR", "HR", "A", "B", "ref")
 class _Slot:
     def __init__(self):
         self.pinned, self.dev_u8, self.dev_flags, self.out = {}, {}, {}, {}
+        self.h2d = {}              # key -> event recorded after the async upload out of this slot's pinned staging buffer
         self.ready = torch.cuda.Event()
         self.free = None           # recorded on the compute stream when the consumer moved on
         self.batch = None
@@ -51,6 +52,10 @@ class DeviceFeeder:
         self.depth = max(2, int(depth))
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.bytes_uploaded = 0
+        # the slots (device buffers, pinned staging, `free` events) live as long as the feeder: a new epoch's first uploads wait
+        # for the step that consumed the slot last, and no buffer goes back to the copy stream's allocator pool while the
+        # compute stream may still read it
+        self._slots = [_Slot() for _ in range(self.depth)]
 
     def __len__(self):
         return len(self.loader)
@@ -67,9 +72,17 @@ class DeviceFeeder:
         if host.is_pinned():
             pin = host                                       # the loader pinned it already (DataLoader(pin_memory=True))
         else:
+            ev = slot.h2d.get(key)
+            if ev is not None:
+                ev.synchronize()                             # the previous upload out of this staging buffer has executed
             pin.copy_(host)                                  # host memcpy into page-locked memory
         dev = slot.dev_u8[key]
         dev.copy_(pin, non_blocking=True)
+        if pin is not host:
+            ev = slot.h2d.get(key)
+            if ev is None:
+                ev = slot.h2d[key] = torch.cuda.Event()
+            ev.record(self.copy_stream)
         self.bytes_uploaded += host.numel() * host.element_size()
         return dev
 
@@ -136,9 +149,8 @@ class DeviceFeeder:
     # ------------------------------------------------------------------ iteration
     def __iter__(self):
         it = iter(self.loader)
-        slots = [_Slot() for _ in range(self.depth)]
         pending = collections.deque()
-        for s in slots:
+        for s in self._slots:
             b = next(it, None)
             if b is None:
                 break

@@ -168,6 +168,11 @@ class HipNet(torch.nn.Module):
             self._memo, self._memo_ver = {}, ver
         self._memo[key] = (x.detach(), out, saved)        # (detached alias: pins the storage, not the autograd graph)
 
+    def memo_clear(self):
+        """Drop every memo entry (the models call this at the start of each training step: an entry is valid only between
+        the stages of ONE step -- feeder slots are refilled by raw kernels that do not move the tensors' version counters)."""
+        self._memo = {}
+
     def replay_forward_side_effects(self, saved):
         """Hook: what a repeated training-mode forward would change besides its outputs (BatchNorm running statistics)."""
 

@@ -11,7 +11,7 @@ raise if enabled (they are off in the ESRGAN recipe and outside the hot path, SU
 import logging
 import os
 from collections import Counter, OrderedDict
-from contextlib import nullcontext
+from contextlib import contextmanager, nullcontext
 from shutil import copyfile
 
 import torch
@@ -24,6 +24,24 @@ from .losses import Adversarial
 from .networks import model_val
 
 logger = logging.getLogger("base")
+
+
+def training_step(fn):
+    """Decorator of the models' optimize_parameters: the step runs inside the AMP region (`use_amp`: bf16 matrix-core operands
+    for forward, losses and backward; validation stays fp32) and starts with empty forward memos -- a memo entry is only ever
+    valid between the generator stage and the discriminator stage of ONE step (engine.HipNet.memoize): buffers refilled by raw
+    kernels (DeviceFeeder slots) keep their torch version counter, so entries must not survive into a later batch."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, step, *a, **kw):
+        for name in self.model_names:
+            net = getattr(self, "net" + name, None)
+            if net is not None and hasattr(net, "memo_clear"):
+                net.memo_clear()
+        with self.amp_region():
+            return fn(self, step, *a, **kw)
+    return wrapped
 
 
 class LazyLog(OrderedDict):
@@ -300,13 +318,26 @@ class BaseModel:
         the VGG feature net) rounds its operands to bf16 on their way into v_mfma_f32_32x32x16_bf16 and accumulates in
         fp32; activations, master weights, BatchNorm, the losses, clip + Adam stay fp32.  bf16 has fp32's exponent
         range, so there is no loss scaling (no GradScaler state: the reference never saves it either, base_model.py:466).
-        The precision is process-wide (ops.MMA), like an autocast region around the whole step."""
+        Like the reference's autocast region the mode covers the TRAINING step only (`amp_region()` around forward / losses /
+        backward in optimize_parameters): test() / validation forwards run in the fp32 arithmetic (base_model.py:736-744,
+        sr_model.py:269-277)."""
         self.amp = bool(self.opt.get("use_amp"))
-        self.cast = nullcontext
+        self.cast = self.amp_region if self.amp else nullcontext
         self.amp_scaler = None
-        ops.MMA = hip.MMA_BF16 if self.amp else ops.FP32_MMA
         if self.amp:
             logger.info("AMP enabled: bf16 matrix-core operands, fp32 accumulation and master weights.")
+
+    @contextmanager
+    def amp_region(self):
+        """ops.MMA = bf16 operands inside, restored on exit (also when the step raises)."""
+        if not getattr(self, "amp", False):
+            yield
+            return
+        prev, ops.MMA = ops.MMA, hip.MMA_BF16
+        try:
+            yield
+        finally:
+            ops.MMA = prev
 
     def setup_cem(self):
         self.CEM = None
@@ -390,8 +421,8 @@ class BaseModel:
         """base_model.py:815-850: step only when the virtual batch is complete; G gets the clip."""
         if step % self.accumulations != 0:
             return
-        self._zero_frozen_grads(opt_flag)
         self._sync_gradients(opt_flag)
+        self._zero_frozen_grads(opt_flag)          # after the exchange: buckets of the frozen layers may still be in flight before it
         if opt_flag == "G":
             self.apply_gradclip()
         optimizer.step()

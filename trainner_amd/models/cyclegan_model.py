@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 from ..utils.image_pool import ImagePool
 from . import losses, networks
-from .base_model import BaseModel, LazyLog
+from .base_model import BaseModel, LazyLog, training_step
 
 logger = logging.getLogger("base")
 
@@ -127,6 +127,7 @@ class CycleGANModel(BaseModel):
         for k, v in self.log_dict_B.items():
             self.log_dict["{}_B".format(k)] = v
 
+    @training_step
     def optimize_parameters(self, step):
         eff_step = step / self.accumulations
         self.forward()

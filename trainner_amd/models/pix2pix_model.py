@@ -11,7 +11,7 @@ import logging
 from collections import OrderedDict
 
 from . import losses, networks
-from .base_model import BaseModel, LazyLog
+from .base_model import BaseModel, LazyLog, training_step
 
 logger = logging.getLogger("base")
 
@@ -77,6 +77,7 @@ class Pix2PixModel(BaseModel):
         self._arm_bucket_schedule([self.netG])
         self.calc_gradients(l_g_total)
 
+    @training_step
     def optimize_parameters(self, step):
         eff_step = step / self.accumulations
         self.forward()

@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 from . import losses, networks
-from .base_model import BaseModel, LazyLog
+from .base_model import BaseModel, LazyLog, training_step
 
 logger = logging.getLogger("base")
 
@@ -93,6 +93,7 @@ class SRModel(BaseModel):
         self._arm_bucket_schedule([self.netD], passes=2)   # D(fake) and D(real) both accumulate: buckets leave in the 2nd
         self.log_dict = self.backward_D_Basic(self.netD, self.var_ref, self.fake_H, self.log_dict)
 
+    @training_step
     def optimize_parameters(self, step):
         eff_step = step / self.accumulations
         if self.cri_gan:
