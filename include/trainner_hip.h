@@ -187,6 +187,18 @@ int tnr_im2col(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t k
 int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *stage0);
 int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,
                    uint32_t epoch, void *stream);
+/* The same five convolutions of a residual dense block (RRDBNet_arch.py:150-163: stage k reads channels [0, nf + 32 k) of ONE buffer
+ * and, except the last, writes the next 32 channels of it; 32, 32, 32, 32, 64 output channels) -- or of its gradient mirror -- as a
+ * SWEEP: TNR_MMA_BF16X3 only.  One workgroup keeps the accumulators of all 192 output channels of its 8 x 32 pixel tile in
+ * registers and reads every input channel chunk once per phase for all the stages that consume it, with the weights streamed
+ * pre-split (three bf16 planes) from `image`, which tnr_conv_sweep_pack builds from the stages' packed fp32 weights (d->wp) and
+ * which stays valid until those change.  tnr_conv_sweep_image_bytes returns 0 when the stages are not such a block (or an
+ * image's tiles exceed the co-resident workgroups): use tnr_conv_chain then.  ws / epoch as for tnr_conv_chain (same buffer,
+ * same counter).  Results are bit-identical to tnr_conv_chain / five tnr_conv_forward calls in TNR_MMA_BF16X3.            */
+int64_t tnr_conv_sweep_image_bytes(const tnr_conv_desc *stages, int32_t n);
+int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, void *stream);
+int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void *image, uint32_t *ws, int64_t ws_bytes, uint32_t epoch,
+                   void *stream);
 /* 3x3 s1 p1 convolution with Cout <= 4 on the vector ALUs (one thread = one pixel x 4 outputs): G's last conv
  * (RRDBNet_arch.py:44) and the data-gradients that end in the RGB image (VGG features[0], D's first conv).
  * y[c] = (sum + bias[c]) * alpha for c < Cout.  Weights: tnr_conv_thin_pack (dgrad = 0: forward of a layer with

@@ -18,6 +18,7 @@
 #include <stddef.h>
 #include "conv_body.h"
 #include "conv_epilogue.h"
+#include "conv_handoff.h"
 #ifdef TNR_CONV_DL_EXPERIMENT     /* tools/build_variant.py dl -DTNR_CONV_DL_EXPERIMENT: LDS-DMA staging experiment, conv_body_dl.h */
 #include "conv_body_dl.h"
 #include <cstdlib>
@@ -37,54 +38,6 @@ struct ChainK {
     int set;
     int wait_chunk[TNR_CHAIN_MAX];
     ConvK st[TNR_CHAIN_MAX];
-};
-
-struct ChainWait {
-    unsigned *progress;
-    unsigned need;
-    int n, ty, tx, tiles_x, tiles_y;
-    unsigned *err;
-    int *pend_tile;          // tile whose previous-stage output still has to be published (-1: none)
-    unsigned pend_value;
-    // Deferred publish: the stores of the previous stage were issued a whole MFMA phase ago; waiting for
-    // them here costs nothing, whereas waiting right after the epilogue would expose the full write burst.
-    __device__ __forceinline__ void drain() const {
-        if (*pend_tile >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __device__ __forceinline__ void publish() const {
-        if (*pend_tile >= 0) {
-            if (threadIdx.x == 0) __hip_atomic_store(progress + *pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *pend_tile = -1;
-        }
-    }
-    __device__ __forceinline__ void operator()() const {
-        if (*pend_tile >= 0) {   // a wait before chunk 2: our own previous stage must be visible first (no circular wait)
-            drain();
-            __syncthreads();
-            publish();
-        }
-        const int t = threadIdx.x;
-#ifdef TNR_ABL_NOWAIT          /* (ablation build: no neighbour polling; results invalid) */
-        if (t < 0) {
-#else
-        if (t < 9 && t != 4) {
-#endif
-            const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
-            if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) {
-                const unsigned *p = progress + ((size_t)n * tiles_y + yy) * tiles_x + xx;
-                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                // (int) difference: robust to the counter base wrapping around
-                while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {   // ~2 s: report instead of hanging the GPU
-                        *err = 1u;
-                        break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
 };
 
 // Stage s of the kernel-argument table, fetched with scalar loads: indexing the by-value struct with a
@@ -247,7 +200,7 @@ __device__ __forceinline__ void chain_x3w8_body(const ConvK a, const int cb, con
         if (row < rows) {
             tnr_f32x2 pc[3];
             tnr_split4_bf16x3(v, pc);
-            float *dst = base + row * ROW + 4 * ((q >> 1) ^ ((row >> 2) & 1)) + 2 * (q & 1);
+            float *dst = base + row * ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
             *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
             *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
             *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
@@ -261,7 +214,7 @@ __device__ __forceinline__ void chain_x3w8_body(const ConvK a, const int cb, con
     };
 
     const int apix0 = (wave * MT) * WT + li;                        // M-tile mi: + mi * WT
-    const int boff = li * ROW + 4 * (half ^ ((li >> 2) & 1));       // row t * 32 + li: bit 2 is that of li
+    const int boff = li * ROW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));       // row t * 32 + li: the swizzle bit is that of li
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -272,7 +225,7 @@ __device__ __forceinline__ void chain_x3w8_body(const ConvK a, const int cb, con
 #pragma unroll
         for (int mi = m0; mi < m1; ++mi) {
             const int pp = apix0 + mi * WT + (t / 3) * WT + (t % 3);
-            const float *src = s_in + pp * ROW + 4 * (half ^ ((pp >> 2) & 1));
+            const float *src = s_in + pp * ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) ca[mi][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
         }
@@ -404,8 +357,9 @@ int chain_capacity(int *out) {
 
 extern "C" int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *d) {
     if (d == nullptr) return 0;
-    const int64_t tiles = (int64_t)tnr_cdiv(d->Wo, CH_TW) * tnr_cdiv(d->Ho, CH_TH) * d->N;
-    // progress counters, per-CU arrival counters, 2 x 2 tile dispensers, the error word (last)
+    // progress counters (sized for the 8 x 32 tiles of tnr_conv_sweep, which shares the buffer: twice the 16 x 32 tiles of this
+    // kernel), per-CU arrival counters, 2 x 2 tile dispensers, the error word (ALWAYS the last word of the buffer)
+    const int64_t tiles = (int64_t)tnr_cdiv(d->Wo, CH_TW) * tnr_cdiv(d->Ho, 8) * d->N;
     return (tiles + CH_CU_KEYS + 4 + 1) * (int64_t)sizeof(uint32_t);
 }
 
@@ -421,9 +375,9 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     c.tiles_y = tnr_cdiv(d0.Ho, CH_TH);
     c.tiles = c.tiles_x * c.tiles_y * d0.N;
     c.progress = ws;
-    c.cu_ctr = ws + c.tiles;
+    c.cu_ctr = ws + (ws_bytes / 4 - 1 - 4 - CH_CU_KEYS);      // (behind the progress counters of either tile grid)
     c.tile_ctr = c.cu_ctr + CH_CU_KEYS;
-    c.err = c.tile_ctr + 4;
+    c.err = ws + ws_bytes / 4 - 1;
     c.set = (int)(epoch & 1u);
     c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
     for (int i = 0; i < n; ++i) {

@@ -1,0 +1,59 @@
+// Tile hand-off between workgroups INSIDE a launch (conv_chain.hip, conv_sweep.hip): per-tile progress counters, deferred publish.
+//
+// Protocol (tools/probes/flag_sync.hip): producer = system-coherent stores (sc0 sc1), s_waitcnt vmcnt(0), workgroup barrier, one relaxed
+// agent-scope store of the counter; consumer = relaxed agent-scope loads of the 8 neighbouring tiles' counters, workgroup barrier,
+// system-coherent loads.  No cache write-back / invalidate fences (they cost 4x a whole tile on this part).
+#pragma once
+#include "common.h"
+
+namespace {
+
+struct ChainWait {
+    unsigned *progress;
+    unsigned need;
+    int n, ty, tx, tiles_x, tiles_y;
+    unsigned *err;
+    int *pend_tile;          // tile whose previous-stage output still has to be published (-1: none)
+    unsigned pend_value;
+    // Deferred publish: the stores of the previous stage were issued a whole MFMA phase ago; waiting for
+    // them here costs nothing, whereas waiting right after the epilogue would expose the full write burst.
+    __device__ __forceinline__ void drain() const {
+        if (*pend_tile >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __device__ __forceinline__ void publish() const {
+        if (*pend_tile >= 0) {
+            if (threadIdx.x == 0) __hip_atomic_store(progress + *pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *pend_tile = -1;
+        }
+    }
+    __device__ __forceinline__ void operator()() const {
+        if (*pend_tile >= 0) {   // a wait before chunk 2: our own previous stage must be visible first (no circular wait)
+            drain();
+            __syncthreads();
+            publish();
+        }
+        const int t = threadIdx.x;
+#ifdef TNR_ABL_NOWAIT          /* (ablation build: no neighbour polling; results invalid) */
+        if (t < 0) {
+#else
+        if (t < 9 && t != 4) {
+#endif
+            const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
+            if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) {
+                const unsigned *p = progress + ((size_t)n * tiles_y + yy) * tiles_x + xx;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                // (int) difference: robust to the counter base wrapping around
+                while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {   // ~2 s: report instead of hanging the GPU
+                        *err = 1u;
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+};
+
+}  // namespace

@@ -1,0 +1,566 @@
+// A residual dense block's five growing-K 3x3 convolutions (RRDBNet_arch.py:150-163) -- or the five of its gradient mirror -- in ONE
+// launch, TNR_MMA_BF16X3 only, with every input channel chunk feeding ALL the stages that consume it ("sweep").
+//
+// Why (profiles/r03a_chain_timeline.txt): on the bf16x3 path conv_chain_kernel is bound by its memory traffic, not by the matrix core.
+// Stage k re-reads the 64 + 32 (k - 1) channels the stages before it already read (832 channel reads per pixel for 192 distinct
+// channels), a chunk's MFMA phase shrank to 6.9 k cycles per wave and the burst of next-chunk loads alone takes 6 k cycles to issue
+// (120 KB per CU per chunk round against ~10 B / cycle / CU of streaming bandwidth).  Here a workgroup keeps the accumulators of all
+// six 32-channel output groups of its tile (x1, x2, x3, x4 and the two halves of x5: 192 fp32 per pixel) in registers and sweeps the
+// input channels once per phase:
+//     phase 0 = channels of x      -> accumulate into x1 .. x5        phase 1 = channels of x1 -> x2 .. x5      ...
+//     phase 4 = channels of x4 -> x5
+// so an input element is read (and split into its three bf16 planes) at most twice instead of up to five times, an A fragment read
+// from LDS feeds up to 5 x 6 MFMAs instead of 6, and the weights arrive PRE-SPLIT from HBM (tnr_conv_sweep_pack builds the LDS image
+// once per optimiser step): no vector-ALU work in the MFMA phase, a pure copy on the weight path.
+//
+// Each phase runs as two passes.  Pass a computes ONLY the stage that completes in this phase (one output group), so that its epilogue
+// (bias / LeakyReLU / residuals / mask, system-coherent stores) is issued as early as possible; pass b sweeps the same channels again
+// for the remaining groups while those stores drain and the neighbouring tiles catch up -- the next phase's first chunk (this tile's
+// and its 8 neighbours' fresh output: 3x3 halo) is fetched during the last chunk of pass b.  Same hand-off protocol as conv_chain.hip
+// (conv_handoff.h).
+//
+// Geometry: one workgroup of 8 waves per CU; tile 8 x 32 pixels, wave w owns tile row w (one 32-pixel M-tile) x up to six N-tiles
+// (96 accumulator VGPRs); input chunk = 16 channels of the 10 x 34 halo tile as 96-byte rows of three bf16 planes (split once, by the
+// stager, double-buffered: 2 x 32.6 KB); weights stream through a two-slot ring of <= 12 units (unit = one tap x one N-tile x 16
+// channels = 32 rows x 96 B = 3 KB; 2 x 36 KB) in exactly the order the MFMA loop consumes them -- one workgroup barrier per slot.
+// Deadlock freedom: a round of the grid covers WHOLE images (dependencies never cross images) with one tile per workgroup, all
+// co-resident (grid <= CU count), so a waited-for tile always belongs to a running workgroup at an earlier program point.
+// Arithmetic (split, kept partial products and their order, channel and tap order, epilogue) is that of conv_tile_body<.., BF = 2>:
+// results are bit-identical to five tnr_conv_forward launches in TNR_MMA_BF16X3.
+#include <stddef.h>
+#include "conv_body.h"
+#include "conv_epilogue.h"
+#include "conv_handoff.h"
+
+namespace {
+
+constexpr int SW_TH = 8, SW_TW = 32, SW_HT = SW_TH + 2, SW_WT = SW_TW + 2;
+constexpr int SW_ROW = TNR_X3_ROW;                                  // floats per LDS row: three planes of 16 bf16
+constexpr int SW_A_ROWS = SW_HT * SW_WT;                            // 340 halo pixels
+constexpr int SW_A_FLOATS = SW_A_ROWS * SW_ROW;
+constexpr int SW_UNIT_FLOATS = 32 * SW_ROW;                         // one tap x one N-tile x 16 channels
+constexpr int SW_SLOT_UNITS = 9;
+constexpr int SW_SLOT_FLOATS = SW_SLOT_UNITS * SW_UNIT_FLOATS;
+constexpr int SW_RING = 3;                                          // weight slots in LDS: slot k + 2 is fetched while slot k is consumed
+constexpr size_t SW_LDS_BYTES = (size_t)(2 * SW_A_FLOATS + SW_RING * SW_SLOT_FLOATS) * sizeof(float);      // 148 224 B
+constexpr int SW_NPASS = 9, SW_NSTAGE = 5, SW_NTILE = 6;
+constexpr int SW_A_IT = (SW_A_ROWS * 4 + 511) / 512;                // staging items (float4) per thread and chunk: 3
+constexpr int SW_B_PIECES = (SW_SLOT_UNITS * 3 + 7) / 8;            // 1 KB LDS-DMA pieces per wave and slot: <= 4
+static_assert(SW_LDS_BYTES <= 160 * 1024, "one sweep workgroup per CU");
+
+// The plan.  N-tile j = output channels [32 j, 32 j + 32) of the block's 192 (x1, x2, x3, x4, x5 lo, x5 hi); phase f sweeps the input
+// channels that stage f - 1 produced (phase 0: the block input) into the N-tiles of stages >= f.  Pass p = 2 f (pass a: the N-tile
+// of the stage that completes in this phase first -- plus one more, so that a chunk carries enough MFMAs to cover the next chunk's
+// fetch) or 2 f + 1 (pass b: the remaining N-tiles, while the stores of pass a's epilogue drain and the neighbours catch up).
+//                                       pass:  0  1  2  3  4  5  6  7  8
+constexpr int SW_J0[SW_NPASS] =               { 0, 3, 1, 3, 2, 4, 3, 5, 4 };      // first N-tile
+constexpr int SW_NJ[SW_NPASS] =               { 3, 3, 2, 3, 2, 2, 2, 1, 2 };      // N-tiles
+constexpr int SW_TT[SW_NPASS] =               { 3, 3, 3, 3, 3, 3, 3, 9, 3 };      // taps per weight slot (T * NJ <= SW_SLOT_UNITS)
+__host__ __device__ constexpr int sw_phase(int p) { return p >> 1; }
+__host__ __device__ constexpr bool sw_apass(int p) { return (p & 1) == 0; }
+__host__ __device__ constexpr int sw_j0(int p) { return SW_J0[p]; }
+__host__ __device__ constexpr int sw_nj(int p) { return SW_NJ[p]; }
+__host__ __device__ constexpr int sw_T(int p) { return SW_TT[p]; }
+// (run-time p: arithmetic instead of a table in memory)
+__host__ __device__ constexpr int sw_nj_rt(int p) { return p == 7 ? 1 : ((p == 0 || p == 1 || p == 3) ? 3 : 2); }
+__host__ __device__ constexpr int sw_j0_rt(int p) { return p == 0 ? 0 : (p == 2 ? 1 : (p == 4 ? 2 : (p == 5 || p == 8 ? 4 : (p == 7 ? 5 : 3)))); }
+__host__ __device__ constexpr int sw_T_rt(int p) { return p == 7 ? 9 : 3; }
+constexpr bool sw_plan_ok() {
+    for (int p = 0; p < SW_NPASS; ++p) {
+        if (SW_TT[p] * SW_NJ[p] > SW_SLOT_UNITS || 9 % SW_TT[p]) return false;
+        if (sw_nj_rt(p) != SW_NJ[p] || sw_j0_rt(p) != SW_J0[p] || sw_T_rt(p) != SW_TT[p]) return false;
+        if (sw_apass(p) && SW_J0[p] != (sw_phase(p) < 4 ? sw_phase(p) : 4)) return false;           // pass a starts at the completing stage's N-tile
+        if (!sw_apass(p) && SW_J0[p] != SW_J0[p - 1] + SW_NJ[p - 1]) return false;                  // pass b continues where pass a stopped
+        if ((!sw_apass(p) || p == 8) && SW_J0[p] + SW_NJ[p] != SW_NTILE) return false;              // ... up to the last N-tile
+    }
+    return true;
+}
+
+static_assert(sw_plan_ok(), "sweep plan");
+static_assert(SW_J0[1] == SW_J0[3] && SW_NJ[1] == SW_NJ[3] && SW_TT[1] == SW_TT[3] && SW_J0[5] == SW_J0[8] && SW_NJ[5] == SW_NJ[8] && SW_TT[5] == SW_TT[8], "passes 1 / 3 and 5 / 8 share a body");
+
+struct SweepK {
+    int nck0;                          // chunks of phase 0 (channels of the block input / 16); the other phases have 2
+    int tiles_x, tiles_y, tpi, tiles;  // 8 x 32 pixel tiles; tpi = tiles per image
+    unsigned *progress;                // [tiles]: base + (stages of that tile whose output is visible)
+    unsigned base;
+    unsigned *err;
+    const float *wq;                   // pre-split weight stream (tnr_conv_sweep_pack)
+    int wq_bytes;
+    ConvK st[SW_NSTAGE];
+};
+
+__host__ __device__ inline int sw_nchunks(int p, int nck0) { return sw_phase(p) == 0 ? nck0 : 2; }
+__host__ __device__ inline int sw_ch_lo(int p, int nck0) { return sw_phase(p) == 0 ? 0 : 16 * nck0 + 32 * (sw_phase(p) - 1); }
+__host__ __device__ inline int sw_total_units(int nck0) {
+    int u = 0;
+    for (int p = 0; p < SW_NPASS; ++p) u += sw_nchunks(p, nck0) * 9 * sw_nj_rt(p);
+    return u;
+}
+
+// ---- weight stream: for every pass, chunk, tap and N-tile of the pass (in that order) one unit of 32 rows (output channels) x 96 B:
+// row r holds the three bf16 planes (hi, mid, lo) of input channels 16 c .. 16 c + 15, the 16-byte slot of channels 8 h .. 8 h + 7 of a
+// plane at slot h ^ ((r >> TNR_X3_SWZ) & 1) -- byte for byte the LDS image the MFMA loop reads.
+struct SweepPackK {
+    int nck0, units;
+    const float *wp[SW_NSTAGE];
+    int KinP[SW_NSTAGE], KoutP[SW_NSTAGE];
+    float *out;
+};
+
+__global__ void __launch_bounds__(256) sweep_pack_kernel(const SweepPackK a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int unit = g >> 6, r = (g >> 1) & 31, sp = g & 1;
+    if (unit >= a.units) return;
+    int p = 0, u0 = 0;
+    for (; p < SW_NPASS; ++p) {
+        const int n = sw_nchunks(p, a.nck0) * 9 * sw_nj_rt(p);
+        if (unit < u0 + n) break;
+        u0 += n;
+    }
+    const int lu = unit - u0, nj = sw_nj_rt(p);
+    const int jj = lu % nj, ct = lu / nj, tap = ct % 9, ck = ct / 9;
+    const int j = sw_j0_rt(p) + jj;
+    const int s = j < 4 ? j : 4, cb = j == 5 ? 1 : 0;
+    const int h = sp ^ ((r >> TNR_X3_SWZ) & 1);
+    const int ch = sw_ch_lo(p, a.nck0) + 16 * ck + 8 * h;
+    const float *src = a.wp[s] + ((size_t)tap * a.KoutP[s] + cb * 32 + r) * a.KinP[s] + ch;
+    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(src), q1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    tnr_bf16x8 pl[3];
+    tnr_split_bf16x3(q0, q1, pl);
+    float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + r * SW_ROW + 4 * sp;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + 8 * k) = pl[k];
+}
+
+// The N-tiles [J0, J0 + NJ) x T taps of one ring slot: (tap, N-tile) units in stream order, 6 MFMAs each.
+template <int J0, int NJ, int T>
+__device__ __forceinline__ void sweep_slot(f32x16 (&acc)[SW_NTILE], const float *s_a, const float *s_b_lane, const int apix0,
+                                           const int half, const int tap0) {
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // the six kept partial products, smallest first
+    tnr_bf16x8 fa[2][3], fb[2][3];
+    auto load_a = [&](int tap, int set) {
+        const int dy = tap / 3, dx = tap - 3 * dy;
+        const int pp = apix0 + dy * SW_WT + dx;
+        const float *src = s_a + pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) fa[set][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+    };
+    auto load_b = [&](int u, int set) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) fb[set][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_b_lane + u * SW_UNIT_FLOATS + 8 * sp);
+    };
+    load_a(tap0, 0);
+    load_b(0, 0);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int u = tt * NJ + jj;
+            // the fragments of the next unit are read before this unit's MFMAs issue (one register set each way)
+            if (jj == 0 && tt + 1 < T) load_a(tap0 + tt + 1, (tt + 1) & 1);
+            if (u + 1 < T * NJ) load_b(u + 1, (u + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+                acc[J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tt & 1][TA[p]], fb[u & 1][TB[p]], acc[J0 + jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Stage s of the kernel-argument table, fetched with scalar loads (indexing the by-value struct with a run-time s would make the
+// compiler copy all of it to scratch)
+__device__ __forceinline__ ConvK sweep_stage(int s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) SweepK karg_sweep;
+    karg_sweep *ka = (karg_sweep *)__builtin_amdgcn_kernarg_segment_ptr();   // constant address space: s_load
+    return ka->st[s];
+#else
+    return ConvK();
+#endif
+}
+
+// cursor over the weight stream's slots (wave-uniform)
+struct SweepCur {
+    int p, ck, sl, unit;
+    __device__ __forceinline__ bool valid() const { return p < SW_NPASS; }
+    __device__ __forceinline__ int pieces() const { return sw_T_rt(p) * sw_nj_rt(p) * 3; }      // 1 KB pieces of the slot
+    __device__ __forceinline__ void advance(int nck0) {
+        unit += sw_T_rt(p) * sw_nj_rt(p);
+        if (++sl * sw_T_rt(p) == 9) {
+            sl = 0;
+            if (++ck == sw_nchunks(p, nck0)) {
+                ck = 0;
+                ++p;
+            }
+        }
+    }
+};
+
+typedef __attribute__((address_space(3))) float sw_lds_float;
+
+#ifdef SW_TIMELINE   /* probe build (tools/build_variant.py sw_tl -DSW_TIMELINE): cycles wave 0 of every workgroup spends per part of the loop */
+__device__ unsigned long long sw_tl[16];
+#define SW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define SW_ADD(i, d) do { tl[i] += (d); } while (0)
+#else
+#define SW_T(v) do { } while (0)
+#define SW_ADD(i, d) do { } while (0)
+#endif
+
+// at most n vector-memory operations of this wave still in flight (n wave-uniform, 0 .. SW_B_PIECES)
+__device__ __forceinline__ void sw_wait_vm(int n) {
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+static_assert(SW_B_PIECES <= 4, "sw_wait_vm covers 0 .. 4");
+
+__global__ void __launch_bounds__(512, 1) conv_sweep_kernel(const SweepK c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_a = smem, *s_b = smem + 2 * SW_A_FLOATS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    // blocks b, b + 8, ... share an XCD (observed, speed only): give every XCD a contiguous run of tiles, i.e. whole image halves,
+    // so that the halo re-reads of neighbouring tiles meet in one L2
+    int b = blockIdx.x;
+    const int g = gridDim.x;
+    if ((g & 7) == 0) b = (b & 7) * (g >> 3) + (b >> 3);
+    const ConvK &x0 = c.st[0];
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x0.x), 0, (int)((unsigned)x0.N * x0.H * x0.W * x0.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.wq), 0, c.wq_bytes, 0x00020000);
+    sw_lds_float *ring = (sw_lds_float *)s_b;
+    const int apix0 = wave * SW_WT + li;
+    const float *s_b_lane = s_b + li * SW_ROW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));
+    int pend_tile = -1;          // tile whose newest stage output still has to be published (wave-uniform)
+    unsigned pend_value = 0;
+    int pend_age = 0;
+#ifdef SW_TIMELINE
+    unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_begin = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (int tile = b; tile < c.tiles; tile += g) {
+        SW_T(t_tile0);
+        const int n = tile / c.tpi, rem = tile - n * c.tpi;
+        const int ty = rem / c.tiles_x, tx = rem - ty * c.tiles_x;
+        const int ty0 = ty * SW_TH, tx0 = tx * SW_TW;
+        // ---- staging plan of the input tile: item i = tid + 512 it -> halo pixel i / 4, channel quad i % 4
+        int in_off[SW_A_IT], a_dst[SW_A_IT];
+#pragma unroll
+        for (int it = 0; it < SW_A_IT; ++it) {
+            const int i = tid + it * 512, row = i >> 2, q = i & 3;
+            const int hr = row / SW_WT, hc = row - hr * SW_WT;
+            const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            const bool in = (row < SW_A_ROWS) & (Y >= 0) & (Y < x0.H) & (X >= 0) & (X < x0.W);
+            in_off[it] = in ? (((n * x0.H + Y) * x0.W + X) * x0.x_ct + x0.x_co + q * 4) : -1;
+            a_dst[it] = row < SW_A_ROWS ? row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1) : -1;
+        }
+        f32x4 rin[SW_A_IT];
+        auto a_load = [&](int ch) {          // system-coherent: the channels may have been written by another CU in this launch
+#pragma unroll
+            for (int it = 0; it < SW_A_IT; ++it) {
+                const unsigned bo = in_off[it] >= 0 ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;      // (past the end: the range check returns 0)
+                rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
+            }
+        };
+        auto a_store = [&](int buf) {
+            float *base = s_a + buf * SW_A_FLOATS;
+#pragma unroll
+            for (int it = 0; it < SW_A_IT; ++it) {
+                if (a_dst[it] >= 0) {
+                    tnr_f32x2 pc[3];
+                    tnr_split4_bf16x3(rin[it], pc);
+                    float *dst = base + a_dst[it];
+                    *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+                }
+            }
+        };
+        // weights: LDS-DMA, no registers.  This wave's 1 KB pieces of a slot (piece q = bytes [1024 q, 1024 q + 1024) of the slot, dealt
+        // round-robin to the 8 waves); returns how many it issued.  The stream in HBM is the LDS image: a pure copy.
+        auto b_issue = [&](const SweepCur &cu, int slot) -> int {
+            const int pieces = cu.pieces();
+            const unsigned src0 = (unsigned)cu.unit * (unsigned)(SW_UNIT_FLOATS * 4) + (unsigned)lane * 16u;
+            sw_lds_float *dst = ring + slot * SW_SLOT_FLOATS;
+            int issued = 0;
+#pragma unroll
+            for (int i = 0; i < SW_B_PIECES; ++i) {
+                const int q = wave + 8 * i;
+                if (q < pieces) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + q * 256, 16, (int)(src0 + (unsigned)q * 1024u), 0, 0, 0);
+                    ++issued;
+                }
+            }
+            return issued;
+        };
+
+        f32x16 acc[SW_NTILE];
+#pragma unroll
+        for (int j = 0; j < SW_NTILE; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+        // ---- prologue: input chunk 0 into LDS, weight slots 0 and 1 on their way
+        SweepCur ld{0, 0, 0, 0};         // the next slot to fetch
+        a_load(0);
+        __syncthreads();                 // the previous tile's last fragments are consumed
+        b_issue(ld, 0);
+        ld.advance(c.nck0);
+        int n1 = b_issue(ld, 1);         // pieces of slot k + 1 this wave has in flight
+        ld.advance(c.nck0);
+        a_store(0);
+        { SW_T(t_pro); SW_ADD(0, t_pro - t_tile0); }
+        int k = 0, e = 0;                // slots / input chunks consumed so far in this tile
+
+        for (int p = 0; p < SW_NPASS; ++p) {
+            const int T = sw_T_rt(p);
+            const int nchunks = sw_nchunks(p, c.nck0), ch_lo = sw_ch_lo(p, c.nck0);
+            for (int ck = 0; ck < nchunks; ++ck) {
+                // the next input chunk goes into registers now and into the other LDS buffer after this chunk's last slot
+                const bool last_ck = ck + 1 == nchunks;
+                const bool has_next = !(last_ck && p == SW_NPASS - 1);
+                if (has_next) {
+                    int ch_next = ch_lo + 16 * (ck + 1);
+                    if (last_ck) {
+                        ch_next = sw_ch_lo(p + 1, c.nck0);
+                        if (sw_apass(p + 1)) {
+                            // the first chunk of the next phase is the output of the stage this tile and its 8 neighbours finished
+                            // in pass a of the current phase
+                            const ChainWait w{c.progress, c.base + (unsigned)sw_phase(p + 1), n, ty, tx, c.tiles_x, c.tiles_y, c.err,
+                                              &pend_tile, pend_value};
+#ifndef SW_ABL_NOWAIT
+                            SW_T(t_w0);
+                            w();
+                            { SW_T(t_w1); SW_ADD(1, t_w1 - t_w0); }
+#endif
+                        }
+                    }
+#ifndef SW_ABL_NOA
+                    SW_T(t_al0);
+                    a_load(ch_next);
+                    { SW_T(t_al1); SW_ADD(2, t_al1 - t_al0); }
+#endif
+                }
+                for (int sl = 0; sl * T < 9; ++sl) {
+                    // slot k must have landed: everything this wave issued before the pieces of slot k + 1 (vector-memory operations
+                    // complete in order; the deferred publish -- the newest stage's stores were issued at least two slots ago --
+                    // waits for all of them)
+                    const bool pub = pend_tile >= 0 && ++pend_age >= 3;
+                    SW_T(t_s0);
+                    sw_wait_vm(pub ? 0 : n1);
+                    SW_T(t_s1);
+                    __syncthreads();
+                    SW_T(t_s2);
+                    SW_ADD(3, t_s1 - t_s0);
+                    SW_ADD(4, t_s2 - t_s1);     // slot k is in LDS for every wave, slot k - 1 (= the buffer refilled below) is consumed
+                    if (pub) {
+                        if (tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pend_tile = -1;
+                    }
+                    n1 = 0;
+#ifndef SW_ABL_NOB          /* (ablation builds: timing only, results invalid) */
+                    if (ld.valid()) {
+                        n1 = b_issue(ld, (k + 2) % SW_RING);
+                        ld.advance(c.nck0);
+                    }
+#endif
+                    { SW_T(t_s3); SW_ADD(5, t_s3 - t_s2); }
+                    SW_T(t_c0);
+                    const float *sa = s_a + (e & 1) * SW_A_FLOATS, *sb = s_b_lane + (k % SW_RING) * SW_SLOT_FLOATS;
+                    const int tap0 = sl * T;
+                    switch (p) {         // (wave-uniform; one unrolled body per pass shape)
+                    case 0: sweep_slot<sw_j0(0), sw_nj(0), sw_T(0)>(acc, sa, sb, apix0, half, tap0); break;
+                    case 1: case 3: sweep_slot<sw_j0(1), sw_nj(1), sw_T(1)>(acc, sa, sb, apix0, half, tap0); break;
+                    case 2: sweep_slot<sw_j0(2), sw_nj(2), sw_T(2)>(acc, sa, sb, apix0, half, tap0); break;
+                    case 4: sweep_slot<sw_j0(4), sw_nj(4), sw_T(4)>(acc, sa, sb, apix0, half, tap0); break;
+                    case 6: sweep_slot<sw_j0(6), sw_nj(6), sw_T(6)>(acc, sa, sb, apix0, half, tap0); break;
+                    case 7: sweep_slot<sw_j0(7), sw_nj(7), sw_T(7)>(acc, sa, sb, apix0, half, tap0); break;
+                    default: sweep_slot<sw_j0(5), sw_nj(5), sw_T(5)>(acc, sa, sb, apix0, half, tap0); break;     // passes 5 and 8
+                    }
+                    { SW_T(t_c1); SW_ADD(6, t_c1 - t_c0); SW_ADD(15, 1ull); }
+                    ++k;
+                }
+#ifndef SW_ABL_NOA
+                SW_T(t_as0);
+                if (has_next) a_store((e + 1) & 1);
+                { SW_T(t_as1); SW_ADD(7, t_as1 - t_as0); }
+#endif
+                ++e;
+            }
+            SW_T(t_e0);
+            if (sw_apass(p)) {
+                // ---- this phase's stage is complete: epilogue straight from the accumulators (coherent stores), publish deferred
+                const int S = sw_phase(p);
+                const ConvK a = sweep_stage(S);
+                const __amdgpu_buffer_rsrc_t y_rs =
+                    __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+                if (pend_tile >= 0) {          // (only when a pass was too short for the deferred publish: keep the counters in order)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend_tile = -1;
+                }
+#ifdef SW_ABL_NOEPI
+                if (a.alpha == 1.2345e30f)
+#endif
+                if (S < 4) {
+                    f32x16 t[1][1];
+                    switch (S) {
+                    case 0: t[0][0] = acc[0]; break;
+                    case 1: t[0][0] = acc[1]; break;
+                    case 2: t[0][0] = acc[2]; break;
+                    default: t[0][0] = acc[3]; break;
+                    }
+                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 1, true>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
+                } else {
+                    f32x16 t[1][2];
+                    t[0][0] = acc[4];
+                    t[0][1] = acc[5];
+                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 1, true>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
+                }
+                pend_tile = tile;
+                pend_value = c.base + (unsigned)S + 1u;
+                pend_age = 0;
+                { SW_T(t_e1); SW_ADD(8, t_e1 - t_e0); }
+            }
+        }
+    }
+    // nothing in this launch waits for the last stage; publish it anyway so the counters stay consistent
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pend_tile >= 0 && tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SW_TIMELINE
+    if (tid == 0) {
+        tl[14] = __builtin_amdgcn_s_memtime() - tl_begin;
+        for (int i = 0; i < 16; ++i) atomicAdd(&sw_tl[i], tl[i]);
+    }
+#endif
+}
+
+// Do the stages form a dense block the sweep kernel covers?  (5 stages over ONE input buffer, stage k reading channels [0, nf + 32 k)
+// and -- except the last -- writing the next 32 channels of that buffer; 32, 32, 32, 32, 64 output channels)
+bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
+    auto no = [&](const char *w) { if (why) *why = w; return false; };
+    if (n != SW_NSTAGE) return no("not 5 stages");
+    const tnr_conv_desc &d0 = st[0];
+    if (d0.Cin < 32 || (d0.Cin % 16) != 0) return no("block input channels must be a multiple of 16, >= 32");
+    for (int i = 0; i < n; ++i) {
+        const tnr_conv_desc &d = st[i];
+        if (d.mode != TNR_CONV_3x3 || d.mma != TNR_MMA_BF16X3 || d.pad_mode != 0) return no("stage is not a zero-padded 3x3 in bf16x3");
+        if (d.N != d0.N || d.H != d0.H || d.W != d0.W || d.Ho != d0.H || d.Wo != d0.W) return no("pixel grids differ");
+        if (d.x.ptr != d0.x.ptr || d.x.ctot != d0.x.ctot || d.x.coff != d0.x.coff) return no("stages read different buffers");
+        if (d.Cin != d0.Cin + 32 * i || d.KinP != d.Cin) return no("input channels do not grow by 32 per stage");
+        if (d.Cout != (i < 4 ? 32 : 64) || d.KoutP != d.Cout) return no("output channels are not 32, 32, 32, 32, 64");
+        if (i < 4 && (d.y.ptr != d0.x.ptr || d.y.ctot != d0.x.ctot || d.y.coff != d0.x.coff + d.Cin)) return no("stage output is not the next channel group");
+        if ((d.x.ctot % 4) || (d.x.coff % 4) || (d.y.ctot % 4) || (d.y.coff % 4)) return no("views must be 4-channel aligned");
+        if (d.r1.ptr && ((d.r1.ctot % 4) || (d.r1.coff % 4) || (d.r1_ch % 4))) return no("r1 view");
+        if (d.r2.ptr && ((d.r2.ctot % 4) || (d.r2.coff % 4))) return no("r2 view");
+        if (d.m.ptr && ((d.m.ctot % 4) || (d.m.coff % 4) || (d.m_lo % 4) || (d.m_hi % 4))) return no("mask view");
+        if ((int64_t)d.N * d.H * d.W * d.x.ctot >= (1LL << 30) || (int64_t)d.N * d.H * d.W * d.y.ctot >= (1LL << 30)) return no("buffer above 4 GiB");
+        if (!d.x.ptr || !d.y.ptr || !d.wp) return no("null pointer");
+    }
+    const tnr_conv_desc &dl = st[n - 1];
+    if (dl.y.ptr == d0.x.ptr && dl.y.coff < d0.x.coff + dl.Cin && dl.y.coff + dl.Cout > d0.x.coff) return no("last stage overwrites its own input");
+    return true;
+}
+
+int sweep_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SW_LDS_BYTES) != hipSuccess || cus < 1)
+            cus = -1;
+    }
+    return cus;
+}
+
+}  // namespace
+
+#ifdef SW_TIMELINE
+extern "C" int tnr_debug_sweep_timeline(unsigned long long *out16, int reset) {
+    if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(sw_tl), sizeof(sw_tl)) != hipSuccess) return TNR_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sw_tl), z, sizeof(z)) != hipSuccess) return TNR_ELAUNCH;
+    }
+    return TNR_OK;
+}
+#endif
+
+extern "C" int64_t tnr_conv_sweep_image_bytes(const tnr_conv_desc *stages, int32_t n) {
+    if (stages == nullptr || !sweep_pattern(stages, n, nullptr)) return 0;
+    const int cus = sweep_cus();
+    const int tpi = tnr_cdiv(stages[0].W, SW_TW) * tnr_cdiv(stages[0].H, SW_TH);
+    if (cus < 1 || tpi > cus) return 0;          // an image's tiles must be co-resident (one workgroup per CU)
+    return (int64_t)sw_total_units(stages[0].Cin / 16) * SW_UNIT_FLOATS * (int64_t)sizeof(float);
+}
+
+extern "C" int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, void *stream) {
+    const char *why = "";
+    TNR_REQUIRE(stages != nullptr && image != nullptr && sweep_pattern(stages, n, &why), "conv_sweep_pack: not a sweepable dense block (%s)", why);
+    SweepPackK a;
+    a.nck0 = stages[0].Cin / 16;
+    a.units = sw_total_units(a.nck0);
+    TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_sweep_pack: image buffer too small");
+    for (int i = 0; i < SW_NSTAGE; ++i) {
+        a.wp[i] = stages[i].wp;
+        a.KinP[i] = stages[i].KinP;
+        a.KoutP[i] = stages[i].KoutP;
+    }
+    a.out = static_cast<float *>(image);
+    hipLaunchKernelGGL(sweep_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return tnr_check_launch("conv_sweep_pack");
+}
+
+extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void *image, uint32_t *ws, int64_t ws_bytes, uint32_t epoch,
+                              void *stream) {
+    const char *why = "";
+    TNR_REQUIRE(stages != nullptr && image != nullptr && ws != nullptr && sweep_pattern(stages, n, &why),
+                "conv_sweep: not a sweepable dense block (%s)", why);
+    const tnr_conv_desc &d0 = stages[0];
+    TNR_REQUIRE(tnr_conv_chain_workspace_bytes(&d0) <= ws_bytes, "conv_sweep: workspace too small");
+    const int cus = sweep_cus();
+    TNR_REQUIRE(cus >= 1, "conv_sweep: cannot set up the kernel");
+    SweepK c;
+    c.nck0 = d0.Cin / 16;
+    c.tiles_x = tnr_cdiv(d0.W, SW_TW);
+    c.tiles_y = tnr_cdiv(d0.H, SW_TH);
+    c.tpi = c.tiles_x * c.tiles_y;
+    c.tiles = c.tpi * d0.N;
+    TNR_REQUIRE(c.tpi <= cus, "conv_sweep: the %d tiles of an image exceed the %d co-resident workgroups", c.tpi, cus);
+    c.progress = ws;
+    c.err = ws + ws_bytes / 4 - 1;
+    c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
+    c.wq = static_cast<const float *>(image);
+    c.wq_bytes = sw_total_units(c.nck0) * SW_UNIT_FLOATS * (int)sizeof(float);
+    for (int i = 0; i < SW_NSTAGE; ++i) {
+        const tnr_conv_desc *d = &stages[i];
+        ConvK &k = c.st[i];
+        k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
+        k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+        k.wp = d->wp; k.KinP = d->KinP; k.KoutP = d->KoutP;
+        k.y = d->y.ptr; k.y_ct = d->y.ctot; k.y_co = d->y.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+        k.bias = d->bias; k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+        k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
+        k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
+        k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+        k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
+        k.th_space = d->Ho; k.tw_space = d->Wo;
+        k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = 0;
+    }
+    // whole images per round of the grid, one tile per workgroup and round
+    const int per_round = (cus / c.tpi) * c.tpi;
+    const int grid = c.tiles < per_round ? c.tiles : per_round;
+    hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
+    return tnr_check_launch("conv_sweep");
+}

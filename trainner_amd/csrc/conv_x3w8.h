@@ -74,13 +74,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3_x3w8_kernel(const ConvK a) {
             rw[it] = v;
         }
     };
-    // row r of either operand: plane P at float 8 P, the 16-byte slot of channels 8 h .. 8 h + 7 at slot h ^ ((r >> 2) & 1)
+    // row r of either operand: plane P at float 8 P, the 16-byte slot of channels 8 h .. 8 h + 7 at slot h ^ ((r >> TNR_X3_SWZ) & 1)
     auto store_item = [&](float *base, int i, int rows, const f32x4 v) {
         const int row = i >> 2, q = i & 3;
         if (row < rows) {
             tnr_f32x2 pc[3];
             tnr_split4_bf16x3(v, pc);
-            float *dst = base + row * ROW + 4 * ((q >> 1) ^ ((row >> 2) & 1)) + 2 * (q & 1);
+            float *dst = base + row * ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
             *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
             *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
             *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_x3w8_kernel(const ConvK a) {
     int apix[MT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) apix[mi] = (wave * MT + mi) * WT + li;
-    const int boff = li * ROW + 4 * (half ^ ((li >> 2) & 1));      // row t * 64 + nn * 32 + li: bit 2 is that of li
+    const int boff = li * ROW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));      // row t * 64 + nn * 32 + li: the swizzle bit is that of li
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_x3w8_kernel(const ConvK a) {
     tnr_bf16x8 ca[MT][3], cb_[2][NT][3];
     auto load_a = [&](int t, int mi) {
         const int pp = apix[mi] + (t / 3) * WT + (t % 3);
-        const float *src = s_in + pp * ROW + 4 * (half ^ ((pp >> 2) & 1));
+        const float *src = s_in + pp * ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) ca[mi][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
     };

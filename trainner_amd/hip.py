@@ -74,6 +74,9 @@ _SIGS = {
     "tnr_im2col": (c_i, [CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "tnr_conv_chain_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
     "tnr_conv_chain": (c_i, [C.POINTER(ConvDesc), C.POINTER(C.c_int32), c_i, c_p, c_l, C.c_uint32, c_p]),
+    "tnr_conv_sweep_image_bytes": (c_l, [C.POINTER(ConvDesc), c_i]),
+    "tnr_conv_sweep_pack": (c_i, [C.POINTER(ConvDesc), c_i, c_p, c_l, c_p]),
+    "tnr_conv_sweep": (c_i, [C.POINTER(ConvDesc), c_i, c_p, c_p, c_l, C.c_uint32, c_p]),
     "tnr_conv_thin_pack_floats": (c_l, [c_i]),
     "tnr_conv_thin_pack": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "tnr_conv_thin": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_p, c_f, c_p]),

@@ -79,10 +79,11 @@ WS = _Workspaces()
 # weight packing
 # ----------------------------------------------------------------------------------------------
 class Packed:
-    __slots__ = ("t", "KoutP", "KinP", "kind")
+    """A packed weight slab; `owner` = the packer whose run() rewrites it (owner.gen counts those runs), None for one-off packs."""
+    __slots__ = ("t", "KoutP", "KinP", "kind", "owner")
 
-    def __init__(self, t, KoutP, KinP, kind):
-        self.t, self.KoutP, self.KinP, self.kind = t, KoutP, KinP, kind
+    def __init__(self, t, KoutP, KinP, kind, owner=None):
+        self.t, self.KoutP, self.KinP, self.kind, self.owner = t, KoutP, KinP, kind, owner
 
 
 def pack_dims(Cout, Cin, kh, kw, kind):
@@ -103,6 +104,7 @@ class WeightPacker:
         self.table = None
         self.max_out = 0
         self.flat = None
+        self.gen = 0            # completed run() calls (consumers of derived layouts -- the sweep images -- compare it)
 
     def add(self, w, kind):
         Cout, Cin, kh, kw = w.shape
@@ -113,6 +115,7 @@ class WeightPacker:
         return len(self.jobs) - 1
 
     def _finalize(self):
+        self.__dict__.pop("_sweep_images", None)       # derived layouts of the old slabs
         total = sum(round_up(j[4], 64) for j in self.jobs)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
         items = (PackItem * len(self.jobs))()
@@ -122,7 +125,7 @@ class WeightPacker:
             off += round_up(n, 64)
             Cout, Cin, kh, kw = w.shape
             items[i] = PackItem(w.data_ptr(), seg.data_ptr(), Cout, Cin, kh, kw, kind, ko, ki, n)
-            self.packed[i] = Packed(seg, ko, ki, kind)
+            self.packed[i] = Packed(seg, ko, ki, kind, self)
             self.max_out = max(self.max_out, n)
         raw = bytes(items)
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
@@ -140,6 +143,7 @@ class WeightPacker:
             self._finalize()
         hip.check(hip.load().tnr_pack_weights(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
                   "pack_weights")
+        self.gen += 1
 
 
 class DensePacker:
@@ -152,6 +156,7 @@ class DensePacker:
         self.packed = []
         self.table = None
         self.max_out = 0
+        self.gen = 0
 
     def add_block(self, weights, nf, gc, scale5):
         """-> list of 5 job indices (t = 0..4)."""
@@ -167,6 +172,7 @@ class DensePacker:
         return idx
 
     def _finalize(self):
+        self.__dict__.pop("_sweep_images", None)
         total = sum(round_up(j[7], 64) for j in self.jobs)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
         items = (DensePackItem * len(self.jobs))()
@@ -179,7 +185,7 @@ class DensePacker:
                 it.w[k] = ws[k].data_ptr()
             it.wp, it.nf, it.gc, it.t, it.KoutP, it.KinP, it.scale5, it.n_out = seg.data_ptr(), nf, gc, t, ko, ki, sc, n
             items[i] = it
-            self.packed[i] = Packed(seg, ko, ki, PACK_DENSE_DGRAD)
+            self.packed[i] = Packed(seg, ko, ki, PACK_DENSE_DGRAD, self)
             self.max_out = max(self.max_out, n)
         self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
         self._ptrs = [w.data_ptr() for j in self.jobs for w in j[0]]
@@ -196,6 +202,7 @@ class DensePacker:
             self._finalize()
         hip.check(hip.load().tnr_pack_dense_dgrad(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
                   "pack_dense_dgrad")
+        self.gen += 1
 
 
 # ----------------------------------------------------------------------------------------------
@@ -289,16 +296,43 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
 CHAIN_MAX = 6
 CHAIN_X3 = os.environ.get("TNR_CHAIN_X3", "1") == "1"   # TNR_MMA=bf16x3 also inside tnr_conv_chain (A/B switch)
 CONV_CHAIN = os.environ.get("TNR_CONV_CHAIN", "1") != "0"     # 0: one launch per layer (A/B switch)
+CONV_SWEEP = os.environ.get("TNR_CONV_SWEEP", "1") != "0"     # TNR_MMA=bf16x3: dense blocks through tnr_conv_sweep (0: tnr_conv_chain; A/B switch)
 COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket handed to RCCL on the side stream until the compute
                                 # stream has waited for all of them: a chain launch needs every workgroup of its grid
                                 # co-resident, which RCCL kernels sharing the CUs could delay -> one launch per layer meanwhile
 _chain_epoch = {}
+_sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
+
+
+def _sweep_image(lib, descs, n, stages, dev):
+    """The pre-split weight stream of a dense block for tnr_conv_sweep (None: not sweepable).  Kept on the packer that owns the
+    block's packed weights and rebuilt (one small launch) when that packer has run since -- once per optimiser step."""
+    need = lib.tnr_conv_sweep_image_bytes(descs, n)
+    if need <= 0:
+        return None
+    owner = stages[0]["wp"].owner
+    if owner is None or any(st["wp"].owner is not owner for st in stages):
+        owner = None
+        cache, gen = _sweep_images, None               # one-off packs: rebuilt on every call
+    else:
+        cache = owner.__dict__.setdefault("_sweep_images", {})
+        gen = owner.gen
+    key = tuple(st["wp"].t.data_ptr() for st in stages)
+    ent = cache.get(key)
+    if ent is None or ent[0].numel() * 4 < need:
+        ent = cache[key] = [torch.empty(need // 4, dtype=torch.float32, device=dev), None]
+    if gen is None or ent[1] != gen:
+        hip.check(lib.tnr_conv_sweep_pack(descs, n, ent[0].data_ptr(), need, hip.stream()), "conv_sweep_pack")
+        ent[1] = gen
+    return ent[0]
 
 
 def conv_chain(stages):
     """Dependent 3x3 convolutions over one pixel grid in one launch (tnr_conv_chain).  stages: dicts with the
     arguments of conv() (x, wp, y, bias, act, ..., mask) plus fresh_from: first input channel produced by the
-    previous stage of this chain (None for the first stage).  Same results as calling conv() per stage."""
+    previous stage of this chain (None for the first stage).  Same results as calling conv() per stage.
+    In TNR_MMA_BF16X3 a residual dense block (or its gradient mirror) goes through tnr_conv_sweep instead: every input channel
+    chunk read once per phase for all the stages that consume it, weights streamed pre-split (csrc/conv_sweep.hip)."""
     n = len(stages)
     assert 1 <= n <= CHAIN_MAX
     eligible = all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages)
@@ -330,8 +364,14 @@ def conv_chain(stages):
     if _chain_epoch[key] > 0x0FFFFFF0:                 # epoch wrap: stale counters would compare as already satisfied
         fill(ws[:-1].view(torch.float32), 0.0)         # (stream-ordered after every earlier launch on this stream)
         _chain_epoch[key] = 1
+    image = None
+    if CONV_SWEEP and n == 5 and descs[0].mma == hip.MMA_BF16X3:
+        image = _sweep_image(lib, descs, n, stages, dev)
     t0 = PROFILE.begin() if PROFILE is not None else None
-    hip.check(lib.tnr_conv_chain(descs, fresh, n, ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_chain")
+    if image is not None:
+        hip.check(lib.tnr_conv_sweep(descs, n, image.data_ptr(), ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_sweep")
+    else:
+        hip.check(lib.tnr_conv_chain(descs, fresh, n, ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_chain")
     if PROFILE is not None:
         x0, yl = stages[0]["x"], stages[-1]["y"]
         PROFILE.end("conv_chain", flops, t0, (x0.C, yl.C, yl.H, stages[0]["wp"].kind))
