@@ -7,16 +7,19 @@ process is one rank; a plain `python bench.py --gpus N` re-launches itself under
 for the C ABI, tiny shapes): a plumbing check whose JSON line is marked invalid -- never a measurement.
 
 Workload = BASELINE.json configs[1]: RRDBNet-23 + Discriminator_VGG(512) + VGG19->conv5_4, batch 16
-per GPU (weak scaling), L1 + perceptual + relativistic GAN, clip + Adam -- fp32 on the matrix cores.
+per GPU (weak scaling), L1 + perceptual + relativistic GAN, clip + Adam -- fp32 arithmetic on the matrix cores: by default the
+split-operand form (`--mma bf16x3`: every fp32 operand split exactly into three bf16 values, six of the nine exact partial products on
+the bf16 matrix core, fp32 accumulate; error against fp64 at or below the fp32 matrix-core instruction's), with the same step on
+v_mfma_f32_32x32x2_f32 measured in the same process as `variant_f32_mfma`.
 Synthetic HR in [0,1), LR = avg_pool(HR, 4), resident in HBM before the timed region; random-init
 (kaiming x0.1) G/D and seeded VGG weights (no network access).  One JSON line on rank 0, with
   roofline     : the dominant kernel family (3x3 implicit-GEMM, forward + data-gradient launches),
                  algorithmic FLOP of every launch / HIP-event time of that launch, both summed over a
                  separate instrumented pass of the same steps (events on the launch stream);
-  cpu_baseline : the CPU oracle (a port of the reference step) on this host's cores, batch 1, same
-                 shapes (N=1 runs only); `reference` inside it = the reference's OWN SRModel timed in the build
-                 container (profiles/*_cpu_reference.json, oracle/time_reference.py) -- the GPU box has no
-                 /root/reference.
+  cpu_baseline : the CPU oracle (a port of the reference step) on this host's cores, by BASELINE.md section 2's protocol (batch 2,
+                 1 warm-up + 3 timed steps, same shapes; N=1 runs only);
+  cpu_reference: the reference's OWN SRModel timed by the same protocol in the build container (profiles/*_cpu_reference.json,
+                 oracle/time_reference.py) -- the GPU box has no /root/reference.
 The GPU result is also written to stderr as `BENCH_GPU_LINE {...}` before the CPU leg starts, so a timeout in the
 CPU leg cannot lose it; stdout carries exactly one JSON line.
 """
@@ -36,10 +39,19 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16, dense: 256 CU x 4 SIMD x 32768 FLOP / 32 cycles x 2.4 GHz
+# fp32 arithmetic on the bf16 matrix core (bf16x3): six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles) do the work of eight
+# v_mfma_f32_32x32x2_f32 (8 x 64 cycles) per 32 x 32 x 16 block -> fp32-equivalent ceiling = bf16 peak / 6 (2.67 x the fp32 pipe)
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 FLOP_PER_IMG = 3.0327e12           # full optimize_parameters, fp32, 128->512 (the reference's schedule)
 D_FWD_FLOP_PER_IMG = 7.34e10       # one Discriminator_VGG(512) forward (the D rows / 4 calls)
 BATCH_PER_GPU = 16
 CROP = 512
+MMA_TEXT = {
+    "bf16x3": "fp32 arithmetic on the bf16 matrix core: every fp32 operand split exactly into 3 bf16 values (hi + mid + lo = x), 6 of the 9 "
+              "exact partial products in v_mfma_f32_32x32x16_bf16, fp32 accumulate (convolutions, dense-block sweeps, data- and "
+              "weight-gradients); error vs fp64 at or below the fp32 matrix-core instruction's (tests/test_gpu_kernels.py)",
+    "f32": "fp32 matrix core (v_mfma_f32_32x32x2_f32)",
+}
 
 YAML = """
 name: bench_esrgan
@@ -164,8 +176,9 @@ def cpu_reference_record():
         return None
 
 
-def cpu_baseline(crop, steps=2):
-    """The reference step as ported in oracle/sr_oracle.py, timed on this host's cores (batch 1)."""
+def cpu_baseline(crop, steps=3, batch=2):
+    """The reference step as ported in oracle/sr_oracle.py, timed on this host's cores by BASELINE.md section 2's protocol:
+    batch 2 (reported per image), 1 warm-up + >= 3 timed steps."""
     from oracle import detrand, sr_oracle as O
     from trainner_amd.models.modules.architectures import RRDBNet_arch, discriminators
     cores = min(os.cpu_count() or 1, 64)       # more threads than this only slow torch's CPU convs down
@@ -175,16 +188,19 @@ def cpu_baseline(crop, steps=2):
     detrand.fill_state_dict_(g, 101, gain=0.1)
     detrand.fill_state_dict_(d, 202, gain=0.1)
     orc = O.OracleSRStep(g, d, O.vgg19_seeded_state(), arch="rrdb_net", nb=23, d_size=crop, d_nf=64)
-    LR, HR = detrand.synthetic_pair(1, crop, 7)
+    LR, HR = detrand.synthetic_pair(batch, crop, 7)
     orc.step(LR, HR)                                # warm-up
-    t0 = time.time()
+    times = []
     for _ in range(steps):
+        t0 = time.time()
         orc.step(LR, HR)
-    dt = (time.time() - t0) / steps
-    return {"value": round(1.0 / dt, 4), "unit": "HR img/s", "cores": cores, "kind": "port",
+        times.append(time.time() - t0)
+    dt = sum(times) / steps
+    return {"value": round(batch / dt, 4), "unit": "HR img/s", "cores": cores, "kind": "port",
+            "s_per_step": round(dt, 3), "step_times_s": [round(t, 3) for t in times],
             "sample": "oracle/sr_oracle.py OracleSRStep (port of SRModel.optimize_parameters), ESRGAN RRDBNet-23 + "
-                      "D_VGG(%d) + VGG19, batch 1, 128->%d, fp32, 1 warm-up + %d timed steps" % (crop, crop, steps),
-            "reference": cpu_reference_record()}
+                      "D_VGG(%d) + VGG19, batch %d, %d->%d, fp32, 1 warm-up + %d timed steps (BASELINE.md section 2)"
+                      % (crop, batch, crop // 4, crop, steps)}
 
 
 def pmc_traffic(family="conv_tile_3x3"):
@@ -204,6 +220,21 @@ def pmc_traffic(family="conv_tile_3x3"):
             return (round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None), src
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def pmc_mfma_busy(family, mode):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD) of the dominant kernel family from the newest committed
+    rocprofv3 --pmc summary of this command in this matrix-core mode (profiles/*_pmc_mfma_busy_<mode>.json, tools/pmc_busy.py), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma_busy_%s.json" % mode)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as fh:
+            e = json.load(fh).get(family)
+        return None if e is None else {"value": e["mfma_busy"], "source": os.path.relpath(files[-1], ROOT)}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def self_launch(args):
@@ -239,10 +270,10 @@ def main():
     ap.add_argument("--amp", action="store_true",
                     help="variant: `use_amp: true` = bf16 matrix-core operands, fp32 accumulate (reported as dtype bf16 with its own "
                          "roofline; the headline run is fp32)")
-    ap.add_argument("--mma", choices=["f32", "bf16x3"], default=os.environ.get("TNR_MMA", "f32"),
-                    help="fp32 arithmetic of the per-layer convolution kernels: f32 = v_mfma_f32_32x32x2_f32 (headline); bf16x3 = operands "
-                         "split exactly into three bf16 values, six partial products on the bf16 matrix core, fp32 accumulate (variant)")
-    ap.add_argument("--no-variant", action="store_true", help="skip the second (bf16x3) measurement")
+    ap.add_argument("--mma", choices=["f32", "bf16x3"], default=os.environ.get("TNR_MMA", "bf16x3"),
+                    help="fp32 arithmetic of the matrix-core kernels: bf16x3 (default, headline) = operands split exactly into three bf16 "
+                         "values, six partial products on the bf16 matrix core, fp32 accumulate; f32 = v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--no-variant", action="store_true", help="skip the second measurement (the other fp32 arithmetic)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
@@ -345,10 +376,16 @@ def main():
             kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
                      "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
             traffic, traffic_src = pmc_traffic(fam)
-            peak = PEAK_BF16_MFMA_TFLOPS if args.amp else PEAK_F32_MFMA_TFLOPS
+            peak = PEAK_BF16_MFMA_TFLOPS if args.amp else (PEAK_BF16X3_TFLOPS if args.mma == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
+            if fam == "conv_chain" and args.mma == "bf16x3" and not args.amp and ops.CONV_SWEEP:
+                kname = "conv_sweep_kernel (a dense block's 5 convolutions per launch, forward and data-gradient; bf16x3)"
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(tf / peak, 4), "peak_note": (
+                        "fp32-equivalent: bf16 dense peak 2516.6 / 6 MFMAs per fp32-equivalent block" if peak == PEAK_BF16X3_TFLOPS else
+                        "v_mfma_f32_32x32x16_bf16 dense" if args.amp else "v_mfma_f32_32x32x2_f32 dense"),
+                    "mfma_busy": pmc_mfma_busy(fam, args.mma if not args.amp else "amp"),
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
@@ -363,13 +400,13 @@ def main():
                              "mfma_view": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
                              "traffic_source": (traffic_src or "") + " -- fp32 run; bf16 operand mode moves the same bytes"})
 
-    # second measurement in the same process: the same step with TNR_MMA_BF16X3 (fp32 operands split exactly into three bf16
-    # values, six exact partial products per multiply on the bf16 matrix core, fp32 accumulate -- error against fp64 not above
-    # the fp32 matrix-core kernels', tests/test_gpu_kernels.py::test_bf16x3_split_operand_mode).  Reported beside the headline,
-    # which stays on v_mfma_f32_32x32x2_f32.  (1 GPU only: the N > 1 runs are the scaling measurement and carry nothing extra.)
-    variant = None
-    if world == 1 and not args.amp and args.mma == "f32" and not args.no_variant and not args.no_roofline and feeder is None and not dry:
-        ops.MMA = ops.FP32_MMA = hip.MMA_BF16X3
+    # second measurement in the same process: the same step in the OTHER fp32 arithmetic (headline bf16x3 -> v_mfma_f32_32x32x2_f32 and
+    # vice versa).  (1 GPU only: the N > 1 runs are the scaling measurement and carry nothing extra.)
+    variant, variant_key = None, None
+    if world == 1 and not args.amp and not args.no_variant and not args.no_roofline and feeder is None and not dry:
+        other = "f32" if args.mma == "bf16x3" else "bf16x3"
+        code = {"f32": hip.MMA_F32, "bf16x3": hip.MMA_BF16X3}
+        ops.MMA = ops.FP32_MMA = code[other]
         for _ in range(2):
             step += 1
             model.feed_data(data)
@@ -382,17 +419,14 @@ def main():
             model.optimize_parameters(step)
         barrier()
         dtv = time.perf_counter() - tv
-        if world > 1:
-            t = torch.tensor([dtv], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dtv = float(t.item())
-        ops.MMA = ops.FP32_MMA = hip.MMA_F32
+        ops.MMA = ops.FP32_MMA = code[args.mma]
         if ops.chain_error_flag():
             raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
-        variant = {"mma": "bf16x3: fp32 operands split exactly into 3 bf16 values, 6 of 9 exact partial products on the bf16 matrix "
-                          "core, fp32 accumulate (convolutions, data- and weight-gradients); same step, same process",
+        variant_key = "variant_f32_mfma" if other == "f32" else "variant_bf16x3"
+        variant = {"mma": MMA_TEXT[other] + "; same step, same process",
                    "value": round(args.batch * world * args.steps / dtv, 3), "unit": "HR img/s",
-                   "ms_per_step": round(1e3 * dtv / args.steps, 2), "steps": args.steps, "warmup": 2, "dtype": "f32 (bf16x3 split operands)"}
+                   "ms_per_step": round(1e3 * dtv / args.steps, 2), "steps": args.steps, "warmup": 2,
+                   "dtype": "f32" if other == "f32" else "f32 (bf16x3)"}
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -401,17 +435,14 @@ def main():
             "metric": "HR images/sec (G+D step), ESRGAN x4 128->512",
             "value": round(imgs / dt, 3), "unit": "HR img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.amp else "f32",
+            "vs_baseline": None, "dtype": "bf16" if args.amp else ("f32 (bf16x3)" if args.mma == "bf16x3" else "f32"),
             "data": "synthetic" if not dry else "DRY-RUN on CPU (emulated C ABI, tiny shapes): NOT a measurement",
             "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                        "world_size_observed": model.dp.world_size,
-                       "mma": ("bf16 operands (use_amp)" if args.amp else
-                               "fp32 matrix core (v_mfma_f32_32x32x2_f32)" if args.mma == "f32" else
-                               "VARIANT bf16x3: convolutions (per-layer and chain, forward and data-gradient) split fp32 operands exactly "
-                               "into 3 bf16 values, 6 of 9 partial products, fp32 accumulate (error vs fp64 <= the fp32 matrix-core "
-                               "path's); weight-gradient kernels on the fp32 matrix core"),
+                       "mma": "bf16 operands (use_amp)" if args.amp else MMA_TEXT[args.mma],
+                       "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of
@@ -419,7 +450,7 @@ def main():
             "step_tflops": round((FLOP_PER_IMG - (2 * D_FWD_FLOP_PER_IMG if memo else 0.0)) * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
             "d_forward_memoized": memo,
             "roofline": roof,
-            "variant_bf16x3": variant,
+            (variant_key or "variant_f32_mfma"): variant,
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
         if feeder is not None:
@@ -435,6 +466,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             print("BENCH_GPU_LINE " + json.dumps(out), file=sys.stderr, flush=True)    # safe before the CPU leg
             out["cpu_baseline"] = cpu_baseline(args.crop)
+            out["cpu_reference"] = cpu_reference_record()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -21,7 +21,7 @@ def test_bench_self_launches_two_ranks():
     assert j["config"]["global_batch"] == 4 and j["scaling"] == "weak" and j["steps"] == 1
     assert j["value"] is None and j["invalid"] == "dry run"          # never mistaken for a measurement
     assert all(v == v for v in j["losses"].values())                 # finite
-    # the contract's keys are all there; the second (bf16x3) measurement only exists for a real 1-GPU run
-    for k in ("metric", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "variant_bf16x3"):
+    # the contract's keys are all there; the second measurement (the other fp32 arithmetic) only exists for a real 1-GPU run
+    for k in ("metric", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "variant_f32_mfma"):
         assert k in j, k
-    assert j["variant_bf16x3"] is None and j["dtype"] == "f32" and j["config"]["mma"].startswith("fp32 matrix core")
+    assert j["variant_f32_mfma"] is None and j["dtype"] == "f32 (bf16x3)" and j["config"]["mma"].startswith("fp32 arithmetic on the bf16 matrix core")

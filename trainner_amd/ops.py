@@ -242,7 +242,7 @@ PROFILE = None      # set to a ConvProfile() to time launches
 # matrix-core arithmetic of every MFMA launch below.  hip.MMA_F32: v_mfma_f32_32x32x2_f32; hip.MMA_BF16X3: fp32 operands split
 # exactly into three bf16 values, six partial products on the bf16 matrix core, fp32 accumulate (fp32-level accuracy at 6/16 of the
 # matrix-core cycles; TNR_MMA=bf16x3); hip.MMA_BF16: operands ROUNDED to bf16 (`use_amp: true`, set by BaseModel.setup_amp)
-FP32_MMA = {"f32": hip.MMA_F32, "bf16x3": hip.MMA_BF16X3}[os.environ.get("TNR_MMA", "f32").lower()]
+FP32_MMA = {"f32": hip.MMA_F32, "bf16x3": hip.MMA_BF16X3}[os.environ.get("TNR_MMA", "bf16x3").lower()]
 MMA = FP32_MMA
 
 
