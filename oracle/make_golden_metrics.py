@@ -1,6 +1,8 @@
-"""tests/golden/metrics.pt from the REFERENCE's own tensor2np (dataops/common.py:502-566) and calculate_psnr
-(utils/metrics.py:110-126) -- run in the build container:  python -m oracle.make_golden_metrics
-(cv2 is not installed, so the reference's SSIM cannot be executed; see oracle/metrics_oracle.py.)
+"""tests/golden/metrics.pt from the REFERENCE's own tensor2np (dataops/common.py:502-566), calculate_psnr (utils/metrics.py:110-126)
+and calculate_ssim (utils/metrics.py:180-223) -- run in the build container:  python -m oracle.make_golden_metrics
+cv2 is not installed: the reference's SSIM code runs with its two OpenCV calls (getGaussianKernel, filter2D) served by scipy
+(oracle/stubs/cv2: scipy.signal.windows.gaussian, scipy.ndimage.correlate(mode="mirror") = BORDER_REFLECT_101) -- an implementation
+independent of oracle/metrics_oracle.py and of csrc/metrics.hip, which both restate the 'valid' correlation directly.
 """
 import os
 
@@ -12,11 +14,17 @@ from . import ref_harness as R
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "metrics.pt")
 
 
+def ssim_value(v):
+    """calculate_ssim returns the MAP (not its mean) for [H, W, 1] inputs (utils/metrics.py:219-220): the fixture keeps its mean."""
+    import numpy as np
+    return float(np.mean(v))
+
+
 def main():
     cases = {}
     with R.reference_env():
         from dataops.common import tensor2np
-        from utils.metrics import calculate_psnr
+        from utils.metrics import calculate_psnr, calculate_ssim
         specs = {"rgb_unit": ((2, 3, 40, 56), 0.0, 1.0, False), "rgb_overshoot": ((1, 3, 33, 47), -0.3, 1.3, False),
                  "rgb_znorm": ((1, 3, 24, 24), -1.2, 1.2, True), "gray": ((1, 1, 30, 30), 0.0, 1.0, False)}
         for name, (shape, lo, hi, den) in specs.items():
@@ -29,7 +37,8 @@ def main():
                 a = tensor2np(sr[n], denormalize=den)
                 b = tensor2np(hr[n], denormalize=den)
                 imgs.append(dict(sr_u8=torch.from_numpy(a.copy()), hr_u8=torch.from_numpy(b.copy()),
-                                 psnr4=calculate_psnr(a, b, 4), psnr0=calculate_psnr(a, b, 0)))
+                                 psnr4=calculate_psnr(a, b, 4), psnr0=calculate_psnr(a, b, 0),
+                                 ssim4=ssim_value(calculate_ssim(a, b, 4)), ssim0=ssim_value(calculate_ssim(a, b, 0))))
             cases[name] = dict(sr=sr, hr=hr, denormalize=den, images=imgs)
     torch.save(cases, OUT)
     print("wrote", OUT, {k: [round(i["psnr4"], 4) for i in v["images"]] for k, v in cases.items()})

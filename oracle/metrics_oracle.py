@@ -1,11 +1,12 @@
 """CPU restatement of the reference's validation metrics (numpy; TEST INFRASTRUCTURE ONLY).
 
 calculate_psnr: codes/utils/metrics.py:110-126 (importable from the reference: pure numpy) -- pinned by
-tests/golden/metrics.pt, which oracle/make_golden_metrics.py produces with the REFERENCE's own tensor2np and
-calculate_psnr.  ssim / calculate_ssim: codes/utils/metrics.py:180-223 call cv2.getGaussianKernel and cv2.filter2D;
-cv2 is not installed here, so the SSIM half is "parity unpinned" by the reference itself: it restates the published
-algorithm (11-tap Gaussian, sigma 1.5: exp(-(i-5)^2 / (2 sigma^2)) normalised; 'valid' correlation; C1, C2 as in
-the reference) in float64.
+tests/golden/metrics.pt, which oracle/make_golden_metrics.py produces with the REFERENCE's own tensor2np,
+calculate_psnr and calculate_ssim.  ssim / calculate_ssim (codes/utils/metrics.py:180-223) call cv2.getGaussianKernel and
+cv2.filter2D; cv2 is not installed here, so the fixture run serves those two calls from scipy (oracle/stubs/cv2) and executes the
+reference's code around them; this module restates the same algorithm directly (11-tap Gaussian, sigma 1.5:
+exp(-(i-5)^2 / (2 sigma^2)) normalised; 'valid' correlation; C1, C2 as in the reference) in float64 and must agree with the
+fixture to 1e-12 (tests/test_metrics.py).
 """
 import math
 

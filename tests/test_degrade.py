@@ -1,8 +1,13 @@
 """Real-ESRGAN degradations on the device.  Blur-kernel generators: pinned to the REFERENCE's own
-get_gaussian_kernel / get_sinc_kernel (tests/golden/degrade_kernels.pt).  Device kernels: against the numpy
-restatements of OpenCV's / libjpeg's published algorithms in oracle/degrade_oracle.py (cv2 is not installed: parity
-with cv2 itself is unpinned) -- filter2D / resize to fp32 round-off, JPEG exactly up to rounding ties, noise by its
-statistics, its structure (grey = equal channels) and its reproducibility."""
+get_gaussian_kernel / get_sinc_kernel (tests/golden/degrade_kernels.pt).  The reference runs the image operations through OpenCV
+(dataops/augmentations.py:1666-1801, dataops/augmennt/augmennt/{transforms,functional,extra_functional}.py), which is not installed
+here; every device kernel is therefore pinned to an INDEPENDENT installed implementation of the same operation:
+  JPEG      libjpeg-turbo through PIL (cv2.imencode / imdecode call the same library with the same defaults: 4:2:0, islow DCT, fancy
+            up-sampling) -- BIT FOR BIT, oracle and device kernel alike;
+  filter2D  scipy.ndimage.correlate(mode="mirror") (= BORDER_REFLECT_101, centred anchor);
+  resize    torch.nn.functional.interpolate for INTER_LINEAR / INTER_CUBIC (half-pixel centres, A = -0.75, clamped borders),
+            average pooling for integer INTER_AREA; fractional INTER_AREA by its closed form (coverage-weighted box);
+  noise     by its statistics, its structure (grey = equal channels) and its reproducibility."""
 import math
 import os
 
@@ -31,14 +36,71 @@ def test_blur_kernel_generators_match_reference():
     assert D.pad_kernel21(np.ones((7, 7))).sum() == 49 and D.pad_kernel21(np.ones((7, 7)))[7:14, 7:14].all()
 
 
-def test_oracle_resize_and_jpeg_sanity():
+def pil_jpeg_roundtrip(u8, quality):
+    """uint8 RGB [3,H,W] through a real libjpeg(-turbo) encode + decode with OpenCV's defaults (4:2:0, baseline tables)."""
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(u8.transpose(1, 2, 0)), "RGB").save(buf, format="JPEG", quality=int(quality), subsampling=2)
+    buf.seek(0)
+    return np.asarray(Image.open(buf).convert("RGB")).transpose(2, 0, 1)
+
+
+JPEG_SHAPES = ((48, 48), (37, 51), (130, 70), (43, 45), (8, 8), (16, 3), (5, 9), (200, 136))
+
+
+def test_oracle_jpeg_is_libjpeg_bit_for_bit():
+    """oracle/degrade_oracle.jpeg_u8 against libjpeg-turbo (PIL): every pixel equal, for white-noise images (the worst case for
+    rounding ties), odd sizes (edge replication in the down-sampled domain, partial MCUs), tiny widths (libjpeg's replication
+    fallback) and the whole quality range of the presets (resrgan_noise.yaml: 30..95) plus the extremes."""
+    pytest.importorskip("PIL")
+    rs = np.random.RandomState(9)
+    for shape in JPEG_SHAPES:
+        u8 = rs.randint(0, 256, (3,) + shape).astype(np.uint8)
+        for q in (5, 30, 50, 75, 90, 95, 100):
+            assert np.array_equal(DO.jpeg_u8(u8, q), pil_jpeg_roundtrip(u8, q)), (shape, q)
+    smooth = np.rint(255 * np.clip(np.stack([np.outer(np.linspace(0, 1, 64), np.linspace(0.2, 0.9, 80))] * 3) + 0.02 * rs.randn(3, 64, 80), 0, 1))
+    assert np.array_equal(DO.jpeg_u8(smooth.astype(np.uint8), 60), pil_jpeg_roundtrip(smooth.astype(np.uint8), 60))
+
+
+def test_oracle_filter2d_is_scipy_correlate_mirror():
+    ndi = pytest.importorskip("scipy.ndimage")
+    rs = np.random.RandomState(4)
+    img = rs.rand(37, 53)
+    for ks in (3, 7, 21):
+        k = rs.rand(ks, ks)
+        k /= k.sum()
+        assert np.abs(DO.filter2d(img, k) - ndi.correlate(img, k, mode="mirror")).max() < 1e-12, ks
+
+
+def test_oracle_resize_linear_cubic_are_torch_interpolate():
+    """INTER_LINEAR / INTER_CUBIC of a float image = half-pixel-centre bilinear / Keys bicubic (A = -0.75) with clamped source
+    indices: torch.nn.functional.interpolate(align_corners=False) implements the same definitions independently."""
+    import torch.nn.functional as F
+    rs = np.random.RandomState(6)
+    img = rs.rand(24, 36)
+    t = torch.from_numpy(img)[None, None]
+    for size in ((20, 31), (61, 80), (15, 22), (24, 36), (50, 13)):
+        lin = F.interpolate(t, size=size, mode="bilinear", align_corners=False)[0, 0].numpy()
+        cub = F.interpolate(t, size=size, mode="bicubic", align_corners=False)[0, 0].numpy()
+        assert np.abs(DO.resize(img, size, "linear") - lin).max() < 5e-6, size       # (the tables carry fp32 coordinates like cv2's)
+        assert np.abs(DO.resize(img, size, "cubic") - cub).max() < 5e-6, size
+
+
+def test_oracle_resize_area_closed_forms():
     img = np.random.RandomState(0).rand(24, 36)
     assert np.allclose(DO.resize(img, (12, 18), "area"), img.reshape(12, 2, 18, 2).mean((1, 3)))      # integer box filter
     assert np.allclose(DO.resize(img, (24, 36), "linear"), img) and np.allclose(DO.resize(img, (24, 36), "cubic"), img)
-    flat = np.full((3, 32, 48), 0.5)
-    assert np.abs(DO.jpeg(flat, 30) - np.rint(127.5) / 255).max() < 2 / 255      # a flat image survives any quality
-    x = np.random.RandomState(1).rand(3, 40, 40)
-    assert np.abs(DO.jpeg(x, 95) - x).mean() < np.abs(DO.jpeg(x, 30) - x).mean()
+    # fractional shrink: every output = coverage-weighted mean of the source cells its box [d s, (d + 1) s) overlaps; the weights of a
+    # row sum to 1 and a constant image stays constant
+    ones = np.ones((24, 36))
+    assert np.allclose(DO.resize(ones, (10, 13), "area"), 1.0) and np.allclose(DO.resize(ones, (7, 36), "area"), 1.0)
+    ramp = np.tile(np.arange(36, dtype=np.float64), (24, 1))
+    got = DO.resize(ramp, (24, 10), "area")[0]
+    # the image is piecewise constant (cell x holds the value x): the box mean is the integral of floor(x) over [3.6 d, 3.6 d + 3.6)
+    fine = np.floor((np.arange(36000) + 0.5) / 1000.0)
+    want = fine.reshape(10, 3600).mean(1)
+    assert np.allclose(got, want, atol=2e-3)       # (cv2's table drops coverage slivers below 1e-3 of a pixel)
 
 
 @pytest.mark.gpu
@@ -48,10 +110,12 @@ def test_device_filter2d_and_resize():
     img = rs.rand(2, 3, 37, 53).astype(np.float32)
     ks = [D.gaussian_kernel(21, (2.0, 0.7), angle=30.0), D.sinc_kernel(1.3, 9)]
     got = D.filter2d(torch.from_numpy(img).cuda(), ks).cpu().numpy()
+    import scipy.ndimage as ndi
     for n in range(2):
         for c in range(3):
             ref = DO.filter2d(img[n, c], ks[n])
             assert np.abs(got[n, c] - ref).max() < 5e-6, (n, c)
+            assert np.abs(got[n, c] - ndi.correlate(img[n, c].astype(np.float64), ks[n], mode="mirror")).max() < 5e-6, (n, c)
     for mode, size in (("area", (10, 13)), ("area", (37, 20)), ("area", (50, 70)), ("area", (18, 53)), ("linear", (20, 31)),
                        ("linear", (61, 80)), ("cubic", (15, 22)), ("cubic", (74, 99)), ("area", (6, 9))):
         got = D.resize(torch.from_numpy(img).cuda(), size, mode).cpu().numpy()
@@ -59,24 +123,36 @@ def test_device_filter2d_and_resize():
         for n in range(2):
             ref = DO.resize(img[n, 1].astype(np.float64), size, mode)
             assert np.abs(got[n, 1] - ref).max() < 2e-5, (mode, size, np.abs(got[n, 1] - ref).max())
+        if mode != "area":       # the independent statement of the same definition
+            tm = torch.nn.functional.interpolate(torch.from_numpy(img), size=size, mode={"linear": "bilinear", "cubic": "bicubic"}[mode],
+                                                 align_corners=False).numpy()
+            assert np.abs(got - tm).max() < 2e-5, (mode, size)
 
 
 @pytest.mark.gpu
-def test_device_jpeg_simulation():
+def test_device_jpeg_is_libjpeg_bit_for_bit():
+    """tnr_jpeg_sim (integer emulation of libjpeg: csrc/degrade.hip) against the oracle AND against libjpeg-turbo itself (PIL):
+    every decoded 8-bit sample equal, batches with per-image qualities, odd sizes, noise images."""
     from trainner_amd.dataops import degradations as D
     rs = np.random.RandomState(3)
-    base = rs.rand(2, 3, 8, 8).astype(np.float32).repeat(6, 2).repeat(6, 3)[:, :, :43, :45]   # blocky image + odd size
-    img = np.clip(base + 0.05 * rs.randn(*base.shape).astype(np.float32), 0, 1)
-    q = [35, 90]
-    got = D.jpeg(torch.from_numpy(img.copy()).cuda(), q).cpu().numpy()
-    for n in range(2):
-        ref = DO.jpeg(img[n], q[n])
-        d = np.abs(got[n] - ref) * 255
-        # float DCT on both sides (fp32 on the device, fp64 here): identical except where a coefficient or a decoded
-        # sample sits within round-off of a rounding boundary -- one quantisation step / one 8-bit level there
-        assert (d > 0.5).mean() < 0.08 and np.median(d) < 1e-3 and d.max() <= 24, (n, (d > 0.5).mean(), d.max())
-        assert np.abs(got[n] * 255 - np.rint(got[n] * 255)).max() < 1e-3          # decoded samples are 8-bit levels
-    assert np.abs(got[1] - img[1]).mean() < np.abs(got[0] - img[0]).mean() + 0.02
+    have_pil = True
+    try:
+        import PIL  # noqa: F401
+    except ImportError:
+        have_pil = False
+    for shape in JPEG_SHAPES:
+        u8 = rs.randint(0, 256, (3, 3) + shape).astype(np.uint8)
+        q = [30, 77, 95]
+        got = D.jpeg(torch.from_numpy(u8.astype(np.float32) / 255.0).cuda(), q).cpu().numpy()
+        got8 = np.rint(got * 255).astype(np.uint8)
+        assert np.abs(got * 255 - got8).max() < 1e-3                               # decoded samples are 8-bit levels
+        for n in range(3):
+            assert np.array_equal(got8[n], DO.jpeg_u8(u8[n], q[n])), (shape, n)
+            if have_pil:
+                assert np.array_equal(got8[n], pil_jpeg_roundtrip(u8[n], q[n])), (shape, n)
+    x = rs.rand(2, 3, 40, 40).astype(np.float32)
+    y = D.jpeg(torch.from_numpy(np.stack([x[0], x[0]])).cuda(), [95, 30]).cpu().numpy()
+    assert np.abs(y[0] - x[0]).mean() < np.abs(y[1] - x[0]).mean()
 
 
 @pytest.mark.gpu
@@ -120,3 +196,137 @@ def test_realesrgan_pipeline_shapes_and_determinism():
     lo = RealESRGANDegradation(scale=4, seed=9)(smooth)
     assert float((lo - D.resize(smooth, (32, 32), "area")).abs().mean()) < 0.12
     assert torch.isfinite(a).all() and ref.shape == a.shape
+
+
+def _grammar(ops, lr_size):
+    """Split a planned operation list by the control flow of aug_pipeline (dataops/augmentations.py:1666-1801); returns the facts the
+    statistics below are taken over, or raises AssertionError when the list is not a sentence of that grammar."""
+    i, facts = 0, {}
+
+    def take(kind):
+        nonlocal i
+        if i < len(ops) and ops[i][0] == kind:
+            i += 1
+            return ops[i - 1]
+        return None
+
+    def noise():
+        nonlocal i
+        assert i < len(ops) and ops[i][0] in ("gaussian", "poisson"), ops[i:i + 1]
+        i += 1
+        return ops[i - 1]
+
+    facts["blur1"], facts["resize1"], facts["noise1"] = take("blur"), take("resize"), noise()
+    facts["jpeg1"] = take("jpeg")
+    assert facts["jpeg1"] is not None
+    facts["blur2"], facts["resize2"], facts["noise2"] = take("blur"), take("resize"), noise()
+    # the second resize and the final resize are both ("resize", ...): the final one targets the LR size and is followed by blur / jpeg / end
+    tail = ops[i:]
+    kinds = [o[0] for o in tail]
+    assert kinds in (["jpeg", "resize"], ["jpeg", "resize", "blur"], ["resize", "jpeg"], ["resize", "blur", "jpeg"]), kinds
+    facts["compress_first"] = kinds[0] == "jpeg"
+    facts["final_sinc"] = "blur" in kinds
+    fr = [o for o in tail if o[0] == "resize"][0]
+    assert tuple(fr[1]) == tuple(lr_size)
+    facts["final_algo"], facts["jpeg2"] = fr[2], [o for o in tail if o[0] == "jpeg"][0]
+    return facts
+
+
+def test_plan_replays_the_reference_control_flow():
+    """The host half of the pipeline (RealESRGANDegradation.plan: every random decision, no device) against aug_pipeline's control
+    flow and the resrgan presets' probabilities / ranges: 1 500 planned samples must all be sentences of
+        [blur] [resize] noise jpeg [blur2] [resize2] noise2 ( jpeg resize [sinc] | resize [sinc] jpeg )
+    with blur 100 %, blur2 80 %, sinc 80 %, either final order 50 %, resize kept 10 % / 30 %, noise kinds 50 / 50, grey 40 %,
+    qualities in 30..95, odd kernel sizes 7..21, the three resize algorithms equally likely."""
+    from trainner_amd.dataops.degradations import RealESRGANDegradation
+    d = RealESRGANDegradation(scale=4, seed=123)
+    H = W = 256
+    F = [_grammar(ops, (H // 4, W // 4)) for _ in range(30) for ops in d.plan(50, H, W)]
+    n = float(len(F))
+
+    def frac(pred):
+        return sum(1 for f in F if pred(f)) / n
+
+    tol = 4.0 * 0.5 / math.sqrt(n)          # 4 sigma of a fair coin: generous for every proportion below
+    assert frac(lambda f: f["blur1"] is not None) == 1.0
+    assert abs(frac(lambda f: f["blur2"] is not None) - 0.8) < tol and abs(frac(lambda f: f["final_sinc"]) - 0.8) < tol
+    assert abs(frac(lambda f: f["compress_first"]) - 0.5) < tol
+    assert abs(frac(lambda f: f["resize1"] is None) - 0.1) < tol and abs(frac(lambda f: f["resize2"] is None) - 0.3) < tol
+    assert abs(frac(lambda f: f["noise1"][0] == "gaussian") - 0.5) < tol and abs(frac(lambda f: f["noise2"][0] == "poisson") - 0.5) < tol
+    assert abs(frac(lambda f: f["noise1"][2]) - 0.4) < tol                                  # grey = 1 - prob_color
+    for a in ("area", "linear", "cubic"):
+        assert abs(frac(lambda f: f["final_algo"] == a) - 1 / 3) < tol
+    qs = [f["jpeg1"][1] for f in F] + [f["jpeg2"][1] for f in F]
+    assert min(qs) == 30 and max(qs) == 95
+    ks = [f["blur1"][1].shape[0] for f in F]
+    assert all(k % 2 == 1 and 7 <= k <= 21 for k in ks) and min(ks) == 7 and max(ks) == 21
+    f1 = [f["resize1"][1][0] / H for f in F if f["resize1"] is not None]
+    assert min(f1) >= 0.15 - 1 / H and max(f1) <= 1.5 + 1 / H and abs(np.mean([x > 1 for x in f1]) - 0.2 / 0.9) < tol
+    g = [f["noise1"][1] for f in F if f["noise1"][0] == "gaussian"]
+    assert all(1.0 <= s ** 2 <= 30.0 + 1e-9 for sig in g for s in sig)
+    multi = np.mean([len(set(sig)) == 3 for sig in g])                                      # MC-AWGN: 34 % of the colour draws
+    assert abs(multi - 0.34 * 0.6) < tol
+    ps = [f["noise2"][1] for f in F if f["noise2"][0] == "poisson"]
+    assert min(ps) >= 0.05 and max(ps) <= 2.5
+    # same seed, same plan; the noise seeds differ per sample and per call
+    a, b = RealESRGANDegradation(scale=4, seed=9).plan(3, 64, 64), RealESRGANDegradation(scale=4, seed=9).plan(3, 64, 64)
+    assert str(a) == str(b)
+    seeds = [op[3] for ops in a for op in ops if op[0] in ("gaussian", "poisson")]
+    assert len(set(seeds)) == len(seeds)
+
+
+def test_presets_are_read_and_overridden(tmp_path):
+    """degradation_config = the reference's preset overlay (options/options.py:148-165,366-463): built-in values == the reference's
+    own resrgan_*.yaml files; a user-edited preset, `add_*_preset`, and keys in the dataset options change the draws."""
+    import yaml
+    from trainner_amd.dataops.degradations import RESRGAN, RealESRGANDegradation, degradation_config
+    ref_root = "/root/reference/codes/options/presets"
+    if os.path.isdir(ref_root):           # build container: the constants ARE the reference's files
+        assert degradation_config({"augs_strategy": "resrgan"}, presets_root=ref_root) == degradation_config() == RESRGAN
+    root = tmp_path / "presets"
+    root.mkdir()
+    (root / "mine_blur.yaml").write_text(yaml.safe_dump({"kind": "Blur", "config": {
+        "pipeline": {"lr_blur": True, "lr_blur_types": {"iso": 1.0}, "blur_prob": 1.0, "lr_blur2": False, "final_blur": ["sinc"], "final_blur_prob": 0.0},
+        "iso": {"min_kernel_size": 9, "kernel_size": 9, "sigmaX": [1.0, 1.0]}}}))
+    (root / "mine_noise.yaml").write_text(yaml.safe_dump({"kind": "Noise", "config": {
+        "pipeline": {"lr_noise": True, "lr_noise_types": ["gaussian"], "lr_noise2": True, "lr_noise_types2": ["poisson"], "compression": ["jpeg"],
+                     "final_compression": ["jpeg"]},
+        "gaussian": {"var_limit": [4, 4], "prob_color": 1.0, "multi": False}, "jpeg": {"min_quality": 50, "max_quality": 50}}}))
+    ds = {"augs_strategy": "resrgan", "add_blur_preset": "mine_blur", "add_noise_preset": "mine_noise", "lr_downscale2": False}
+    conf = degradation_config(ds, presets_root=str(root))
+    assert conf["blur"]["types"] == {"iso": 1.0} and conf["blur2"]["enabled"] is False and conf["resize2"]["enabled"] is False
+    assert conf["resize"] == RESRGAN["resize"]                                             # untouched stage keeps the built-in values
+    for ops in RealESRGANDegradation(scale=4, preset=conf, seed=1).plan(40, 64, 64):
+        kinds = [o[0] for o in ops]
+        assert kinds.count("blur") == 1 and ops[0][0] == "blur" and ops[0][1].shape == (9, 9)     # one iso blur of 9 taps, no blur2, no sinc
+        assert [o for o in ops if o[0] == "gaussian"][0][1] == [2.0, 2.0, 2.0] and not [o for o in ops if o[0] == "gaussian"][0][2]
+        assert "poisson" in kinds and all(o[1] == 50 for o in ops if o[0] == "jpeg")
+        assert kinds.count("resize") <= 2
+    with pytest.raises(NotImplementedError):
+        degradation_config({"augs_strategy": "resrgan", "lr_noise_types": ["camera"]})
+    with pytest.raises(NotImplementedError):
+        degradation_config({"augs_strategy": "bsrgan"}, presets_root=str(root))            # no such files, nothing built in
+    # options.parse carries the merged configuration into the train dataset options
+    from oracle import ref_harness
+    from trainner_amd.options import options
+    yml = ref_harness.esrgan_yaml(name="presets", out_root=str(tmp_path), gpu_ids="[0]", nb=1, batch=2, crop=64, d_nf=16)
+    txt = open(yml).read().replace("    dataroot_LR: /tmp/none_lr\n", "    augs_strategy: resrgan\n    add_blur_preset: mine_blur\n")
+    txt = txt.replace("use_tb_logger: false", "use_tb_logger: false\npresets_root: %s" % root)
+    open(yml, "w").write(txt)
+    opt = options.parse(yml, is_train=True)
+    dsopt = opt["datasets"]["train"]
+    assert dsopt["degradation"]["blur"]["types"] == {"iso": 1.0} and dsopt["presets_root"] == str(root)
+
+
+@pytest.mark.gpu
+def test_batched_leading_stages_equal_per_sample_execution():
+    """run(): the operations all samples share at the head of their plans (the full-size first blur, always) go out as one launch with
+    per-sample parameters -- bit-identical to executing every sample on its own."""
+    from trainner_amd.dataops.degradations import RealESRGANDegradation
+    hr = torch.rand(6, 3, 96, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    d = RealESRGANDegradation(scale=4, seed=11)
+    plans = d.plan(6, 96, 128)
+    assert all(p[0][0] == "blur" for p in plans)
+    whole = d.run(hr, plans)
+    for n in range(6):
+        assert torch.equal(whole[n:n + 1], d.run(hr[n:n + 1], [plans[n]])), n

@@ -1,7 +1,7 @@
 """Validation metrics: the device-side tensor2np / PSNR / SSIM against fixtures produced by the
-REFERENCE's own tensor2np + calculate_psnr (tests/golden/metrics.pt, oracle/make_golden_metrics.py) and against the
-numpy restatement oracle/metrics_oracle.py (SSIM: cv2 is not installed, the reference's SSIM cannot run here).
-uint8 images must match byte for byte, PSNR to 1e-9 dB, SSIM to 1e-9."""
+REFERENCE's own tensor2np + calculate_psnr + calculate_ssim (tests/golden/metrics.pt, oracle/make_golden_metrics.py; the reference's
+SSIM code ran with its two OpenCV calls served by scipy: oracle/stubs/cv2) and against the numpy restatement
+oracle/metrics_oracle.py.  uint8 images must match byte for byte, PSNR to 1e-9 dB, SSIM to 1e-9."""
 import os
 
 import numpy as np
@@ -20,6 +20,8 @@ def test_oracle_metrics_match_reference_fixtures():
             b = MO.tensor2np(c["hr"][n].numpy(), denormalize=c["denormalize"])
             assert np.array_equal(a, im["sr_u8"].numpy()) and np.array_equal(b, im["hr_u8"].numpy()), name
             assert abs(MO.calculate_psnr(a, b, 4) - im["psnr4"]) < 1e-12 and abs(MO.calculate_psnr(a, b, 0) - im["psnr0"]) < 1e-12
+            # the reference's own ssim() / calculate_ssim() (scipy serving getGaussianKernel / filter2D, then [5:-5, 5:-5])
+            assert abs(MO.calculate_ssim(a, b, 4) - im["ssim4"]) < 1e-12 and abs(MO.calculate_ssim(a, b, 0) - im["ssim0"]) < 1e-12
     # SSIM restatement: identical images -> 1, and the window is cv2.getGaussianKernel(11, 1.5)'s published formula
     a = FX["rgb_unit"]["images"][0]["sr_u8"].numpy()
     assert abs(MO.calculate_ssim(a, a, 4) - 1.0) < 1e-12
@@ -41,6 +43,7 @@ def test_device_tensor2np_psnr_ssim():
             assert abs(M.calculate_psnr(a, b, 4) - im["psnr4"]) < 1e-9 and abs(M.calculate_psnr(a, b, 0) - im["psnr0"]) < 1e-9
             want = MO.calculate_ssim(im["sr_u8"].numpy(), im["hr_u8"].numpy(), 4)
             assert abs(M.calculate_ssim(a, b, 4) - want) < 1e-9, (name, M.calculate_ssim(a, b, 4), want)
+            assert abs(M.calculate_ssim(a, b, 4) - im["ssim4"]) < 1e-9 and abs(M.calculate_ssim(a, b, 0) - im["ssim0"]) < 1e-9    # the reference's
         # batch form: every image in one launch; remove_batch keeps image 0 like the reference
         A = tensor2np(sr, remove_batch=False, denormalize=c["denormalize"])
         B = tensor2np(hr, remove_batch=False, denormalize=c["denormalize"])

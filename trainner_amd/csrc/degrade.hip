@@ -259,103 +259,155 @@ __constant__ int JQ_CHROMA[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66
                                   47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
                                   99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
 
-__device__ __forceinline__ float jq_entry(int base, int quality) {      // libjpeg: jpeg_quality_scaling + jpeg_add_quant_table
+// ---- JPEG round trip: an integer-exact emulation of libjpeg (what cv2.imencode + cv2.imdecode run in the reference,
+// dataops/augmennt/augmennt/extra_functional.py:293-297): JFIF colour conversion in 16-bit fixed point (jccolor.c / jdcolor.c), 4:2:0 with
+// the encoder's 2x2 box average and its alternating rounding bias (jcsample.c h2v2_downsample), the "islow" integer forward / inverse
+// DCT (jfdctint.c / jidctint.c, 13-bit constants), quantisation by division with round-half-away (jcdctmgr.c), "fancy" triangle
+// chroma up-sampling with the decoder's 8 / 7 biases (jdsample.c h2v2_fancy_upsample).  Pinned bit for bit against libjpeg-turbo
+// through PIL (tests/test_degrade.py).
+__device__ __forceinline__ int jq_entry(int base, int quality) {      // libjpeg: jpeg_quality_scaling + jpeg_add_quant_table (baseline)
     int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
     const int sf = q < 50 ? 5000 / q : 200 - 2 * q;
     int t = (base * sf + 50) / 100;
-    t = t < 1 ? 1 : (t > 255 ? 255 : t);
-    return (float)t;
+    return t < 1 ? 1 : (t > 255 ? 255 : t);
 }
 
-// quantise one 8x8 block held in blk[64] (row-major, level-shifted samples) in place: DCT-II -> round(c / q) * q -> inverse
-__device__ void jpeg_block(float *blk, const float *cosT, bool chroma, int quality, int t /* 0..63 */, float *tmp) {
-    const int u = t >> 3, v = t & 7;
-    // rows then columns: tmp[u][v] = sum_x blk[u][x] cos[v][x]
-    float s = 0.f;
-#pragma unroll
-    for (int x = 0; x < 8; ++x) s += blk[u * 8 + x] * cosT[v * 8 + x];
-    tmp[t] = s;
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) s += tmp[y * 8 + v] * cosT[u * 8 + y];
-    const float qv = jq_entry(chroma ? JQ_CHROMA[t] : JQ_LUMA[t], quality);
-    __syncthreads();
-    blk[t] = rintf(s / qv) * qv;              // coefficient (u = vertical, v = horizontal frequency)
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += blk[u * 8 + k] * cosT[k * 8 + v];      // inverse along x
-    tmp[t] = s;
-    __syncthreads();
-    s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += tmp[k * 8 + v] * cosT[k * 8 + u];      // inverse along y
-    __syncthreads();
-    blk[t] = s;
-    __syncthreads();
+namespace jdct {
+constexpr int CB = 13, P1 = 2;
+constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+              F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+__device__ __forceinline__ int ds(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// one 8-point forward pass over d[0], d[st], ..., d[7 st] (jfdctint.c; first = the row pass)
+__device__ __forceinline__ void fwd8(int *d, int st, bool first) {
+    const int d0 = d[0], d1 = d[st], d2 = d[2 * st], d3 = d[3 * st], d4 = d[4 * st], d5 = d[5 * st], d6 = d[6 * st], d7 = d[7 * st];
+    int t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    const int sh = first ? CB - P1 : CB + P1;
+    d[0] = first ? (t10 + t11) << P1 : ds(t10 + t11, P1);
+    d[4 * st] = first ? (t10 - t11) << P1 : ds(t10 - t11, P1);
+    int z1 = (t12 + t13) * F0_541;
+    d[2 * st] = ds(z1 + t13 * F0_765, sh);
+    d[6 * st] = ds(z1 + t12 * (-F1_847), sh);
+    z1 = t4 + t7;
+    int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const int z5 = (z3 + z4) * F1_175;
+    t4 *= F0_298; t5 *= F2_053; t6 *= F3_072; t7 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    d[7 * st] = ds(t4 + z1 + z3, sh);
+    d[5 * st] = ds(t5 + z2 + z4, sh);
+    d[3 * st] = ds(t6 + z2 + z3, sh);
+    d[st] = ds(t7 + z1 + z4, sh);
 }
+// one 8-point inverse pass (jidctint.c; first = the column pass)
+__device__ __forceinline__ void inv8(int *d, int st, bool first) {
+    const int i0 = d[0], i1 = d[st], i2 = d[2 * st], i3 = d[3 * st], i4 = d[4 * st], i5 = d[5 * st], i6 = d[6 * st], i7 = d[7 * st];
+    int z1 = (i2 + i6) * F0_541;
+    int t2 = z1 + i6 * (-F1_847), t3 = z1 + i2 * F0_765;
+    int t0 = (i0 + i4) << CB, t1 = (i0 - i4) << CB;
+    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    t0 = i7; t1 = i5; t2 = i3; t3 = i1;
+    z1 = t0 + t3;
+    int z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+    const int z5 = (z3 + z4) * F1_175;
+    t0 *= F0_298; t1 *= F2_053; t2 *= F3_072; t3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+    const int sh = first ? CB - P1 : CB + P1 + 3;
+    d[0] = ds(t10 + t3, sh); d[7 * st] = ds(t10 - t3, sh);
+    d[st] = ds(t11 + t2, sh); d[6 * st] = ds(t11 - t2, sh);
+    d[2 * st] = ds(t12 + t1, sh); d[5 * st] = ds(t12 - t1, sh);
+    d[3 * st] = ds(t13 + t0, sh); d[4 * st] = ds(t13 - t0, sh);
+}
+}  // namespace jdct
 
-// pass 1: one workgroup (64 threads) per 8x8 block of one plane; planes: Y at full size, Cb / Cr at half size
-// ycc planes are [N][3] with per-plane padded dims; this kernel quantises plane `pl` of every image
+// one workgroup (64 threads) per 8x8 block of one plane (Y at full size, Cb / Cr at half size; 8-bit sample values held in floats):
+// forward DCT -> quantise -> dequantise -> inverse DCT -> range limit, all in libjpeg's integer arithmetic
 __global__ void __launch_bounds__(64) jpeg_quant_kernel(float *plane, int N, int Hp, int Wp, const int32_t *quality, int chroma) {
-    __shared__ float blk[64], tmp[64], cosT[64];
+    __shared__ int blk[64];
     const int t = threadIdx.x, bx = blockIdx.x, by = blockIdx.y, n = blockIdx.z;
-    {
-        const int k = t >> 3, x = t & 7;     // orthonormal DCT-II basis: cosT[k][x] = c(k) cos((2x + 1) k pi / 16)
-        cosT[t] = (k == 0 ? 0.35355339059327373f : 0.5f) * cosf((2 * x + 1) * k * 0.19634954084936207f);
-    }
     float *p = plane + ((size_t)n * Hp + by * 8 + (t >> 3)) * Wp + bx * 8 + (t & 7);
-    blk[t] = *p - 128.f;
+    blk[t] = (int)*p - 128;
     __syncthreads();
-    jpeg_block(blk, cosT, chroma != 0, quality[n], t, tmp);
-    *p = blk[t] + 128.f;
+    if (t < 8) jdct::fwd8(blk + 8 * t, 1, true);           // rows
+    __syncthreads();
+    if (t < 8) jdct::fwd8(blk + t, 8, false);              // columns: coefficients scaled by 8
+    __syncthreads();
+    {
+        const int q = jq_entry(chroma ? JQ_CHROMA[t] : JQ_LUMA[t], quality[n]), qv = q << 3;
+        const int c = blk[t], a = (c < 0 ? -c : c) + (qv >> 1);
+        const int lvl = a / qv;
+        blk[t] = (c < 0 ? -lvl : lvl) * q;                 // quantised, then dequantised by the decoder
+    }
+    __syncthreads();
+    if (t < 8) jdct::inv8(blk + t, 8, true);               // columns
+    __syncthreads();
+    if (t < 8) jdct::inv8(blk + 8 * t, 1, false);          // rows
+    __syncthreads();
+    const int v = blk[t] + 128;
+    *p = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// RGB [0,1] -> Y (padded to a multiple of 16 by edge replication) and 2x2-averaged Cb, Cr
+__device__ __forceinline__ int jfix(double x) { return (int)(x * 65536.0 + 0.5); }
+
+// RGB [0,1] -> 8-bit Y (full size) and Cb / Cr (half size).  Right edge: the last column is replicated at full resolution; bottom edge:
+// the last REAL row of every component is replicated (for the chroma planes that is the last down-sampled row: jcprepct.c)
 __global__ void jpeg_to_ycc_kernel(const float *img, int N, int H, int W, float *Y, float *Cb, float *Cr, int Hp, int Wp) {
-    const int Hc = Hp / 2, Wc = Wp / 2;
+    const int Hc = Hp / 2, Wc = Wp / 2, Hcv = (H + 1) / 2;
     const int64_t total = (int64_t)N * Hc * Wc;
+    const int fy_r = jfix(0.299), fy_g = jfix(0.587), fy_b = jfix(0.114), fb_r = jfix(0.16874), fb_g = jfix(0.33126), f_half = jfix(0.5),
+              fr_g = jfix(0.41869), fr_b = jfix(0.08131);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int cx = (int)(e % Wc), cy = (int)((e / Wc) % Hc), n = (int)(e / ((int64_t)Wc * Hc));
-        float sb = 0.f, sr = 0.f;
+        const int cys = cy < Hcv ? cy : Hcv - 1;          // chroma rows below the image repeat the last real one
+        int sb = 0, sr = 0;
         for (int dy = 0; dy < 2; ++dy)
             for (int dx = 0; dx < 2; ++dx) {
-                const int y = min(2 * cy + dy, H - 1), x = min(2 * cx + dx, W - 1);
-                const size_t o = (size_t)y * W + x, pl = (size_t)H * W;
-                // the codec sees 8-bit samples: round(255 x)
-                const float r = rintf(255.f * fminf(fmaxf(img[(size_t)n * 3 * pl + o], 0.f), 1.f));
-                const float g = rintf(255.f * fminf(fmaxf(img[((size_t)n * 3 + 1) * pl + o], 0.f), 1.f));
-                const float b = rintf(255.f * fminf(fmaxf(img[((size_t)n * 3 + 2) * pl + o], 0.f), 1.f));
-                Y[((size_t)n * Hp + 2 * cy + dy) * Wp + 2 * cx + dx] = rintf(0.299f * r + 0.587f * g + 0.114f * b);
-                sb += -0.168735892f * r - 0.331264108f * g + 0.5f * b + 128.f;
-                sr += 0.5f * r - 0.418687589f * g - 0.081312411f * b + 128.f;
+                const int x = min(2 * cx + dx, W - 1);
+                const size_t pl = (size_t)H * W;
+                auto px = [&](int y, int c) {          // the codec sees 8-bit samples: round(255 x)
+                    return (int)rintf(255.f * fminf(fmaxf(img[((size_t)n * 3 + c) * pl + (size_t)y * W + x], 0.f), 1.f));
+                };
+                {
+                    const int y = min(2 * cy + dy, H - 1);
+                    Y[((size_t)n * Hp + 2 * cy + dy) * Wp + 2 * cx + dx] =
+                        (float)((fy_r * px(y, 0) + fy_g * px(y, 1) + fy_b * px(y, 2) + 32768) >> 16);
+                }
+                const int y = min(2 * cys + dy, H - 1);
+                const int r = px(y, 0), g = px(y, 1), b = px(y, 2);
+                sb += (-fb_r * r - fb_g * g + f_half * b + (128 << 16) + 32767) >> 16;
+                sr += (f_half * r - fr_g * g - fr_b * b + (128 << 16) + 32767) >> 16;
             }
-        Cb[((size_t)n * Hc + cy) * Wc + cx] = rintf(0.25f * sb);
-        Cr[((size_t)n * Hc + cy) * Wc + cx] = rintf(0.25f * sr);
+        const int bias = (cx & 1) ? 2 : 1;
+        Cb[((size_t)n * Hc + cy) * Wc + cx] = (float)((sb + bias) >> 2);
+        Cr[((size_t)n * Hc + cy) * Wc + cx] = (float)((sr + bias) >> 2);
     }
 }
-
-// decoded planes -> RGB [0,1]; chroma up-sampled with the triangle ("fancy", 9/3/3/1) filter of libjpeg's h2v2 decoder
+// decoded planes -> RGB [0,1]; chroma up-sampled with the triangle ("fancy") filter of libjpeg's h2v2 decoder over the
+// ceil(H / 2) x ceil(W / 2) samples the decoder sees
 __global__ void jpeg_from_ycc_kernel(float *img, int N, int H, int W, const float *Y, const float *Cb, const float *Cr, int Hp, int Wp) {
-    const int Hc = Hp / 2, Wc = Wp / 2;
+    const int Hc = Hp / 2, Wc = Wp / 2, Hcv = (H + 1) / 2, Wcv = (W + 1) / 2;
     const int64_t total = (int64_t)N * H * W;
+    const int fr = jfix(1.402), fb = jfix(1.772), fg_b = jfix(0.34414), fg_r = jfix(0.71414);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % W), y = (int)((e / W) % H), n = (int)(e / ((int64_t)W * H));
         const int cx = x >> 1, cy = y >> 1;
-        const int nx = min(max(cx + ((x & 1) ? 1 : -1), 0), Wc - 1), ny = min(max(cy + ((y & 1) ? 1 : -1), 0), Hc - 1);
+        const int nx = min(max(cx + ((x & 1) ? 1 : -1), 0), Wcv - 1), ny = min(max(cy + ((y & 1) ? 1 : -1), 0), Hcv - 1);
         const float *pb = Cb + (size_t)n * Hc * Wc, *pr = Cr + (size_t)n * Hc * Wc;
         auto tri = [&](const float *p) {
-            return (9.f * p[(size_t)cy * Wc + cx] + 3.f * p[(size_t)cy * Wc + nx] + 3.f * p[(size_t)ny * Wc + cx] + p[(size_t)ny * Wc + nx]) *
-                   (1.f / 16.f);
+            if (Wcv <= 2) return (int)p[(size_t)cy * Wc + cx];      // jdsample.c: <= 2 chroma columns -> plain replication
+            const int th = 3 * (int)p[(size_t)cy * Wc + cx] + (int)p[(size_t)ny * Wc + cx];       // this column: 3 x near row + far row
+            const int ot = 3 * (int)p[(size_t)cy * Wc + nx] + (int)p[(size_t)ny * Wc + nx];       // the neighbouring column
+            return (3 * th + ot + ((x & 1) ? 7 : 8)) >> 4;
         };
-        const float yy = fminf(fmaxf(rintf(Y[((size_t)n * Hp + y) * Wp + x]), 0.f), 255.f);
-        const float cb = fminf(fmaxf(rintf(tri(pb)), 0.f), 255.f) - 128.f, cr = fminf(fmaxf(rintf(tri(pr)), 0.f), 255.f) - 128.f;
-        const float r = yy + 1.402f * cr, g = yy - 0.344136286f * cb - 0.714136286f * cr, b = yy + 1.772f * cb;
+        const int yy = (int)Y[((size_t)n * Hp + y) * Wp + x];
+        const int cb = tri(pb) - 128, cr = tri(pr) - 128;
+        const int r = yy + ((fr * cr + 32768) >> 16), b = yy + ((fb * cb + 32768) >> 16), g = yy + ((-fg_b * cb + 32768 - fg_r * cr) >> 16);
         const size_t pl = (size_t)H * W, o = (size_t)y * W + x;
-        img[(size_t)n * 3 * pl + o] = fminf(fmaxf(rintf(r), 0.f), 255.f) * (1.f / 255.f);
-        img[((size_t)n * 3 + 1) * pl + o] = fminf(fmaxf(rintf(g), 0.f), 255.f) * (1.f / 255.f);
-        img[((size_t)n * 3 + 2) * pl + o] = fminf(fmaxf(rintf(b), 0.f), 255.f) * (1.f / 255.f);
+        img[(size_t)n * 3 * pl + o] = (float)min(max(r, 0), 255) * (1.f / 255.f);
+        img[((size_t)n * 3 + 1) * pl + o] = (float)min(max(g, 0), 255) * (1.f / 255.f);
+        img[((size_t)n * 3 + 2) * pl + o] = (float)min(max(b, 0), 255) * (1.f / 255.f);
     }
 }
 

@@ -63,7 +63,9 @@ def create_dataloader(dataset, dataset_opt, gpu_ids=None, device=None, rank=0, w
     else:
         loader = tud.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, drop_last=False, pin_memory=True)
     degrade = None
-    if train and str(dataset_opt.get("augs_strategy", "")).lower() == "resrgan":       # options/presets/README.md:25-33
-        from ..dataops.degradations import RealESRGANDegradation
-        degrade = RealESRGANDegradation(scale=int(dataset_opt.get("scale", 4) or 4), seed=int(dataset_opt.get("seed", 0) or 0) + rank)
+    if train and not dataset_opt.get("dataroot_LR") and (dataset_opt.get("augs_strategy") or dataset_opt.get("degradation")):
+        # on-the-fly LR: the presets named by `augs_strategy` / `add_*_preset` (options/presets/README.md:25-33), merged by options.parse
+        from ..dataops.degradations import RealESRGANDegradation, degradation_config
+        conf = dataset_opt.get("degradation") or degradation_config(dataset_opt, dataset_opt.get("presets_root"))
+        degrade = RealESRGANDegradation(scale=int(dataset_opt.get("scale", 4) or 4), preset=conf, seed=int(dataset_opt.get("seed", 0) or 0) + rank)
     return DeviceFeeder(loader, device=device, znorm=bool(dataset_opt.get("znorm")), degrade=degrade)

@@ -78,8 +78,8 @@ class AlignedWindowDataset(data.Dataset):
             self.lr_paths = _list_images(lr_root)
             if len(self.lr_paths) != len(self.hr_paths):
                 raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_paths), len(self.hr_paths)))
-        elif str(opt.get("augs_strategy", "")).lower() != "resrgan":
-            raise NotImplementedError("no dataroot_LR: on-the-fly LR needs `augs_strategy: resrgan` (GPU degradation pipeline)")
+        elif not (opt.get("augs_strategy") or opt.get("degradation")):
+            raise NotImplementedError("no dataroot_LR: on-the-fly LR needs `augs_strategy: <preset>` (GPU degradation pipeline)")
 
     def __len__(self):
         return len(self.hr_paths)

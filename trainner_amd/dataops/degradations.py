@@ -180,112 +180,302 @@ def jpeg(img, quality):
 # ----------------------------------------------------------------------------------------------
 # the pipeline
 # ----------------------------------------------------------------------------------------------
+# Built-in configuration = the values of the reference's resrgan presets (options/presets/resrgan_{blur,resize,noise}.yaml over
+# base_*.yaml); `degradation_config` replaces any of it from the user's preset files / dataset options, like options.parse does
+# in the reference (options/options.py:148-165,366-463; options/presets/README.md "Overriding").
 RESRGAN = {
-    # options/presets/resrgan_blur.yaml
-    "blur": dict(types={"sinc": 0.1, "iso": 0.58, "aniso": 0.32}, prob=1.0, ks=(7, 21), sigma=(0.2, 3.0), angle=(-180, 180)),
-    "blur2": dict(types={"sinc": 0.1, "iso": 0.58, "aniso": 0.32}, prob=0.8, ks=(7, 21), sigma=(0.2, 1.5), angle=(-180, 180)),
-    "final_sinc_prob": 0.8,
-    # options/presets/resrgan_resize.yaml
-    "resize": dict(prob={"up": 0.2, "down": 0.7, "keep": 0.1}, up=(1.0, 1.5), down=(0.15, 1.0), algos=("area", "linear", "cubic")),
-    "resize2": dict(prob={"up": 0.3, "down": 0.4, "keep": 0.3}, up=(1.0, 1.2), down=(0.3, 1.0), algos=("area", "linear", "cubic")),
-    "final_algos": ("area", "linear", "cubic"),
-    # options/presets/resrgan_noise.yaml
-    "noise": dict(types=("gaussian", "poisson"), var=(1, 30), prob_color=0.6, multi=True, poisson_scale=(0.05, 3.0)),
-    "noise2": dict(types=("gaussian", "poisson"), var=(1, 25), prob_color=0.6, multi=True, poisson_scale=(0.05, 2.5)),
-    "jpeg": (30, 95),
+    "blur": dict(enabled=True, types={"sinc": 0.1, "iso": 0.58, "aniso": 0.32}, prob=1.0,
+                 iso=dict(ks=(7, 21), sigmaX=(0.2, 3.0)), aniso=dict(ks=(7, 21), sigmaX=(0.2, 3.0), sigmaY=(0.2, 3.0), angle=(-180, 180)),
+                 sinc=dict(ks=(7, 21))),
+    "blur2": dict(enabled=True, types={"sinc": 0.1, "iso": 0.58, "aniso": 0.32}, prob=0.8,
+                  iso=dict(ks=(7, 21), sigmaX=(0.2, 1.5)), aniso=dict(ks=(7, 21), sigmaX=(0.2, 1.5), sigmaY=(0.2, 1.5), angle=(-180, 180)),
+                  sinc=dict(ks=(7, 21))),
+    "final_blur": dict(enabled=True, prob=0.8, sinc=dict(ks=(7, 21))),
+    "resize": dict(enabled=True, prob={"up": 0.2, "down": 0.7, "keep": 0.1}, up=(1.0, 1.5), down=(0.15, 1.0), algos=("area", "linear", "cubic")),
+    "resize2": dict(enabled=True, prob={"up": 0.3, "down": 0.4, "keep": 0.3}, up=(1.0, 1.2), down=(0.3, 1.0), algos=("area", "linear", "cubic")),
+    "final_scale": dict(enabled=True, algos=("area", "linear", "cubic")),
+    "noise": dict(enabled=True, types=("gaussian", "poisson"), gaussian=dict(var=(1, 30), prob_color=0.6, multi=True),
+                  poisson=dict(scale=(0.05, 3.0), prob_color=0.6)),
+    "noise2": dict(enabled=True, types=("gaussian", "poisson"), gaussian=dict(var=(1, 25), prob_color=0.6, multi=True),
+                   poisson=dict(scale=(0.05, 2.5), prob_color=0.6)),
+    "compression": dict(enabled=True, quality=(30, 95)),
+    "final_compression": dict(enabled=True, quality=(30, 95)),
+    "shuffle": False,
 }
+_ALGO = {"area": "area", "linear": "linear", "bilinear": "linear", "cubic": "cubic", "bicubic": "cubic"}
+
+
+def _load_preset(path, kind):
+    import yaml
+    with open(path) as f:
+        doc = yaml.safe_load(f)
+    if doc.get("kind") != kind:
+        raise ValueError("preset %s: kind %r, expected %r" % (path, doc.get("kind"), kind))
+    return doc.get("config") or {}
+
+
+def degradation_config(dataset_opt=None, presets_root=None):
+    """The pipeline configuration of a train dataset with `augs_strategy: <name>` / `add_{blur,resize,noise}_preset` (reference:
+    options/options.py presets_names :148-165 and the merge :366-463): the built-in resrgan values, overlaid by the preset files
+    `<name>_{blur,resize,noise}.yaml` found under `presets_root` (default: `presets` next to the options file, as in the reference)
+    when they exist, overlaid by keys given directly in the dataset options (pipeline switches such as `lr_blur_types`, `blur_prob`,
+    `shuffle_degradations`, and per-type dictionaries under `aug_configs`).  Types the device pipeline does not implement raise."""
+    import copy
+    import os
+    ds = dict(dataset_opt or {})
+    cfg = copy.deepcopy(RESRGAN)
+    strat = ds.get("augs_strategy")
+    names = {k: ds.get("add_%s_preset" % k) or (("%s_%s" % (strat, k)) if strat else None) for k in ("blur", "resize", "noise")}
+    root = presets_root or ds.get("presets_root") or "presets"
+    raw = {}
+    for k, kind in (("blur", "Blur"), ("resize", "Resize"), ("noise", "Noise")):
+        path = os.path.join(root, "%s.yaml" % names[k]) if names[k] else None
+        if path and os.path.isfile(path):
+            raw[k] = _load_preset(path, kind)
+        elif names[k] and not str(names[k]).startswith("resrgan"):
+            raise NotImplementedError("preset %r not found under %r (only the resrgan values are built in)" % (names[k], root))
+        else:
+            raw[k] = {}
+    pipe = {}
+    for k in ("blur", "resize", "noise"):
+        pipe.update(raw[k].get("pipeline") or {})
+    aug = {}
+    for k in ("blur", "resize", "noise"):
+        aug.update({n: v for n, v in raw[k].items() if n != "pipeline"})
+    for n, v in (ds.get("aug_configs") or {}).items():           # per-type overrides from the options file
+        aug[n] = dict(aug.get(n) or {}, **(v or {}))
+    for n in ("lr_blur", "lr_blur_types", "blur_prob", "lr_blur2", "lr_blur_types2", "blur_prob2", "shuffle_degradations", "final_blur",
+              "final_blur_prob", "lr_downscale", "lr_downscale_types", "lr_downscale2", "lr_downscale_types2", "final_scale",
+              "final_scale_types", "lr_noise", "lr_noise_types", "lr_noise2", "lr_noise_types2", "compression", "final_compression"):
+        if n in ds and ds[n] is not None:
+            pipe[n] = ds[n]
+
+    def weights(v):
+        return {t: 1.0 for t in v} if isinstance(v, (list, tuple)) else dict(v)
+
+    def rng(v, default):
+        return default if v is None else (tuple(v) if isinstance(v, (list, tuple)) else (v, v))
+
+    for key, sw, tk, pk, sfx in (("blur", "lr_blur", "lr_blur_types", "blur_prob", ""), ("blur2", "lr_blur2", "lr_blur_types2", "blur_prob2", "2")):
+        c = cfg[key]
+        if sw in pipe:
+            c["enabled"] = bool(pipe[sw])
+        if tk in pipe and pipe[tk]:
+            c["types"] = weights(pipe[tk])
+        if pk in pipe:
+            c["prob"] = float(pipe[pk])
+        for t in c["types"]:
+            if t not in ("iso", "aniso", "sinc"):
+                raise NotImplementedError("blur type %r is not implemented by the device pipeline (iso / aniso / sinc)" % t)
+            a = aug.get(t + sfx) or {}
+            d = c[t]
+            if "kernel_size" in a or "min_kernel_size" in a:
+                d["ks"] = (int(a.get("min_kernel_size", d["ks"][0])), int(a.get("kernel_size", d["ks"][1])))
+            for src, dst in (("sigmaX", "sigmaX"), ("sigmaY", "sigmaY"), ("angle", "angle")):
+                if dst in d and a.get(src) is not None:
+                    d[dst] = rng(a[src], d[dst])
+    if "final_blur" in pipe:
+        cfg["final_blur"]["enabled"] = bool(pipe["final_blur"])
+        if pipe["final_blur"] and list(pipe["final_blur"]) != ["sinc"]:
+            raise NotImplementedError("final_blur %r: only [sinc] is implemented" % (pipe["final_blur"],))
+    if "final_blur_prob" in pipe:
+        cfg["final_blur"]["prob"] = float(pipe["final_blur_prob"])
+    for key, sw, tk in (("resize", "lr_downscale", "lr_downscale_types"), ("resize2", "lr_downscale2", "lr_downscale_types2")):
+        c = cfg[key]
+        if sw in pipe:
+            c["enabled"] = bool(pipe[sw])
+        if tk in pipe and pipe[tk]:
+            c["algos"] = tuple(_ALGO[str(t)] for t in pipe[tk])
+        a = aug.get(key) or {}
+        if a.get("resize_prob"):
+            c["prob"] = dict(a["resize_prob"])
+        c["up"], c["down"] = rng(a.get("resize_range_up"), c["up"]), rng(a.get("resize_range_down"), c["down"])
+    if "final_scale" in pipe:
+        cfg["final_scale"]["enabled"] = bool(pipe["final_scale"])
+    if pipe.get("final_scale_types"):
+        cfg["final_scale"]["algos"] = tuple(_ALGO[str(t)] for t in pipe["final_scale_types"])
+    for key, sw, tk, sfx in (("noise", "lr_noise", "lr_noise_types", ""), ("noise2", "lr_noise2", "lr_noise_types2", "2")):
+        c = cfg[key]
+        if sw in pipe:
+            c["enabled"] = bool(pipe[sw])
+        if tk in pipe and pipe[tk]:
+            c["types"] = tuple(pipe[tk])
+        for t in c["types"]:
+            if t not in ("gaussian", "poisson"):
+                raise NotImplementedError("noise type %r is not implemented by the device pipeline (gaussian / poisson)" % t)
+            a = aug.get(t + sfx) or {}
+            if t == "gaussian":
+                c[t]["var"] = rng(a.get("var_limit"), c[t]["var"])
+                c[t]["multi"] = bool(a.get("multi", c[t]["multi"]))
+            else:
+                c[t]["scale"] = rng(a.get("scale_range"), c[t]["scale"])
+            c[t]["prob_color"] = float(a.get("prob_color", c[t]["prob_color"]))
+    for key in ("compression", "final_compression"):
+        if key in pipe:
+            v = pipe[key]
+            cfg[key]["enabled"] = bool(v)
+            if v and list(v) != ["jpeg"]:
+                raise NotImplementedError("%s %r: only [jpeg] is implemented" % (key, v))
+        a = aug.get("jpeg") or {}
+        cfg[key]["quality"] = (int(a.get("min_quality", cfg[key]["quality"][0])), int(a.get("max_quality", cfg[key]["quality"][1])))
+    cfg["shuffle"] = bool(pipe.get("shuffle_degradations", cfg["shuffle"]))
+    return cfg
 
 
 class RealESRGANDegradation:
-    """HR batch [N,3,H,W] (device, fp32 in [0,1], RGB) -> LR batch [N,3,H/scale,W/scale]."""
+    """HR batch [N,3,H,W] (device, fp32 in [0,1], RGB) -> LR batch [N,3,H/scale,W/scale].
+
+    Two halves.  `plan(N, H, W)` draws, on the host and in the reference's order, every random decision of every sample and returns
+    one operation list per sample -- ("blur", kernel), ("resize", (h, w), algo), ("gaussian", sigma[3], grey, seed),
+    ("poisson", scale, grey, seed), ("jpeg", quality) -- following aug_pipeline (dataops/augmentations.py:1666-1801): blur -> resize ->
+    noise -> compression -> blur2 -> resize2 -> noise2 (shuffled as a whole when `shuffle_degradations`), then final compression and
+    final resize (+ sinc) in random order.  `run(hr, plans)` executes the lists on the device: operations at the same position that
+    agree in kind and tensor shape across samples -- always the first blur over the full-size HR batch, the most expensive stage --
+    run as ONE launch with per-sample parameters; after the random resizes the shapes differ and the rest runs per sample."""
 
     def __init__(self, scale=4, preset=None, seed=0):
         self.scale = int(scale)
-        self.p = dict(RESRGAN if preset is None else preset)
+        self.p = degradation_config() if preset is None else preset
         self.rs = np.random.RandomState(seed)
         self.calls = 0
 
     # ---- parameter draws (per sample, like the reference's per-sample pipeline)
+    def _sinc_kernel(self, conf):
+        rs = self.rs
+        lo, hi = conf["ks"]
+        ks = int(rs.randint(lo, hi))              # RandomSincBlur.get_params (transforms.py:2619-2640): randint(lo, hi), forced odd
+        ks += 1 - ks % 2
+        return sinc_kernel(rs.uniform(math.pi / 3 if ks < 13 else math.pi / 5, math.pi), ks)
+
     def _blur_kernel(self, conf):
         rs = self.rs
-        kind = rs.choice(list(conf["types"]), p=np.array(list(conf["types"].values())) / sum(conf["types"].values()))
-        lo, hi = conf["ks"]
-        if kind == "sinc":                       # RandomSincBlur.get_params: randint(lo, hi), forced odd
-            ks = int(rs.randint(lo, hi))
-            ks += 1 - ks % 2
-            cutoff = rs.uniform(math.pi / 3 if ks < 13 else math.pi / 5, math.pi)
-            return sinc_kernel(cutoff, ks)
-        ks = int(rs.randint(lo, hi + 1))          # RandomAnIsoBlur.get_params: randint(lo, hi + 1), forced odd
+        kind = rs.choice(list(conf["types"]), p=np.array(list(conf["types"].values()), dtype=np.float64) / sum(conf["types"].values()))
+        if kind == "sinc":
+            return self._sinc_kernel(conf["sinc"])
+        c = conf[kind]
+        lo, hi = c["ks"]
+        ks = int(rs.randint(lo, hi + 1))          # RandomAnIsoBlur.get_params (transforms.py:2546-2571): randint(lo, hi + 1), forced odd
         ks += 1 - ks % 2
         ks = min(ks, KMAX)
-        sx = rs.uniform(*conf["sigma"])
+        sx = rs.uniform(*c["sigmaX"])
         if kind == "iso":
             return gaussian_kernel(ks, (sx, sx))
-        return gaussian_kernel(ks, (sx, rs.uniform(*conf["sigma"])), angle=rs.uniform(*conf["angle"]))
+        return gaussian_kernel(ks, (sx, rs.uniform(*c["sigmaY"])), angle=rs.uniform(*c["angle"]))
 
-    def _resize_factor(self, conf):
+    def _resize_op(self, conf, h, w):
         rs = self.rs
-        mode = rs.choice(list(conf["prob"]), p=np.array(list(conf["prob"].values())) / sum(conf["prob"].values()))
-        if mode == "up":
-            return rs.uniform(*conf["up"])
-        if mode == "down":
-            return rs.uniform(*conf["down"])
-        return 1.0
+        mode = rs.choice(list(conf["prob"]), p=np.array(list(conf["prob"].values()), dtype=np.float64) / sum(conf["prob"].values()))
+        f = rs.uniform(*conf["up"]) if mode == "up" else (rs.uniform(*conf["down"]) if mode == "down" else 1.0)
+        if f == 1.0:
+            return None
+        return ("resize", (max(int(round(h * f)), 1), max(int(round(w * f)), 1)), conf["algos"][rs.randint(len(conf["algos"]))])
 
-    def _noise(self, x, conf, seed):
+    def _noise_op(self, conf, seed):
         rs = self.rs
         kind = conf["types"][rs.randint(len(conf["types"]))]
-        grey = rs.rand() >= conf["prob_color"]
+        c = conf[kind]
+        grey = bool(rs.rand() >= c["prob_color"])
         if kind == "gaussian":
-            if conf["multi"] and rs.rand() > 0.66 and not grey:      # MC-AWGN a third of the time (transforms.py:1579-1586)
-                sig = [math.sqrt(rs.uniform(*conf["var"])) for _ in range(3)]
+            if c["multi"] and rs.rand() > 0.66 and not grey:          # MC-AWGN a third of the time (transforms.py:1579-1586)
+                sig = [math.sqrt(rs.uniform(*c["var"])) for _ in range(3)]
             else:
-                sig = [math.sqrt(rs.uniform(*conf["var"]))] * 3
-            add_gaussian_noise(x, [sig], [grey], seed)
+                sig = [math.sqrt(rs.uniform(*c["var"]))] * 3
+            return ("gaussian", sig, grey, seed)
+        return ("poisson", float(rs.uniform(*c["scale"])), grey, seed)
+
+    def _plan_one(self, H, W, seed):
+        p, rs = self.p, self.rs
+        ops, h, w = [], H, W
+
+        def stage(bkey, rkey, nkey, sd):
+            nonlocal h, w
+            if p[bkey]["enabled"] and rs.rand() < p[bkey]["prob"]:
+                ops.append(("blur", self._blur_kernel(p[bkey])))
+            if p[rkey]["enabled"]:
+                r = self._resize_op(p[rkey], h, w)
+                if r is not None:
+                    ops.append(r)
+                    h, w = r[1]
+            if p[nkey]["enabled"]:
+                ops.append(self._noise_op(p[nkey], sd))
+
+        stage("blur", "resize", "noise", seed + 1)
+        if p["compression"]["enabled"]:
+            ops.append(("jpeg", int(rs.randint(p["compression"]["quality"][0], p["compression"]["quality"][1] + 1))))
+        stage("blur2", "resize2", "noise2", seed + 2)
+        if p["shuffle"]:                                  # random.shuffle(transform_list) (augmentations.py:1749-1750)
+            order = rs.permutation(len(ops))
+            ops = [ops[i] for i in order]
+            h, w = H, W
+            fixed = []
+            for op in ops:                                # a resize target was drawn as a FACTOR of its input: re-derive the sizes
+                if op[0] == "resize":
+                    raise NotImplementedError("shuffle_degradations with in-pipeline resizes is not implemented by the device pipeline")
+                fixed.append(op)
+            ops = fixed
+        final_c = [("jpeg", int(rs.randint(p["final_compression"]["quality"][0], p["final_compression"]["quality"][1] + 1)))] \
+            if p["final_compression"]["enabled"] else []
+        final_r = []
+        if p["final_scale"]["enabled"]:
+            final_r.append(("resize", (H // self.scale, W // self.scale), p["final_scale"]["algos"][rs.randint(len(p["final_scale"]["algos"]))]))
+            if p["final_blur"]["enabled"] and rs.rand() < p["final_blur"]["prob"]:
+                final_r.append(("blur", self._sinc_kernel(p["final_blur"]["sinc"])))
+        elif (h, w) != (H // self.scale, W // self.scale):
+            raise ValueError("final_scale is off but the pipeline does not end at the LR size")
+        if final_c and rs.rand() < 0.5:                   # compression then resize (+ sinc), or the other way round (augmentations.py:1779-1784)
+            ops += final_c + final_r
         else:
-            add_poisson_noise(x, [rs.uniform(*conf["poisson_scale"])], [grey], seed)
+            ops += final_r + final_c
+        return ops
+
+    def plan(self, N, H, W):
+        self.calls += 1
+        return [self._plan_one(H, W, (self.calls << 20) + n * 16) for n in range(N)]
+
+    # ---- execution
+    @staticmethod
+    def _apply(x, ops):
+        """x [n,3,h,w]; ops: one operation per image of x, all of the same kind (and target size)."""
+        kind = ops[0][0]
+        if kind == "blur":
+            return filter2d(x, [o[1] for o in ops])
+        if kind == "resize":
+            algos = {o[2] for o in ops}
+            if len(algos) == 1:
+                return resize(x, ops[0][1], ops[0][2])
+            return torch.cat([resize(x[i:i + 1], o[1], o[2]) for i, o in enumerate(ops)], 0)
+        x = x.clamp_(0, 1) if kind == "jpeg" else x
+        for i, o in enumerate(ops):        # noise / jpeg: in place, per-image parameters (seeds are per sample)
+            xi = x[i:i + 1]
+            if kind == "gaussian":
+                add_gaussian_noise(xi, [o[1]], [o[2]], o[3])
+            elif kind == "poisson":
+                add_poisson_noise(xi, [o[1]], [o[2]], o[3])
+            else:
+                jpeg(xi, [o[1]])
         return x
 
-    def _round(self, x, bkey, rkey, nkey, seed):
-        p, rs = self.p, self.rs
-        if rs.rand() < p[bkey]["prob"]:
-            x = filter2d(x, [self._blur_kernel(p[bkey])])
-        f = self._resize_factor(p[rkey])
-        if f != 1.0:
-            H, W = x.shape[2:]
-            x = resize(x, (max(int(round(H * f)), 1), max(int(round(W * f)), 1)), p[rkey]["algos"][rs.randint(len(p[rkey]["algos"]))])
-        x = self._noise(x, p[nkey], seed)
-        return x
+    def run(self, hr, plans):
+        N, C, H, W = hr.shape
+        out = torch.empty((N, 3, H // self.scale, W // self.scale), dtype=torch.float32, device=hr.device)
+        # leading operations shared by the whole batch (same kind, same shapes) run as one launch each
+        x, pos = hr.contiguous().clone(), 0
+        while all(len(pl) > pos for pl in plans) and len({pl[pos][0] for pl in plans}) == 1 and \
+                (plans[0][pos][0] != "resize" or len({pl[pos][1] for pl in plans}) == 1):
+            x = self._apply(x, [pl[pos] for pl in plans])
+            pos += 1
+        for n, pl in enumerate(plans):
+            xn = x[n:n + 1].contiguous()
+            for op in pl[pos:]:
+                xn = self._apply(xn, [op])
+            if tuple(xn.shape[2:]) != tuple(out.shape[2:]):
+                raise hip.HipEngineError("degradation plan ended at %s, expected %s" % (tuple(xn.shape[2:]), tuple(out.shape[2:])))
+            out[n] = xn[0].clamp_(0, 1)
+        return out
 
     def __call__(self, hr):
         hip.require_device(hr)
         N, C, H, W = hr.shape
         if C != 3 or H % self.scale or W % self.scale:
             raise ValueError("degradation expects RGB batches with sizes divisible by the scale")
-        p, rs = self.p, self.rs
-        out = torch.empty((N, 3, H // self.scale, W // self.scale), dtype=torch.float32, device=hr.device)
-        self.calls += 1
-        for n in range(N):
-            seed = (self.calls << 20) + n * 16
-            x = hr[n:n + 1].contiguous().clone()
-            x = self._round(x, "blur", "resize", "noise", seed + 1)
-            jpeg(x, [int(rs.randint(p["jpeg"][0], p["jpeg"][1] + 1))])
-            x = self._round(x, "blur2", "resize2", "noise2", seed + 2)
-            algo = p["final_algos"][rs.randint(len(p["final_algos"]))]
-            final_sinc = rs.rand() < p["final_sinc_prob"]
-            q = int(rs.randint(p["jpeg"][0], p["jpeg"][1] + 1))
-
-            def final_resize(t):
-                t = resize(t, (H // self.scale, W // self.scale), algo)
-                if final_sinc:
-                    ks = int(rs.randint(7, 21))
-                    ks += 1 - ks % 2
-                    t = filter2d(t, [sinc_kernel(rs.uniform(math.pi / 3 if ks < 13 else math.pi / 5, math.pi), ks)])
-                return t
-
-            if rs.rand() < 0.5:                  # jpeg then resize(+sinc), or the other way round (augmentations.py:1779-1784)
-                x = final_resize(jpeg(x, [q]))
-            else:
-                x = jpeg(final_resize(x).clamp_(0, 1), [q])
-            out[n] = x[0].clamp_(0, 1)
-        return out
+        return self.run(hr, self.plan(N, H, W))

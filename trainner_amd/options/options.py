@@ -97,6 +97,12 @@ def parse_datasets(opt, scale=1):
             ds["subset_file"] = os.path.normpath(os.path.expanduser(ds["subset_file"]))
         if phase == "train" and scale != 1 and not ds.get("pre_crop", None) and not ds.get("preprocess"):
             ds["preprocess"] = "crop"
+        if phase == "train" and (ds.get("augs_strategy") or any(ds.get("add_%s_preset" % k) for k in ("blur", "resize", "noise"))):
+            # presets overlay (options.py:148-165,366-463): the merged degradation configuration of the device pipeline
+            # (dataops/degradations.degradation_config reads <presets_root>/<name>_{blur,resize,noise}.yaml and the dataset's overrides)
+            from ..dataops.degradations import degradation_config
+            ds["presets_root"] = opt.get("presets_root", None) or ds.get("presets_root", None) or "presets"
+            ds["degradation"] = degradation_config(ds, ds["presets_root"])
         ds.setdefault("resize_strat", "pre")
         if ds.get("tensor_shape", None):
             opt["tensor_shape"] = ds["tensor_shape"]
