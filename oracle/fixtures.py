@@ -132,12 +132,16 @@ def i2i_batches(fx):
 def i2i_oracle_for(fx):
     from . import i2i_oracle
     y, st = fx["spec"]["yaml"], i2i_initial_states(fx)
-    common = dict(n_blocks=fx["network_G"]["n_blocks"], norm=fx["network_G"]["norm_type"], gan_type=y.get("gan_type", "vanilla"),
+    common = dict(n_blocks=fx["network_G"].get("n_blocks"), norm=fx["network_G"]["norm_type"], gan_type=y.get("gan_type", "vanilla"),
                   pixel_weight=y["pixel_weight"])
     if y["model"] == "pix2pix":
-        return i2i_oracle.OraclePix2PixStep(st["G"], st["D"], **common)
-    return i2i_oracle.OracleCycleGANStep(st["G_A"], st["G_B"], st["D_A"], st["D_B"], lambda_identity=y.get("lambda_identity"),
-                                         pool_size=y.get("pool_size", 0), **common)
+        orc = i2i_oracle.OraclePix2PixStep(st["G"], st["D"], **common)
+    else:
+        orc = i2i_oracle.OracleCycleGANStep(st["G_A"], st["G_B"], st["D_A"], st["D_B"], lambda_identity=y.get("lambda_identity"),
+                                            pool_size=y.get("pool_size", 0), **common)
+    if fx["network_G"]["type"] == "unet_net":
+        orc.arch, orc.num_downs = "unet_net", fx["network_G"]["num_downs"]
+    return orc
 
 
 def norm_shadowed_biases(keys, norm_type):

@@ -109,3 +109,121 @@ def gates_of_vgg(saved):
             xi = xin.dense().permute(0, 3, 1, 2).detach().cpu().contiguous()
             pools[name] = F.max_pool2d(xi, 2, 2, return_indices=True)[1]
     return relu, pools
+
+
+# --------------------------------------------------------------------------------------
+# The whole step with pinned gates (tests/test_gpu_step.py::test_step_gate_pinned_fp64_trajectory)
+# --------------------------------------------------------------------------------------
+def gates_of_rrdbnet(saved, nf=64, gc=32):
+    """LeakyReLU gates of trainner_amd's RRDBNet (upconv) from its saved activations: every dense block is one [N,H,W,nf+4gc] NHWC
+    buffer whose channel groups 1..4 hold x1..x4 AFTER the activation; the up-sampling stages and HR_conv0 keep theirs."""
+    g = {"rdb": [], "up": [], "hr0": None}
+    for buf in saved["bufs"]:
+        t = buf.detach().cpu()
+        g["rdb"].append([t[..., nf + gc * k: nf + gc * (k + 1)].permute(0, 3, 1, 2) > 0 for k in range(4)])
+    for _src, dst, _t in saved["stages"]:
+        g["up"].append(dst.dense().permute(0, 3, 1, 2).detach().cpu() > 0)
+    g["hr0"] = saved["h0"].dense().permute(0, 3, 1, 2).detach().cpu() > 0
+    return g
+
+
+def rrdbnet_forward_gated(lr, sd, nb, gates, upscale=4):
+    """sr_oracle.rrdbnet_forward (upconv) in the dtype of lr / sd with every LeakyReLU branch taken from `gates`."""
+    import math
+    n_up = int(math.log(upscale, 2))
+    fea = O._conv(lr, sd, "model.0")
+    t = fea
+    i = 0
+    for b in range(nb):
+        x_rrdb = t
+        for r in (1, 2, 3):
+            pre, x0 = "model.1.sub.%d.RDB%d" % (b, r), t
+            feats = [x0]
+            for k in range(1, 5):
+                feats.append(_gate(O._conv(torch.cat(feats, 1), sd, "%s.conv%d.0" % (pre, k)), gates["rdb"][i][k - 1], O.LRELU))
+            t = O._conv(torch.cat(feats, 1), sd, pre + ".conv5.0") * 0.2 + x0
+            i += 1
+        t = t * 0.2 + x_rrdb
+    y = fea + O._conv(t, sd, "model.1.sub.%d" % nb)
+    idx = 2
+    for u in range(n_up):
+        y = F.interpolate(y, scale_factor=2.0, mode="nearest")
+        y = _gate(O._conv(y, sd, "model.%d" % (idx + 1)), gates["up"][u], O.LRELU)
+        idx += 3
+    y = _gate(O._conv(y, sd, "model.%d" % idx), gates["hr0"], O.LRELU)
+    return O._conv(y, sd, "model.%d" % (idx + 2))
+
+
+def _bn_batch_stats(x, sd, size, base_nf, gates, eps=1e-5):
+    """Per BatchNorm layer of Discriminator_VGG: (batch mean, UNBIASED batch variance) of its input in one gated forward."""
+    convs, _nc, _cur = O.disc_vgg_layout(size, base_nf)
+    stats = {}
+    for (i, _cin, _cout, k, s, bn), g in zip(convs, gates):
+        x = O._conv(x, sd, "features.%d" % i, stride=s, pad=1)
+        if bn:
+            p = "features.%d" % (i + 1)
+            n = x.numel() // x.shape[1]
+            stats[p] = (x.mean((0, 2, 3)).detach(), (x.var((0, 2, 3), unbiased=False) * n / (n - 1)).detach())
+            x = F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, eps)
+        x = _gate(x, g, O.LRELU)
+    return stats
+
+
+def adam64(p, g, m, v, t, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """One torch.optim.Adam update (optimizers.py:130-132 defaults) in float64; returns (p, m, v)."""
+    import math
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    denom = v.sqrt() / math.sqrt(1 - b2 ** t) + eps
+    return p - (lr / (1 - b1 ** t)) * m / denom, m, v
+
+
+def gated_step64(LR, HR, g_sd, d_sd, f_sd, gates, adam_state, *, nb, d_size, d_nf, pixel_weight=1e-2, feature_weight=1.0,
+                 gan_weight=5e-3, grad_clip=0.1, lr=1e-4):
+    """SRModel.optimize_parameters (models/sr_model.py:195-267; the ESRGAN recipe as in sr_oracle.OracleSRStep) evaluated in float64
+    from the GIVEN state -- parameters g_sd / d_sd / f_sd, Adam moments and step counts in adam_state = {"G": (m, v, t), "D": ...} --
+    with every piecewise-linear branch (LeakyReLU of G and D, ReLU and max-pool winners of VGG on the generated image) taken from
+    `gates` = {"G": .., "D_fake": (gates, hid), "D_real": (gates, hid), "F_fake": (relu, pools)}, the branches the implementation
+    under test took.  Returns logs, fake_H, the clipped G gradients, the D gradients, the updated parameters and moments, and the
+    BatchNorm batch statistics of the two discriminator inputs."""
+    dd = torch.float64
+    G = {k: v.detach().to(dd).clone().requires_grad_(True) for k, v in g_sd.items()}
+    D = {k: (v.detach().to(dd).clone().requires_grad_(O._is_param(k)) if v.is_floating_point() else v.clone()) for k, v in d_sd.items()}
+    Fs = {k: v.detach().to(dd) for k, v in f_sd.items()}
+    LR, HR = LR.to(dd), HR.to(dd)
+    log = {}
+    fake = rrdbnet_forward_gated(LR, G, nb, gates["G"])
+    l_pix = pixel_weight * F.l1_loss(fake, HR)
+    fx = vgg19_conv54_gated(fake, Fs, *gates["F_fake"])
+    fy = O.vgg19_conv54(HR, Fs)                                    # no gradient flows through the real branch
+    l_fea = F.l1_loss(fx, fy.detach()) * feature_weight
+    dfix = {k: (v.detach() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in D.items()}     # D frozen in the G stage
+    pf = disc_vgg_forward_gated(fake, dfix, d_size, d_nf, *gates["D_fake"])
+    pr = disc_vgg_forward_gated(HR, dfix, d_size, d_nf, *gates["D_real"])
+    l_gan = gan_weight * O.ragan_g_loss(pf, pr)
+    log["pix-l1"], log["fea-vgg19-l1"], log["l_g_gan"] = l_pix.item(), l_fea.item(), l_gan.item()
+    gk = list(G.keys())
+    gg = list(torch.autograd.grad(l_pix + l_fea + l_gan, [G[k] for k in gk]))
+    total = torch.sqrt(sum((g ** 2).sum() for g in gg))
+    coef = torch.clamp(grad_clip / (total + 1e-6), max=1.0)
+    gg = [g * coef for g in gg]
+    mG, vG, tG = adam_state["G"]
+    newG, newmG, newvG = {}, {}, {}
+    for k, g in zip(gk, gg):
+        newG[k], newmG[k], newvG[k] = adam64(G[k].detach(), g, mG[k].to(dd), vG[k].to(dd), tG + 1, lr)
+    # ---- D stage on the detached fake, D parameters as before the step (the G update does not touch them)
+    dk = [k for k in D if O._is_param(k)]
+    pf = disc_vgg_forward_gated(fake.detach(), D, d_size, d_nf, *gates["D_fake"])
+    pr = disc_vgg_forward_gated(HR, D, d_size, d_nf, *gates["D_real"])
+    l_real, l_fake = O.ragan_d_loss(pf, pr)
+    log["l_d_real"], log["l_d_fake"] = l_real.item(), l_fake.item()
+    log["D_real"], log["D_fake"] = pr.detach().mean().item(), pf.detach().mean().item()
+    dg = list(torch.autograd.grad((l_fake + l_real) * 0.5, [D[k] for k in dk]))
+    mD, vD, tD = adam_state["D"]
+    newD, newmD, newvD = {}, {}, {}
+    for k, g in zip(dk, dg):
+        newD[k], newmD[k], newvD[k] = adam64(D[k].detach(), g, mD[k].to(dd), vD[k].to(dd), tD + 1, lr)
+    stats = {"fake": _bn_batch_stats(fake.detach(), dfix, d_size, d_nf, gates["D_fake"][0]),
+             "real": _bn_batch_stats(HR, dfix, d_size, d_nf, gates["D_real"][0])}
+    return dict(log=log, fake=fake.detach(), g_grads=dict(zip(gk, gg)), d_grads=dict(zip(dk, dg)), G=newG, D=newD,
+                mG=newmG, vG=newvG, mD=newmD, vD=newvD, bn=stats)

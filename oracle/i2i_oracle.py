@@ -11,7 +11,7 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
-from .sr_oracle import Adam, _is_param, patchgan_forward, resnet_generator_forward
+from .sr_oracle import Adam, _is_param, patchgan_forward, resnet_generator_forward, unet_generator_forward
 
 
 def gan_label_loss(pred, target_is_real, gan_type):
@@ -60,7 +60,11 @@ class _I2IBase:
         self.nb, self.norm, self.gan_type, self.pw, self.lr, self.b1 = n_blocks, norm, gan_type, pixel_weight, lr, beta1
         self.log = OrderedDict()
 
+    arch, num_downs = "resnet_net", None          # generator: ResnetGenerator (n_blocks) or UnetGenerator (num_downs)
+
     def G(self, net, x):
+        if self.arch == "unet_net":
+            return unet_generator_forward(x, net.sd, self.num_downs, self.norm)
         return resnet_generator_forward(x, net.sd, self.nb, self.norm)
 
     def D(self, net, x):

@@ -26,6 +26,10 @@ CASES = {
     # the same with a BatchNorm generator and lsgan
     "pix2pix_rn1_bn_lsgan": dict(yaml=dict(model="pix2pix", batch=2, crop=64, n_blocks=1, ngf=16, ndf=16, norm_G="batch",
                                            gan_type="lsgan", pixel_weight=100.0), steps=2, seed=82),
+    # the SHIPPED Pix2Pix recipe's generator (options/i2i/train_pix2pix.yml:65: which_model_G unet_net): UnetGenerator with 7
+    # down-samplings (unet_128: 128 x 128 down to 1 x 1), BatchNorm, deconv up-sampling, conditional PatchGAN
+    "pix2pix_unet128": dict(yaml=dict(model="pix2pix", batch=2, crop=128, ngf=16, ndf=16, norm_G="batch", pixel_weight=100.0,
+                                      which_G="unet_128"), steps=3, seed=85),
     # CycleGAN: identity terms, image pools that fill during step 1-2 and draw from step 3 on, lsgan
     "cyclegan_rn2_crop64": dict(yaml=dict(model="cyclegan", batch=2, crop=64, n_blocks=2, ngf=16, ndf=16, gan_type="lsgan",
                                           pixel_weight=10.0, lambda_identity=0.5, pool_size=4), steps=5, seed=83),

@@ -120,7 +120,7 @@ def reference_netF(model):
 
 def i2i_yaml(name="oracle_i2i", model="pix2pix", batch=2, crop=64, n_blocks=2, ngf=16, ndf=16, norm_G="instance",
              gan_type="vanilla", pixel_weight=100.0, lambda_identity=None, pool_size=0, out_root=None, gpu_ids="[]",
-             lr_scheme="MultiStepLR", amp=False):
+             lr_scheme="MultiStepLR", amp=False, which_G="resnet_net"):
     """A train_pix2pix.yml / train_cyclegan.yml-shaped config (codes/options/i2i/train_pix2pix.yml:1-143,
     train_cyclegan.yml:1-140) with the ResNet generator + PatchGAN of BASELINE.json configs[4], for CPU."""
     out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
@@ -145,7 +145,10 @@ def i2i_yaml(name="oracle_i2i", model="pix2pix", batch=2, crop=64, n_blocks=2, n
         "    n_workers: 0", "    batch_size: %d" % batch, "    virtual_batch_size: %d" % batch,
         "    preprocess: crop", "    crop_size: %d" % crop, "    image_channels: 3", "    input_nc: 3", "    output_nc: 3",
         "path:", "  root: %s" % out_root,
-        "network_G:", "  which_model_G: resnet_net", "  n_blocks: %d" % n_blocks, "  ngf: %d" % ngf, "  norm_type: %s" % norm_G,
+        *(["network_G:", "  which_model_G: resnet_net", "  n_blocks: %d" % n_blocks, "  ngf: %d" % ngf, "  norm_type: %s" % norm_G]
+          if which_G == "resnet_net" else
+          # the shipped Pix2Pix recipe's generator (options/i2i/train_pix2pix.yml:65): unet_128 = 7 down-samplings, crop 128
+          ["network_G:", "  which_model_G: %s" % which_G, "  ngf: %d" % ngf, "  norm_type: %s" % norm_G]),
         "network_D:", "  which_model_D: patchgan", "  in_nc: %d" % d_in, "  nf: %d" % ndf,
         "train:", *train,
         "logger:", "  print_freq: 1", "  save_checkpoint_freq: 1000000", ""])

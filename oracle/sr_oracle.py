@@ -186,6 +186,36 @@ def resnet_generator_forward(x, sd, n_blocks, norm="instance"):
     return torch.tanh(conv(F.pad(h, (3,) * 4, mode="reflect"), i + 7))
 
 
+def unet_generator_forward(x, sd, num_downs, norm="batch"):
+    """UnetGenerator.forward (models/modules/architectures/UNet_arch.py:11-162, deconv up-sampling, no dropout): nested blocks
+    x -> cat[x, up(sub(down(x)))] with down = LeakyReLU(0.2) -> Conv2d(k4, s2, p1) -> norm and up = ReLU -> ConvTranspose2d(k4, s2,
+    p1) -> norm (outermost: no activation / norm going down, bias + Tanh coming up; innermost: no norm going down).  Both
+    activations are in place (:106,108), so the x a block concatenates is the ACTIVATED one.  Keys as in the reference
+    (`model.model.<i>...`)."""
+    def block(t, pre, level):
+        outer, inner = level == 0, level == num_downs - 1
+        if outer:
+            h = F.conv2d(t, sd[pre + ".0.weight"], sd.get(pre + ".0.bias"), stride=2, padding=1)
+            h = block(h, pre + ".1.model", level + 1)
+            h = F.relu(h)
+            return torch.tanh(F.conv_transpose2d(h, sd[pre + ".3.weight"], sd.get(pre + ".3.bias"), stride=2, padding=1))
+        a = F.leaky_relu(t, LRELU)                          # in place in the reference: this is also what gets concatenated
+        h = F.conv2d(a, sd[pre + ".1.weight"], sd.get(pre + ".1.bias"), stride=2, padding=1)
+        if inner:
+            h = F.relu(h)
+            h = F.conv_transpose2d(h, sd[pre + ".3.weight"], sd.get(pre + ".3.bias"), stride=2, padding=1)
+            h = _norm2d(h, sd, pre + ".4", norm)
+        else:
+            h = _norm2d(h, sd, pre + ".2", norm)
+            h = block(h, pre + ".3.model", level + 1)
+            h = F.relu(h)
+            h = F.conv_transpose2d(h, sd[pre + ".5.weight"], sd.get(pre + ".5.bias"), stride=2, padding=1)
+            h = _norm2d(h, sd, pre + ".6", norm)
+        return torch.cat([a, h], 1)
+
+    return block(x, "model.model", 0)
+
+
 def patchgan_forward(x, sd, n_layers=3):
     """NLayerDiscriminator.forward (discriminators.py:472-579), default configuration: conv4 s2 + LReLU; (n_layers - 1) x
     [conv4 s2 + BatchNorm + LReLU]; conv4 s1 + BatchNorm + LReLU; conv4 s1 -> 1 channel."""

@@ -112,3 +112,8 @@ def test_freezeD_layers_are_not_trained(tmp_path):
         assert torch.equal(before[k], after[k]), k
     moved = [k for k in before if k.endswith("weight") and k not in frozen and not torch.equal(before[k], after[k])]
     assert "features.5.weight" in moved and "classifier.2.weight" in moved
+
+
+def test_step_gate_pinned_fp64_trajectory(tmp_path):
+    """The gate-pinned float64 arbitration of three consecutive steps (tests/test_gpu_step.py) over the emulated C ABI."""
+    TS.test_step_gate_pinned_fp64_trajectory(tmp_path)

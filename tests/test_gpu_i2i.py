@@ -24,7 +24,8 @@ from oracle import detrand, fixtures as FX, ref_harness
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt"]
+I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt",
+             "pix2pix_unet128"]        # the shipped Pix2Pix recipe's U-Net generator (which_model_G: unet_net)
 
 
 def build_i2i_model(yaml_kw, tmp_path):

@@ -112,6 +112,107 @@ def test_step_matches_reference_golden_bf16x3(case, tmp_path, monkeypatch):
     assert ops.MMA == hip.MMA_BF16X3
 
 
+def test_step_gate_pinned_fp64_trajectory(tmp_path):
+    """Three consecutive G+D steps, each arbitrated by float64 with the engine's own gates (oracle/gated.gated_step64): before every
+    step the float64 side takes the engine's state (parameters, Adam moments and step counts, BatchNorm running statistics) and
+    re-computes the WHOLE step independently -- forward, the three losses, both backward passes, clip, Adam(G), Adam(D), the
+    BatchNorm statistics -- with every LeakyReLU / ReLU / max-pool branch pinned to the one the engine took.  The function is then
+    smooth, so steps 2 and 3 (non-zero moments, bias corrections, running statistics that moved) are held to round-off like
+    step 1: logs 2e-5 relative, the generated image 2e-5, moments 1e-4 of their scale, running statistics 1e-5 -- not the 3e-3 /
+    0.15 lr trajectory bounds of the K = 10 golden.  A systematic optimiser or BatchNorm error after the first step cannot hide."""
+    from oracle import gated
+    kw = dict(nb=2, batch=2, crop=64, d_nf=16)
+    opt, model = build_engine_model(kw, tmp_path)
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+    d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+    f = FX.vgg_state(77)
+    load_initial(model, g, d, f)
+    netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+    calls = []
+
+    def tap(net, tag):
+        inner = net.engine_forward
+
+        def wrapped(x, save):
+            out, saved = inner(x, save)
+            calls.append((tag, x.data_ptr(), saved))
+            return out, saved
+        net.engine_forward = wrapped
+
+    tap(model.netG, "G")
+    tap(model.netD, "D")
+    tap(netF, "F")
+    lr = 1e-4
+    d_keys = [(k, tuple(v.shape)) for k, v in model.netD.state_dict().items()]
+    # exactly-zero true gradients (noise-only updates): conv biases in front of a BatchNorm, and the last logit's bias -- the
+    # relativistic losses only see differences of logits (losses.py:428-433,503-512)
+    shadow = set(FX.bn_shadowed_biases(d_keys)) | {"classifier.2.bias"}
+    report = []
+    for s in (1, 2, 3):
+        gsd = {k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}
+        dsd = {k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}
+
+        def moments(optim, net):
+            m, v, t = {}, {}, 0
+            for k, p in net.named_parameters():
+                st = optim.state.get(p, {})
+                m[k] = st["exp_avg"].detach().cpu().clone() if "exp_avg" in st else torch.zeros_like(p, device="cpu")
+                v[k] = st["exp_avg_sq"].detach().cpu().clone() if "exp_avg_sq" in st else torch.zeros_like(p, device="cpu")
+                t = int(float(st["step"])) if "step" in st else 0
+            return m, v, t
+
+        state = {"G": moments(model.optimizer_G, model.netG), "D": moments(model.optimizer_D, model.netD)}
+        assert state["G"][2] == s - 1 and state["D"][2] == s - 1
+        LR, HR = detrand.synthetic_pair(2, 64, 90 + s)
+        del calls[:]
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+        log = model.get_current_log()
+        fake_ptr, real_ptr = model.fake_H.data_ptr(), model.var_ref.data_ptr()
+        by = {}
+        for tag, ptr, saved in calls:
+            if saved is not None:
+                by.setdefault((tag, "fake" if ptr == fake_ptr else ("real" if ptr == real_ptr else "in")), saved)
+        gates = {"G": gated.gates_of_rrdbnet(by[("G", "in")]), "D_fake": gated.gates_of_discriminator(by[("D", "fake")]),
+                 "D_real": gated.gates_of_discriminator(by[("D", "real")]), "F_fake": gated.gates_of_vgg(by[("F", "fake")])}
+        ref = gated.gated_step64(LR, HR, gsd, dsd, f, gates, state, nb=2, d_size=64, d_nf=16)
+        for k, v in ref["log"].items():
+            assert abs(log[k] - v) <= 2e-5 * max(1.0, abs(v)) + 1e-6, (s, k, log[k], v)
+        dfake = (model.fake_H.detach().cpu().double() - ref["fake"]).abs().max().item()
+        assert dfake < 2e-5, (s, dfake)
+        for name, net, optim, new, nm, nv, skip in (("G", model.netG, model.optimizer_G, ref["G"], ref["mG"], ref["vG"], ()),
+                                                    ("D", model.netD, model.optimizer_D, ref["D"], ref["mD"], ref["vD"], shadow)):
+            worst_m, worst_v, deltas = 0.0, 0.0, []
+            for k, p in net.named_parameters():
+                if k in skip:
+                    continue
+                st = optim.state[p]
+                ms = max(nm[k].abs().max().item(), 1e-30)
+                em = (st["exp_avg"].detach().cpu().double() - nm[k]).abs().max().item() / ms
+                assert em < 1e-4, (s, name, k, em, ms)
+                worst_m = max(worst_m, em)
+                worst_v = max(worst_v, (st["exp_avg_sq"].detach().cpu().double() - nv[k]).abs().max().item() / max(nv[k].abs().max().item(), 1e-300))
+                deltas.append(((p.detach().cpu().double() - new[k]) / lr).abs().flatten())
+            dl = torch.cat(deltas)
+            report.append((s, name, worst_m, worst_v, dl.mean().item(), (dl > 0.05).double().mean().item(), dl.max().item()))
+            # the moments are linear / quadratic in the gradient: round-off only
+            assert worst_m < 1e-4 and worst_v < 2e-4, report[-1]
+            # the update lr m^ / (sqrt(v^) + eps) is sign-like for elements whose gradient history is noise-sized: a vanishing fraction
+            assert dl.mean().item() < 2e-4 and (dl > 0.05).double().mean().item() < 2e-4 and dl.max().item() <= 2.05, report[-1]     # (measured: 2e-5, 1.5e-5)
+        # BatchNorm running statistics: four training-mode forwards per step (fake, real in the G stage; fake, real in the D stage)
+        for key in [k for k in dsd if k.endswith("running_mean")]:
+            pfx = key[:-len(".running_mean")]
+            rm, rv = dsd[key].double(), dsd[pfx + ".running_var"].double()
+            for which in ("fake", "real", "fake", "real"):
+                bm, bv = ref["bn"][which][pfx]
+                rm, rv = 0.9 * rm + 0.1 * bm, 0.9 * rv + 0.1 * bv
+            got_m = model.netD.state_dict()[key].detach().cpu().double()
+            got_v = model.netD.state_dict()[pfx + ".running_var"].detach().cpu().double()
+            assert (got_m - rm).abs().max().item() <= 1e-5 * max(1.0, rm.abs().max().item()), (s, key)
+            assert (got_v - rv).abs().max().item() <= 1e-5 * max(1.0, rv.abs().max().item()), (s, key)
+    print("gate-pinned trajectory (step, net, dm, dv, mean |dw|/lr, frac > 0.05 lr, max):", report)
+
+
 @pytest.mark.timeout(420)
 def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
     """ESRGAN RRDBNet-23 + Discriminator_VGG(512) + VGG19, 128 -> 512, batch 1: two live steps."""

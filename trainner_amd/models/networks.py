@@ -68,6 +68,9 @@ def get_network(opt, step=0, selector=None):
     elif kind == "resnet_net":
         from .modules.architectures import ResNet_arch
         net = ResNet_arch.ResnetGenerator
+    elif kind == "unet_net":
+        from .modules.architectures import UNet_arch
+        net = UNet_arch.UnetGenerator
     elif kind in ("patchgan", "nlayerdiscriminator"):
         from .modules.architectures import discriminators
         net = discriminators.NLayerDiscriminator

@@ -56,6 +56,18 @@ def get_network_G_config(network_G, scale, crop_size):
         full["convtype"] = src.pop("convtype", "Conv2D")
         full["finalact"] = src.pop("finalact", None)
         full["res_scale"] = src.pop("res_scale", 1)
+    elif "unet" in kind and "wbc" not in kind:            # pix2pix U-Net generator (defaults.py:194-217)
+        full["type"] = "unet_net"
+        full["input_nc"] = src.pop("in_nc", 3)
+        full["output_nc"] = src.pop("out_nc", 3)
+        full["num_downs"] = src.pop("num_downs", 7 if kind == "unet_128" else 8)
+        want = {7: 128, 8: 256, 9: 512}.get(full["num_downs"])
+        if want is not None:
+            assert crop_size == want, f"Invalid crop size {crop_size} for UNET config, must be {want}"
+        full["ngf"] = src.pop("ngf", 64)
+        full["norm_type"] = src.pop("norm_type", "batch")
+        full["use_dropout"] = src.pop("use_dropout", False)
+        full["upsample_mode"] = src.pop("upsample_mode", "deconv")
     elif "resnet" in kind and kind != "sr_resnet":        # image-to-image ResNet generator (defaults.py:218-234)
         full["type"] = "resnet_net"
         full["input_nc"] = src.pop("in_nc", 3)
