@@ -440,7 +440,7 @@ def main():
             "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "world_size_observed": model.dp.world_size,
+                       "world_size_observed": model.dp.observed_world_size(),
                        "mma": "bf16 operands (use_amp)" if args.amp else MMA_TEXT[args.mma],
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},

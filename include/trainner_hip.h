@@ -271,6 +271,8 @@ int tnr_dp_unique_id(void *id128);
 int tnr_dp_init(const void *id128, int32_t rank, int32_t world, void **comm);
 int tnr_dp_allreduce_bucket(void *comm, float *buf, int64_t count, int32_t average, void *stream);
 int tnr_dp_broadcast(void *comm, float *buf, int64_t count, int32_t root, void *stream);
+/* the communicator's own rank count (ncclCommCount): what bench.py reports as config.world_size_observed */
+int tnr_dp_comm_count(void *comm, int32_t *nranks);
 int tnr_dp_finalize(void *comm);
 /* Real-ESRGAN style degradations on fp32 NCHW images in [0, 1] (the LR synthesis the reference runs per sample with
  * OpenCV on DataLoader workers: dataops/augmentations.py:1666-1801, options/presets/resrgan_*.yaml).

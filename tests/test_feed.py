@@ -274,3 +274,90 @@ def test_memoized_discriminator_with_gradient_accumulation_through_the_feeder(tm
         assert torch.equal(da[k], db[k]), k
     for k in ga:
         assert torch.equal(ga[k], gb[k]), k
+
+
+def test_lmdb_dataset_reader(tmp_path, monkeypatch):
+    """`data_type: lmdb` (a dataroot ending in .lmdb, dataops/common.py:47-105): keys from meta_info.txt, values = encoded image files,
+    the environment opened read-only without lock / read-ahead / meminit (_init_lmdb).  Runs against the real `lmdb` module when it is
+    installed; otherwise an in-memory module with the same three calls (open, begin(write=False), get) stands in, so the reader's own
+    logic -- key list, lazy open, decode to BGR, windows, paired parameters -- is exercised either way."""
+    import io
+    import sys
+    import types
+    from PIL import Image
+    from trainner_amd.data.aligned_dataset import AlignedWindowDataset, LmdbSource
+    rs = np.random.RandomState(4)
+    imgs = {"%03d" % i: rs.randint(0, 256, (48, 64, 3), dtype=np.uint8) for i in range(3)}      # RGB as stored in the PNG files
+
+    def png(a):
+        b = io.BytesIO()
+        Image.fromarray(a, "RGB").save(b, format="PNG")
+        return b.getvalue()
+
+    try:
+        import lmdb as real
+    except ImportError:
+        real = None
+    stores = {}
+    for name, scale in (("hr.lmdb", 1), ("lr.lmdb", 4)):
+        root = tmp_path / name
+        root.mkdir()
+        vals = {k: png(v[::scale, ::scale].copy()) for k, v in imgs.items()}
+        (root / "meta_info.txt").write_text("".join("%s.png (%d,%d,3) 1\n" % (k, 48 // scale, 64 // scale) for k in imgs))
+        if real is not None:
+            env = real.open(str(root), map_size=1 << 24)
+            with env.begin(write=True) as txn:
+                for k, v in vals.items():
+                    txn.put(k.encode("ascii"), v)
+            env.close()
+        stores[str(root)] = vals
+    if real is None:
+        opened = []
+
+        class _Txn:
+            def __init__(self, vals):
+                self.vals = vals
+
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+            def get(self, key):
+                return self.vals.get(key.decode("ascii"))
+
+        class _Env:
+            def __init__(self, root):
+                self.vals = stores[root]
+
+            def begin(self, write=False):
+                assert write is False
+                return _Txn(self.vals)
+
+        fake = types.ModuleType("lmdb")
+
+        def _open(root, readonly=False, lock=True, readahead=True, meminit=True, **kw):
+            assert readonly and not lock and not readahead and not meminit            # _init_lmdb's flags
+            opened.append(root)
+            return _Env(root)
+
+        fake.open = _open
+        monkeypatch.setitem(sys.modules, "lmdb", fake)
+    src = LmdbSource(str(tmp_path / "hr.lmdb"))
+    assert len(src) == 3 and src.path(1) == "001"
+    assert np.array_equal(src.read(2), imgs["002"][:, :, ::-1])                         # decoded to BGR like cv2.imdecode
+    opt = dict(scale=4, crop_size=32, dataroot_HR=str(tmp_path / "hr.lmdb"), dataroot_LR=str(tmp_path / "lr.lmdb"), data_type="lmdb",
+               use_flip=True, use_rot=True)
+    ds = AlignedWindowDataset(opt)
+    random.seed(3)
+    d = ds[1]
+    random.seed(3)
+    from trainner_amd.data.aligned_dataset import paired_params
+    p = paired_params((16, 12), 8)
+    x, y = p["crop_pos"]
+    assert d["HR"].shape == (32, 32, 3) and d["LR"].shape == (8, 8, 3) and d["HR_path"] == "001"
+    assert np.array_equal(d["HR"], imgs["001"][:, :, ::-1][4 * y:4 * y + 32, 4 * x:4 * x + 32])
+    assert np.array_equal(d["LR"], imgs["001"][::4, ::4][:, :, ::-1][y:y + 8, x:x + 8])
+    with pytest.raises(ValueError):
+        LmdbSource(str(tmp_path))                                                        # not a .lmdb folder

@@ -1,0 +1,134 @@
+"""Data-parallel SRModel step over RCCL (-m gpu).  SURVEY.md 8(e): one process per GPU, bucketed gradient averaging on a side HIP
+stream, the relativistic global-mean exchange, rank-0 start-state broadcast, global-batch sharding of feed_data.
+
+  * test_rccl_ranks_equal_single_process[2]  two ranks on two GPUs against one process stepping the whole batch.  Needs >= 2 visible
+    devices: skipped on the 1-GPU boxes this repository is developed on, runs the day the driver's multi-GPU node collects the suite.
+  * test_rccl_ranks_equal_single_process[1]  the SAME worker in a 1-rank RCCL group (TNR_DP_SELFTEST=1): every collective is issued
+    (ncclAllReduce / ncclAvg on the side stream, broadcast, the 3-/4-float relativistic exchanges) and the dense-block launches fall
+    back to per-layer while buckets are in flight -- it validates the worker, the launcher and the communicator plumbing on one GPU.
+Both backends: torch.distributed's nccl (= RCCL) group, and the library's own tnr_dp_* entry points (TNR_DP_BACKEND=abi).
+The U-Net discriminator is used because it has no BatchNorm: per-replica batch statistics (nn.DataParallel semantics) would make a
+2-rank run differ from a 1-process run by design (tests/test_cpu_dp_step.py covers that case with chunked statistics).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(nb=1, batch=4, crop=64, d_nf=16, d_type="unet")
+STEPS = 2
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, {root!r})
+import torch
+from oracle import detrand, fixtures as FX, ref_harness
+from trainner_amd import dp as dpmod
+from trainner_amd.models import create_model
+from trainner_amd.options import options
+
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+dpmod.BUCKET_FLOATS = 100_000                      # several buckets per network, fired from inside backward
+kw, steps, out_dir = json.loads({kw!r}), {steps}, {out!r}
+yml = ref_harness.esrgan_yaml(name="dp_gpu", out_root=os.path.join(out_dir, "r%d" % rank), gpu_ids="[0]", **kw)
+model = create_model(options.parse(yml, is_train=True), verbose=False)
+# every rank loads DIFFERENT weights; sync_replicas must bring them to rank 0's
+seed_g, seed_d = (101, 202) if rank == 0 else (555 + rank, 666 + rank)
+model.netG.load_state_dict(detrand.fill_state_dict_({{k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}}, seed_g))
+model.netD.load_state_dict(detrand.fill_state_dict_({{k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}}, seed_d))
+netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+sd = netF.state_dict(); sd.update(FX.vgg_state(77)); netF.load_state_dict(sd)
+expect_active = world > 1 or os.environ.get("TNR_DP_SELFTEST") == "1"
+assert model.dp.active == expect_active and model.dp.world_size == world, (model.dp.active, model.dp.world_size)
+observed = model.dp.observed_world_size()
+model.sync_replicas()
+logs = []
+for s in range(1, steps + 1):
+    LR, HR = detrand.synthetic_pair(kw["batch"], kw["crop"], 70 + s)      # every rank is fed the GLOBAL batch
+    model.feed_data({{"LR": LR, "HR": HR}})
+    model.optimize_parameters(s)
+    logs.append(dict(model.get_current_log()))
+torch.save(dict(logs=logs, fake=model.fake_H.detach().cpu(), observed=observed, backend=os.environ.get("TNR_DP_BACKEND", "torch"),
+                g={{k: v.detach().cpu() for k, v in model.netG.state_dict().items()}},
+                d={{k: v.detach().cpu() for k, v in model.netD.state_dict().items()}}), os.path.join(out_dir, "rank%d.pt" % rank))
+model.dp.finalize()
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+'''
+
+
+def _launch(tmp_path, world, backend, mma):
+    out = tmp_path / ("w%d_%s" % (world, backend))
+    out.mkdir()
+    script = out / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, kw=json.dumps(KW), steps=STEPS, out=str(out)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TNR_DP_BACKEND"] = backend
+    env["TNR_MMA"] = mma or "bf16x3"                  # the workers compute in the arithmetic this test instance runs in
+    if world == 1:
+        env["TNR_DP_SELFTEST"] = "1"
+    port = 29500 + (os.getpid() + world * 7 + (13 if backend == "abi" else 0)) % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return [torch.load(str(out / ("rank%d.pt" % k)), weights_only=False) for k in range(world)]
+
+
+def _single_process(tmp_path):
+    import test_gpu_step as TS
+    from oracle import detrand, fixtures as FX
+    (tmp_path / "one").mkdir()
+    opt, model = TS.build_engine_model(KW, tmp_path / "one")
+    assert not model.dp.active
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+    d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+    TS.load_initial(model, g, d, FX.vgg_state(77))
+    logs = []
+    for s in range(1, STEPS + 1):
+        LR, HR = detrand.synthetic_pair(KW["batch"], KW["crop"], 70 + s)
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(s)
+        logs.append(dict(model.get_current_log()))
+    return dict(logs=logs, fake=model.fake_H.detach().cpu(), g={k: v.detach().cpu() for k, v in model.netG.state_dict().items()},
+                d={k: v.detach().cpu() for k, v in model.netD.state_dict().items()})
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("backend", ["torch", "abi"])
+@pytest.mark.parametrize("world", [1, 2])
+def test_rccl_ranks_equal_single_process(world, backend, tmp_path, mma_mode):
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d visible GPUs (this box has %d)" % (world, torch.cuda.device_count()))
+    one = _single_process(tmp_path)
+    res = _launch(tmp_path, world, backend, mma_mode)
+    per, lr_steps = KW["batch"] // world, 1e-4 * STEPS
+    for r, out in enumerate(res):
+        assert out["observed"] == world and out["backend"] == backend          # the communicator's own rank count
+        for s in range(STEPS):
+            for k, v in one["logs"][s].items():
+                # every log entry is a global-batch quantity on every rank (G losses are all-reduced means)
+                assert abs(out["logs"][s][k] - v) <= 1e-4 * abs(v) + 2e-6, (r, s, k, out["logs"][s][k], v)
+        diff = (out["fake"] - one["fake"][r * per:(r + 1) * per]).abs().max().item()
+        assert diff <= 2e-5, ("fake_H", r, diff)
+        for name, mine, ref in (("G", out["g"], one["g"]), ("D", out["d"], one["d"])):
+            tot, cnt, worst = 0.0, 0, 0.0
+            for k, v in ref.items():
+                if not v.is_floating_point():
+                    continue
+                dd = (mine[k] - v).abs() / lr_steps
+                tot, cnt, worst = tot + dd.sum().item(), cnt + dd.numel(), max(worst, dd.max().item())
+            # Adam's first steps are sign-like: noise-gradient elements may move +-lr either way -> mean tight, worst loose
+            assert tot / cnt < 2e-3 and worst <= 1.05, (name, r, worst, tot / cnt)
+    for r in range(1, world):                  # all replicas hold identical weights after the steps
+        for k, v in res[0]["g"].items():
+            assert torch.equal(v, res[r]["g"][k]), k
+        for k, v in res[0]["d"].items():
+            assert torch.equal(v, res[r]["d"][k]), k

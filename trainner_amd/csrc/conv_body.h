@@ -21,8 +21,10 @@ __device__ __forceinline__ tnr_bf16x8 tnr_pack_bf16(const f32x4 lo, const f32x4 
 // fp32 on the bf16 matrix core, exactly split: x = hi + mid + lo with three bf16 values (8 + 8 + 8 significand bits; every
 // residual is computed exactly in fp32).  A product a b = sum of 9 partial products a_i b_j, each EXACT in the fp32 accumulator's
 // input; the three smallest (mid lo, lo mid, lo lo: together < 2^-23 |a b| by construction, 2^-24.3 at most and 2^-28 on average over
-// 2 M random pairs, tests/test_cpu_bf16x3.py) are dropped -- on average 6x below the rounding error of one fp32 multiply.  Six v_mfma_f32_32x32x16_bf16 (k = 16) replace sixteen v_mfma_f32_32x32x2_f32: 192 instead of 1024 matrix-core
-// cycles per 32 x 32 x 16 block.  (tnr_conv_desc.mma = TNR_MMA_BF16X3.)
+// 2 M random pairs, tests/test_cpu_bf16x3.py) are dropped -- on average 6x below the rounding error of one fp32 multiply.  Six
+// v_mfma_f32_32x32x16_bf16 (k = 16, 32 cycles each) replace EIGHT v_mfma_f32_32x32x2_f32 (k = 2, 64 cycles each): 192 instead of 512
+// matrix-core cycles per 32 x 32 x 16 block, i.e. a fp32-equivalent ceiling of 2516.6 / 6 = 419 TFLOP/s = 2.67 x the fp32 pipe.
+// (tnr_conv_desc.mma = TNR_MMA_BF16X3.)
 __device__ __forceinline__ void tnr_split_bf16x3(const f32x4 q0, const f32x4 q1, tnr_bf16x8 (&out)[3]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

@@ -20,6 +20,7 @@ typedef int (*fn_comm_init_rank)(dp_comm_t *, int, dp_unique_id, int);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, dp_comm_t, hipStream_t);
 typedef int (*fn_broadcast)(const void *, void *, size_t, int, int, dp_comm_t, hipStream_t);
 typedef int (*fn_comm_destroy)(dp_comm_t);
+typedef int (*fn_comm_count)(dp_comm_t, int *);
 typedef const char *(*fn_error_string)(int);
 
 struct Rccl {
@@ -29,6 +30,7 @@ struct Rccl {
     fn_all_reduce all_reduce = nullptr;
     fn_broadcast broadcast = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_count comm_count = nullptr;
     fn_error_string error_string = nullptr;
 } g_rccl;
 
@@ -51,6 +53,7 @@ int load_rccl() {
     g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     g_rccl.broadcast = (fn_broadcast)dlsym(h, "ncclBroadcast");
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.comm_count = (fn_comm_count)dlsym(h, "ncclCommCount");
     g_rccl.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.broadcast || !g_rccl.comm_destroy) {
         tnr_set_error("tnr_dp: librccl lacks a required symbol");
@@ -99,6 +102,14 @@ extern "C" int tnr_dp_broadcast(void *comm, float *buf, int64_t count, int32_t r
     TNR_REQUIRE(comm != nullptr && buf != nullptr && count >= 0 && g_rccl.h != nullptr, "dp_broadcast: bad arguments");
     if (count == 0) return TNR_OK;
     return check_rccl(g_rccl.broadcast(buf, buf, (size_t)count, NCCL_FLOAT32, root, comm, (hipStream_t)stream), "dp_broadcast");
+}
+
+extern "C" int tnr_dp_comm_count(void *comm, int32_t *nranks) {
+    TNR_REQUIRE(comm != nullptr && nranks != nullptr && g_rccl.h != nullptr && g_rccl.comm_count != nullptr, "dp_comm_count: bad arguments");
+    int n = 0;
+    const int rc = check_rccl(g_rccl.comm_count(comm, &n), "dp_comm_count");
+    *nranks = n;
+    return rc;
 }
 
 extern "C" int tnr_dp_finalize(void *comm) {

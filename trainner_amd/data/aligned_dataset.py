@@ -6,7 +6,8 @@ coordinates, then flip, rot, vflip, hrrot, angle -- the same `random` draws in t
 (crop(), :776-790; HR position = LR position x scale, scale_params :1025-1036) and return the batch-dict entries of
 aligned_dataset.py:166-175.  Differences, all deliberate: the crop is a zero-copy slice of the decoded uint8 array; the
 flip / rot90 and np2tensor are NOT done here but on the GPU (data/feeder.py), so a sample also carries its `flags`.
-Files: .npy arrays (uint8 HWC, BGR like cv2.imread) or anything PIL opens (converted RGB -> BGR).
+Files: .npy arrays (uint8 HWC, BGR like cv2.imread) or anything PIL opens (converted RGB -> BGR); `data_type: lmdb` (a dataroot ending
+in .lmdb: dataops/common.py:47-105) reads the encoded images out of one lmdb database (the `lmdb` module is imported on first use).
 """
 import os
 import random
@@ -26,6 +27,76 @@ def _list_images(root):
     if not out:
         raise ValueError("no images found under %s" % (roots,))
     return out
+
+
+class LmdbSource:
+    """Images stored in one lmdb database (dataops/common.py:47-105: `dataroot` ends in `.lmdb`, the keys are the lines of its
+    meta_info.txt up to the first dot, the values are encoded image files; _init_lmdb opens it read-only without lock, read-ahead or
+    meminit).  The environment is opened lazily, once per process (DataLoader workers each open their own)."""
+
+    def __init__(self, dataroot):
+        if not isinstance(dataroot, str) or not dataroot.endswith(".lmdb"):
+            raise ValueError(f"Folder {dataroot} should in lmdb format.")
+        self.root = dataroot
+        with open(os.path.join(dataroot, "meta_info.txt")) as fin:
+            self.keys = [line.split(".")[0] for line in fin if line.strip()]
+        if not self.keys:
+            raise ValueError("%s: empty meta_info.txt" % dataroot)
+        self._env = None
+
+    def __len__(self):
+        return len(self.keys)
+
+    def path(self, index):
+        return self.keys[index]
+
+    def env(self):
+        if self._env is None:
+            try:
+                import lmdb
+            except ImportError:
+                raise ImportError("Please install lmdb to enable use.")
+            self._env = lmdb.open(self.root, readonly=True, lock=False, readahead=False, meminit=False)
+        return self._env
+
+    def read(self, index):
+        with self.env().begin(write=False) as txn:
+            buf = txn.get(self.keys[index].encode("ascii"))
+        if buf is None:
+            raise KeyError("%s: key %r not found" % (self.root, self.keys[index]))
+        return decode_image_bgr(bytes(buf), self.keys[index])
+
+
+class FolderSource:
+    def __init__(self, root):
+        self.paths = _list_images(root)
+
+    def __len__(self):
+        return len(self.paths)
+
+    def path(self, index):
+        return self.paths[index]
+
+    def read(self, index):
+        return read_image_bgr(self.paths[index])
+
+
+def image_source(root, data_type="img"):
+    """data_type as options.parse sets it (`lmdb` when the dataroot ends in .lmdb, else `img`; dataops/common.py:76-88)."""
+    if data_type == "lmdb" or (isinstance(root, str) and root.lower().endswith(".lmdb")):
+        return LmdbSource(root)
+    return FolderSource(root)
+
+
+def decode_image_bgr(content, name="<bytes>"):
+    """imfrombytes (dataops/common.py:108-128, flag 'color'): an encoded image file -> uint8 HWC BGR."""
+    import io
+    from PIL import Image
+    with Image.open(io.BytesIO(content)) as im:
+        img = np.asarray(im.convert("RGB"))[:, :, ::-1]
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise ValueError("%s: expected a uint8 HWC image" % name)
+    return img
 
 
 def read_image_bgr(path):
@@ -71,28 +142,29 @@ class AlignedWindowDataset(data.Dataset):
         self.use_flip, self.use_rot = bool(opt.get("use_flip")), bool(opt.get("use_rot"))
         if opt.get("use_hrrot"):
             raise NotImplementedError("use_hrrot (free-angle rotation) is not implemented by the HIP engine feeder")
-        self.hr_paths = _list_images(opt["dataroot_HR"] if opt.get("dataroot_HR") else opt["dataroot_B"])
+        dt = opt.get("data_type", "img") or "img"
+        self.hr_src = image_source(opt["dataroot_HR"] if opt.get("dataroot_HR") else opt["dataroot_B"], dt)
         lr_root = opt.get("dataroot_LR") or opt.get("dataroot_A")
-        self.lr_paths = None
+        self.lr_src = None
         if lr_root:
-            self.lr_paths = _list_images(lr_root)
-            if len(self.lr_paths) != len(self.hr_paths):
-                raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_paths), len(self.hr_paths)))
+            self.lr_src = image_source(lr_root, dt)
+            if len(self.lr_src) != len(self.hr_src):
+                raise ValueError("LR / HR datasets have different lengths: %d vs %d" % (len(self.lr_src), len(self.hr_src)))
         elif not (opt.get("augs_strategy") or opt.get("degradation")):
             raise NotImplementedError("no dataroot_LR: on-the-fly LR needs `augs_strategy: <preset>` (GPU degradation pipeline)")
 
     def __len__(self):
-        return len(self.hr_paths)
+        return len(self.hr_src)
 
     def __getitem__(self, index):
-        hr = read_image_bgr(self.hr_paths[index])
-        if self.lr_paths is None:           # HR window only: the LR image is synthesised on the GPU (data/feeder.py)
+        hr = self.hr_src.read(index)
+        if self.lr_src is None:             # HR window only: the LR image is synthesised on the GPU (data/feeder.py)
             p = paired_params((hr.shape[1], hr.shape[0]), self.crop)
             flags = (1 if (self.use_flip and p["flip"]) else 0) | (2 if (self.use_rot and p["rot"]) else 0)
             if flags & 2 and p["vflip"]:
                 flags |= 4
-            return {"HR": np.ascontiguousarray(window(hr, p["crop_pos"], self.crop)), "flags": flags, "HR_path": self.hr_paths[index]}
-        lr = read_image_bgr(self.lr_paths[index])
+            return {"HR": np.ascontiguousarray(window(hr, p["crop_pos"], self.crop)), "flags": flags, "HR_path": self.hr_src.path(index)}
+        lr = self.lr_src.read(index)
         crop_lr = self.crop // self.scale
         p = paired_params((lr.shape[1], lr.shape[0]), crop_lr)
         x, y = p["crop_pos"]
@@ -102,7 +174,7 @@ class AlignedWindowDataset(data.Dataset):
         if flags & 2 and p["vflip"]:
             flags |= 4
         return {"LR": np.ascontiguousarray(lr_w), "HR": np.ascontiguousarray(hr_w), "flags": flags,
-                "LR_path": self.lr_paths[index], "HR_path": self.hr_paths[index]}
+                "LR_path": self.lr_src.path(index), "HR_path": self.hr_src.path(index)}
 
 
 class UnalignedWindowDataset(data.Dataset):

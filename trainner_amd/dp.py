@@ -53,6 +53,23 @@ class DPGroup:
         hip.check(lib.tnr_dp_init(uid.data_ptr(), self.rank, self.world_size, ctypes.byref(comm)), "dp_init")
         self._abi = (lib, comm)
 
+    def observed_world_size(self):
+        """The rank count as the COMMUNICATOR sees it, not as the launcher's environment says: ncclCommCount through the C ABI
+        (TNR_DP_BACKEND=abi), else an all-reduce of ones over the torch group (the collective itself counts the ranks)."""
+        if not dist.is_initialized():
+            return 1
+        if self._abi is not None:
+            import ctypes
+            from . import hip
+            lib, comm = self._abi
+            n = ctypes.c_int32(0)
+            hip.check(lib.tnr_dp_comm_count(comm, ctypes.byref(n)), "dp_comm_count")
+            return int(n.value)
+        dev = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend(self.group) == "nccl") else torch.device("cpu")
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+        return int(round(float(one.item())))
+
     def finalize(self):
         if self._abi is not None:
             lib, comm = self._abi

@@ -107,6 +107,7 @@ _SIGS = {
     "tnr_dp_init": (c_i, [c_p, c_i, c_i, C.POINTER(c_p)]),
     "tnr_dp_allreduce_bucket": (c_i, [c_p, c_p, c_l, c_i, c_p]),
     "tnr_dp_broadcast": (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    "tnr_dp_comm_count": (c_i, [c_p, C.POINTER(c_i)]),
     "tnr_dp_finalize": (c_i, [c_p]),
     "tnr_filter2d": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "tnr_resize": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -87,6 +87,10 @@ class SRModel(BaseModel):
         # dense-block chain kernel has to fall back to one launch per layer (it needs its whole grid co-resident), which costs the
         # trunk's backward more (~8 ms) than the overlap could hide.  They go out in one sweep at the optimizer step (_sync_gradients);
         # D, which has no chain launches and the larger buffer (110 MB), keeps the overlapped schedule (backward_D).
+        # TNR_DP_OVERLAP_G=1 arms the bucket schedule for G as well (north star: overlapped with backward on a side stream); together
+        # with TNR_CHAIN_WITH_COLLECTIVES=1 the dense blocks stay one launch each next to the collectives (ops.CHAIN_WITH_COLLECTIVES).
+        if os.environ.get("TNR_DP_OVERLAP_G", "0") == "1":
+            self._arm_bucket_schedule([self.netG], passes=1)
         self.calc_gradients(l_g_total)
 
     def backward_D(self):

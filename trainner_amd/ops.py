@@ -300,6 +300,11 @@ CONV_SWEEP = os.environ.get("TNR_CONV_SWEEP", "1") != "0"     # TNR_MMA=bf16x3: 
 COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket handed to RCCL on the side stream until the compute
                                 # stream has waited for all of them: a chain launch needs every workgroup of its grid
                                 # co-resident, which RCCL kernels sharing the CUs could delay -> one launch per layer meanwhile
+# TNR_CHAIN_WITH_COLLECTIVES=1: keep the one-launch forms while gradient buckets are on the wire.  Measured next to a 4 x 64 MB RCCL
+# all-reduce on a side stream (1-rank group, tools/chain_stress.py --rccl, profiles/r03j): bit-identical results, no wait ever timed out,
+# +0.10 ms per dense-block launch (sweep 0.61 -> 0.71 ms, chain 1.01 -> 1.14 ms).  Off by default: with N > 1 ranks an RCCL kernel waits
+# for its peers while it holds CUs the launch wants all of -- never exercised on hardware here.
+CHAIN_WITH_COLLECTIVES = os.environ.get("TNR_CHAIN_WITH_COLLECTIVES", "0") == "1"
 _chain_epoch = {}
 _sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
 
@@ -336,7 +341,7 @@ def conv_chain(stages):
     n = len(stages)
     assert 1 <= n <= CHAIN_MAX
     eligible = all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages)
-    if not CONV_CHAIN or COLLECTIVES_IN_FLIGHT or not eligible:
+    if not CONV_CHAIN or (COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES) or not eligible:
         for st in stages:
             conv(**{k: v for k, v in st.items() if k != "fresh_from"})
         return
