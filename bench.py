@@ -203,13 +203,15 @@ def cpu_baseline(crop, steps=3, batch=2):
                       % (crop, batch, crop // 4, crop, steps)}
 
 
-def pmc_traffic(family="conv_tile_3x3"):
+def pmc_traffic(family="conv_tile_3x3", mode=None):
     """HBM bytes per launch of the dominant kernel family (average over its launches) from the newest committed
     rocprofv3 --pmc summary (profiles/*_pmc_traffic.json, made by tools/pmc_traffic.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same command).  Counters cannot be read from inside the timed
     process, so this is the recorded figure for the same kernels and shapes; None if no summary exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_%s.json" % mode))) if mode else []
+    if not files and mode in (None, "f32"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))      # (round-2 naming: fp32 matrix core)
     if not files:
         return None, None
     try:
@@ -375,7 +377,7 @@ def main():
             per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
             kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
                      "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
-            traffic, traffic_src = pmc_traffic(fam)
+            traffic, traffic_src = pmc_traffic(fam, "f32" if args.amp else args.mma)
             peak = PEAK_BF16_MFMA_TFLOPS if args.amp else (PEAK_BF16X3_TFLOPS if args.mma == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
             if fam == "conv_chain" and args.mma == "bf16x3" and not args.amp and ops.CONV_SWEEP:
                 kname = "conv_sweep_kernel (a dense block's 5 convolutions per launch, forward and data-gradient; bf16x3)"
