@@ -57,6 +57,24 @@ struct WgCfg {
 };
 
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
+
+// ---- TNR_MMA_BF16X3: the LDS image is PRE-SPLIT -- three bf16 planes (hi, mid, lo) written once by the stager -- and pixel-major,
+// which is what this GEMM reduces over: an MFMA operand fragment needs, per lane (= channel), 8 consecutive PIXELS.  gfx950's
+// transposing LDS read delivers exactly that: ds_read_b64_tr_b16 lets the 16 lanes of a group fetch 4 pixels x 16 channels (each lane 4
+// consecutive channels of one pixel: 8 contiguous bytes) and hands lane i channel i of the 4 pixels (tools/probes/tr_read.hip,
+// profiles/r03a_tr_read.txt) -- 6 reads per fragment (2 x 4 pixels x 3 planes) and NO vector arithmetic, against 8 scalar reads +
+// ~56 VALU operations per fragment when the split happens at the read (the weight gradient was VALU-bound there: 36 % MFMA-busy).
+// Layout of a tile with C channels (a multiple of 32): 768-byte blocks of 4 pixels x 32 channels x 3 planes,
+//     byte address (pixel p, channel c, plane s) = ((p >> 2) * (C / 32) + (c >> 5)) * 768 + s * 256 + (p & 3) * 64 + (c & 31) * 2
+// so the 4 pixels a half-wave reads are always the four 64-byte quarters of all 64 banks (any starting pixel: the tap offset shifts
+// the start), plane and second-read offsets are immediates, and a fragment costs one address computation.
+__device__ __forceinline__ int wg_x3_off(int p, int c, int C) {          // byte offset of (pixel p, channel c), plane 0
+    return ((p >> 2) * (C >> 5) + (c >> 5)) * 768 + (p & 3) * 64 + (c & 31) * 2;
+}
 
 // compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>) (register arrays need constant indices)
 template <int B, class F, int... I>
@@ -242,10 +260,49 @@ wgrad_tile_kernel(const WgK ga) {
         const TileAt ta = tile_at(tile);
         wg_static_for<k0, k1>([&](auto kc) __attribute__((always_inline)) { load_item(ta, 0, kc); });
     };
+    auto split4 = [&](const f32x4 v, wg_f32x2 (&out)[3]) {
+        wg_bf16x4 h, m, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __bf16 hh = (__bf16)v[i];
+            const float r1 = v[i] - (float)hh;
+            const __bf16 mm = (__bf16)r1;
+            h[i] = hh;
+            m[i] = mm;
+            l[i] = (__bf16)(r1 - (float)mm);
+        }
+        out[0] = __builtin_bit_cast(wg_f32x2, h);
+        out[1] = __builtin_bit_cast(wg_f32x2, m);
+        out[2] = __builtin_bit_cast(wg_f32x2, l);
+    };
+    char *const s_gb = reinterpret_cast<char *>(smem);                          // (BF == 2) byte views of the two pre-split tiles
+    char *const s_xb = s_gb + (size_t)PX * COB * 6;
     auto store_batch = [&](int batch) {
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int it = batch * BATCH + k;
+            if constexpr (BF == 2) {
+                // item i = (pixel, channel quad): three 8-byte pieces, one per plane (wg_x3_off)
+                wg_f32x2 pc[3];
+                if (it < G_IT) {
+                    const int i = tid + it * 256;
+                    if (i < G_ITEMS) {
+                        split4(rr[k], pc);
+                        char *d = s_gb + wg_x3_off(i / (COB / 4), (i % (COB / 4)) * 4, COB);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<wg_f32x2 *>(d + 256 * sp) = pc[sp];
+                    }
+                } else if (it < N_IT) {
+                    const int i = tid + (it - G_IT) * 256;
+                    if (i < X_ITEMS) {
+                        split4(rr[k], pc);
+                        char *d = s_xb + wg_x3_off(i / (CIB / 4), (i % (CIB / 4)) * 4, CIB);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) *reinterpret_cast<wg_f32x2 *>(d + 256 * sp) = pc[sp];
+                    }
+                }
+                continue;
+            }
             if (it < G_IT) {
                 const int i = tid + it * 256;
                 if (i < G_ITEMS) *reinterpret_cast<f32x4 *>(s_g + i * 4) = rr[k];
@@ -286,58 +343,72 @@ wgrad_tile_kernel(const WgK ga) {
 #pragma unroll
             for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
             if constexpr (BF == 2) {
-                // TNR_MMA_BF16X3: fp32 operands split exactly into three bf16 values as they leave LDS (conv_body.h has the
-                // arithmetic), six MFMAs per output tile and tile row.  The J tiles of a wave are taken two at a time: the raw
-                // values of the next pair are read while the current pair's 12 MFMAs run -- 2 x 8 raw + 2 x 12 split registers
-                // beside the J accumulators, whatever J is.
+                // TNR_MMA_BF16X3: both tiles are pre-split in LDS (wg_x3_off); a fragment = 6 transposing reads (2 x 4 pixels x 3
+                // planes), six MFMAs per output tile and tile row.  The J tiles of a wave are taken two at a time (two independent
+                // accumulator chains); the fragments of the next pair are read while the current pair's 12 MFMAs run.
                 constexpr int NP = (J + 1) / 2;
                 constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
-                float ra[8], rb[2][2][8];
-                wg_bf16x8 ca[3], cb[2][3];
-                auto split8 = [&](const float (&v)[8], wg_bf16x8 (&out)[3]) {
+                // lane roles of the transposing read: 16-lane group -> (pixel half h = lane >> 5, channel half cg); inside the group
+                // lane 4 m + q supplies pixel m, channels 4 q .. 4 q + 3
+                const int cg = (lane >> 4) & 1, m4 = (lane >> 2) & 3, q4 = lane & 3;
+                const int lch = 16 * cg + 4 * q4;                                    // channel inside the 32-channel block
+                auto frag = [&](const char *base, wg_bf16x8 (&out)[3], int rd_stride) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const __bf16 h = (__bf16)v[i];
-                        const float r1 = v[i] - (float)h;
-                        const __bf16 m = (__bf16)r1;
-                        out[0][i] = h;
-                        out[1][i] = m;
-                        out[2][i] = (__bf16)(r1 - (float)m);
+                    for (int sp = 0; sp < 3; ++sp) {
+                        const wg_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp));
+                        const wg_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp + rd_stride));
+                        typedef short s16x8 __attribute__((ext_vector_type(8)));
+                        const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                        out[sp] = __builtin_bit_cast(wg_bf16x8, v);
                     }
                 };
+                // A (gradient tile, 16 pixels per row: the pixel phase is the lane's m): constant per-lane offset + a row stride
+                const char *ga_ptr = s_gb + ((pg * ROWS * 4 + 2 * half) * (COB / 32) + aa_w) * 768 + m4 * 64 + lch * 2;
+                constexpr int GA_ROW = 4 * (COB / 32) * 768, GA_RD = (COB / 32) * 768, XB_RD = (CIB / 32) * 768;
+                // B (input halo tile): pixel = (row + ty) * WT + tx + 8 half + m (+ 4 for the second read)
+                int xpix[J], xblk[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const int tap = t_tap[j] >> 10, bb = t_tap[j] & 31;
+                    const int ty = tap / KH, tx = tap - ty * KH;
+                    xpix[j] = (pg * ROWS + ty) * WT + tx + 8 * half + m4;
+                    xblk[j] = bb * 768 + lch * 2;
+                }
+                auto xaddr = [&](int j) {
+                    const int P = xpix[j];
+                    return s_xb + (P >> 2) * ((CIB / 32) * 768) + (P & 3) * 64 + xblk[j];
+                };
+                wg_bf16x8 ca[3], cb[2][2][3];
                 auto read_pair = [&](int jp, int set) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int j = 2 * jp + q < J ? 2 * jp + q : J - 1;
-#pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) rb[set][q][kk] = smem[xo[j] + 2 * kk * CIB];
+                        frag(xaddr(j), cb[set][q], XB_RD);
                     }
                 };
 #pragma unroll 1
                 for (int r = 0; r < ROWS; ++r) {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) ra[kk] = smem[go + 2 * kk * COB];
+                    frag(ga_ptr, ca, GA_RD);
                     read_pair(0, 0);
-                #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) bsum += ra[kk];
-                    split8(ra, ca);
+                    if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) bsum += ((float)ca[0][kk] + (float)ca[1][kk]) + (float)ca[2][kk];
+                    }
 #pragma unroll
                     for (int jp = 0; jp < NP; ++jp) {
                         if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
-                        split8(rb[jp & 1][0], cb[0]);
-                        if (2 * jp + 1 < J) split8(rb[jp & 1][1], cb[1]);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int p = 0; p < 6; ++p) {
-                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[0][TB[p]], acc[2 * jp], 0, 0, 0);
+                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[jp & 1][0][TB[p]], acc[2 * jp], 0, 0, 0);
                             if (2 * jp + 1 < J)
-                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
+                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[jp & 1][1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    go += TWG * COB;
+                    ga_ptr += GA_ROW;
 #pragma unroll
-                    for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
+                    for (int j = 0; j < J; ++j) xpix[j] += WT;
                 }
             } else if constexpr (BF) {
                 float ra[8], rb[8][J];
@@ -426,7 +497,8 @@ wgrad_tile_kernel(const WgK ga) {
     float btot = bsum + __shfl_xor(bsum, 32);
     if constexpr (KS > 1) {
         constexpr int ACC_FLOATS = WPG * J * 16 * 64;
-        static_assert((ACC_FLOATS + WPG * 64) <= PX * COB + (HT + 1) * WT * CIB, "pixel-group reduction does not fit the tile LDS");
+        constexpr int TILE_FLOATS = BF == 2 ? (PX * COB + ((HT * WT + 3) / 4) * 4 * CIB) * 6 / 4 : PX * COB + (HT + 1) * WT * CIB;
+        static_assert((ACC_FLOATS + WPG * 64) <= TILE_FLOATS, "pixel-group reduction does not fit the tile LDS");
 #pragma unroll 1
         for (int p = 1; p < KS; ++p) {
             __syncthreads();                       // the tiles (p == 1) / the previous round's values are consumed
@@ -583,6 +655,8 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     const int ab = p.a_t * p.b_t;
     p.ks = (!s2d && (ab == 1 || ab == 2)) ? 4 / ab : 1;      // WgCfg::KS
     if (p.ks > 1) p.thg = 16;                                // each pixel group keeps >= 4 rows (J = 9: one workgroup per CU)
+    // the pre-split LDS image of TNR_MMA_BF16X3 takes 6 bytes per element: the 32 x 64 class halves its tile to stay inside 160 KB
+    if (p.ks > 1 && d->mma == TNR_MMA_BF16X3 && p.a_t == 1 && p.b_t == 2) p.thg = 8;
     p.cinp32 = tnr_round_up(d->Cin, 32);
     p.KinVP = vch;
     p.KoutP = tnr_round_up(d->Cout, 32);
@@ -613,9 +687,16 @@ template <int MODE, int A_T, int B_T, int THG, int BF>
 int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
-    constexpr size_t lds = (size_t)(THG * 16 * 32 * A_T + (THG + KH) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
+    // (TNR_MMA_BF16X3: both tiles pre-split into three bf16 planes, 6 bytes per element, pixels in blocks of 4: wg_x3_off)
+    constexpr size_t lds_f32 = (size_t)(THG * 16 * 32 * A_T + (THG + KH) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
+    constexpr size_t lds_x3 = (size_t)(THG * 16 * 32 * A_T + (((THG + KH - 1) * (16 + KH - 1) + 3) / 4) * 4 * 32 * B_T) * 6;
+    constexpr size_t lds = BF == 2 ? (lds_x3 > lds_f32 ? lds_x3 : lds_f32) : lds_f32;
     constexpr bool one_wg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD == 1;
-    static_assert(lds <= (one_wg ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
+    if constexpr (BF == 2 && lds > 160 * 1024) {       // (a tile class plan_wgrad never picks in this mode)
+        tnr_set_error("wgrad_tile: tile class %d x %d x %d rows does not fit the LDS in TNR_MMA_BF16X3", A_T, B_T, THG);
+        return TNR_EINVAL;
+    } else {
+    static_assert(lds <= ((one_wg || BF == 2) ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
     auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF>;
     if (!attr_done) {
@@ -628,6 +709,7 @@ int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     }
     hipLaunchKernelGGL(fn, dim3(k.nsplits, jobs, 1), dim3(256), lds, s, k);
     return tnr_check_launch("wgrad_tile");
+    }
 }
 
 template <int MODE, int A_T, int B_T, int THG>
@@ -645,7 +727,11 @@ int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
     }
     switch (p.b_t) {
         case 1: return launch_wgrad<MODE, 1, 1, THS>(k, jobs, s);
-        case 2: return launch_wgrad<MODE, 1, 2, THS>(k, jobs, s);
+        case 2:
+            if constexpr (MODE != TNR_CONV_4x4_S2) {
+                if (p.thg == 8) return launch_wgrad_t<MODE, 1, 2, 8, 2>(k, jobs, s);          // (bf16x3 only: plan_wgrad)
+            }
+            return launch_wgrad<MODE, 1, 2, THS>(k, jobs, s);
         case 3: return launch_wgrad<MODE, 1, 3, 4>(k, jobs, s);
         default:
             if constexpr (MODE != TNR_CONV_4x4_S2) {
