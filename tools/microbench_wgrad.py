@@ -15,7 +15,7 @@ def main():
     dev = torch.device("cuda")
     H = W = 128
     print("%5s %5s %4s %9s %9s" % ("Cin", "Cout", "N", "us", "TFLOP/s"))
-    for Cout, Cin in ((32, 64), (32, 96), (64, 192), (64, 64)):
+    for Cout, Cin in ((32, 64), (32, 96), (32, 128), (32, 32), (64, 192), (64, 64)):
         pts = []
         for N in (4, 8, 16, 32, 64):
             x = torch.randn(N, H, W, Cin, device=dev)

@@ -89,8 +89,11 @@ __device__ __forceinline__ void wg_static_for(F &&f) {
 // BF: operands rounded to bf16 in front of the matrix core (tnr_wgrad_desc.mma = TNR_MMA_BF16).  The reduction index of
 // this GEMM is the pixel: a 16-pixel tile row is exactly the k = 16 of one v_mfma_f32_32x32x16_bf16 (lane-half h supplies
 // pixels h, 2 + h, .., 14 + h: the same 8 values it feeds to 8 fp32 k-steps), so a row costs J MFMAs instead of 8 J.
-template <int MODE, int A_T, int B_T, int THG, int BF>
-__global__ void __launch_bounds__(256, (WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD))
+// WPS: workgroups per CU (= waves per SIMD).  The accumulator count picks it (WgCfg) except for the TNR_MMA_BF16X3 half-height classes
+// (plan_wgrad): two workgroups of 4-row tiles, so that one workgroup's refill (global loads, the operand split, LDS writes: ~1/3 of a
+// tile's time with one workgroup per CU, during which the matrix core idles) runs under the other's MFMA phase.
+template <int MODE, int A_T, int B_T, int THG, int BF, int WPS>
+__global__ void __launch_bounds__(256, WPS)
 wgrad_tile_kernel(const WgK ga) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
@@ -104,7 +107,13 @@ wgrad_tile_kernel(const WgK ga) {
     constexpr int T = AB * NTAPS, J = WgCfg<A_T, B_T, NTAPS>::J;
     constexpr int ROWS = THG / KS;                           // pixel rows of the tile one wave group reduces over
     static_assert(THG % KS == 0, "tile rows must split evenly over the pixel groups");
+#ifdef TNR_WG_X3_PIPE2
     constexpr bool PIPE = WgCfg<A_T, B_T, NTAPS>::PIPE;
+#else
+    // (TNR_MMA_BF16X3 with two workgroups per CU: the staging registers of an in-flight next tile do not fit next to 144 accumulators
+    //  in 256 registers -- the tile is loaded at its start instead, under the OTHER workgroup's MFMA phase)
+    constexpr bool PIPE = WgCfg<A_T, B_T, NTAPS>::PIPE && !(BF == 2 && WPS == 2 && WgCfg<A_T, B_T, NTAPS>::J >= 9);
+#endif
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_g = smem;             // PX * COB
@@ -173,7 +182,7 @@ wgrad_tile_kernel(const WgK ga) {
     constexpr int G_ITEMS = PX * (COB / 4), G_IT = (G_ITEMS + 255) / 256;
     constexpr int X_ITEMS = HT * WT * (CIB / 4), X_IT = (X_ITEMS + 255) / 256;
     constexpr int N_IT = G_IT + X_IT;
-    constexpr int BATCH = PIPE ? N_IT : 8;
+    constexpr int BATCH = (PIPE || N_IT <= 12) ? N_IT : 8;
     constexpr int NBATCH = (N_IT + BATCH - 1) / BATCH;
     f32x4 rr[BATCH];
     // staging item k (a compile-time index at every call site) of batch `batch` of the pixel tile at (n, ty0, tx0) -> rr[k]
@@ -366,19 +375,23 @@ wgrad_tile_kernel(const WgK ga) {
                 const char *ga_ptr = s_gb + ((pg * ROWS * 4 + 2 * half) * (COB / 32) + aa_w) * 768 + m4 * 64 + lch * 2;
                 constexpr int GA_ROW = 4 * (COB / 32) * 768, GA_RD = (COB / 32) * 768, XB_RD = (CIB / 32) * 768;
                 // B (input halo tile): pixel = (row + ty) * WT + tx + 8 half + m (+ 4 for the second read)
+                // wave-uniform part (SGPRs) + one per-lane term: 2 address registers instead of 2 J
                 int xpix[J], xblk[J];
+                const int lpix = 8 * half + m4, lblk = lch * 2;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
                     const int tap = t_tap[j] >> 10, bb = t_tap[j] & 31;
                     const int ty = tap / KH, tx = tap - ty * KH;
-                    xpix[j] = (pg * ROWS + ty) * WT + tx + 8 * half + m4;
-                    xblk[j] = bb * 768 + lch * 2;
+                    xpix[j] = __builtin_amdgcn_readfirstlane((pg * ROWS + ty) * WT + tx);
+                    xblk[j] = __builtin_amdgcn_readfirstlane(bb * 768);
                 }
                 auto xaddr = [&](int j) {
-                    const int P = xpix[j];
-                    return s_xb + (P >> 2) * ((CIB / 32) * 768) + (P & 3) * 64 + xblk[j];
+                    const int P = xpix[j] + lpix;
+                    return s_xb + (P >> 2) * ((CIB / 32) * 768) + (P & 3) * 64 + xblk[j] + lblk;
                 };
-                wg_bf16x8 ca[3], cb[2][2][3];
+                // (two workgroups per CU: the other workgroup's wave covers the LDS latency, one fragment set is enough -- 24 registers)
+                constexpr int NSET = WPS == 1 ? 2 : 1;
+                wg_bf16x8 ca[3], cb[NSET][2][3];
                 auto read_pair = [&](int jp, int set) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -389,20 +402,22 @@ wgrad_tile_kernel(const WgK ga) {
 #pragma unroll 1
                 for (int r = 0; r < ROWS; ++r) {
                     frag(ga_ptr, ca, GA_RD);
-                    read_pair(0, 0);
+                    if (NSET == 2) read_pair(0, 0);
                     if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
 #pragma unroll
                         for (int kk = 0; kk < 8; ++kk) bsum += ((float)ca[0][kk] + (float)ca[1][kk]) + (float)ca[2][kk];
                     }
 #pragma unroll
                     for (int jp = 0; jp < NP; ++jp) {
-                        if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
+                        if (NSET == 1) read_pair(jp, 0);
+                        else if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
                         __builtin_amdgcn_sched_barrier(0);
+                        const int cs = NSET == 1 ? 0 : (jp & 1);
 #pragma unroll
                         for (int p = 0; p < 6; ++p) {
-                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[jp & 1][0][TB[p]], acc[2 * jp], 0, 0, 0);
+                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][0][TB[p]], acc[2 * jp], 0, 0, 0);
                             if (2 * jp + 1 < J)
-                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[jp & 1][1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
+                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -497,8 +512,7 @@ wgrad_tile_kernel(const WgK ga) {
     float btot = bsum + __shfl_xor(bsum, 32);
     if constexpr (KS > 1) {
         constexpr int ACC_FLOATS = WPG * J * 16 * 64;
-        constexpr int TILE_FLOATS = BF == 2 ? (PX * COB + ((HT * WT + 3) / 4) * 4 * CIB) * 6 / 4 : PX * COB + (HT + 1) * WT * CIB;
-        static_assert((ACC_FLOATS + WPG * 64) <= TILE_FLOATS, "pixel-group reduction does not fit the tile LDS");
+        // (ACC_FLOATS + WPG * 64 floats: launch_wgrad_t sizes the dynamic LDS for the larger of the tile image and this exchange)
 #pragma unroll 1
         for (int p = 1; p < KS; ++p) {
             __syncthreads();                       // the tiles (p == 1) / the previous round's values are consumed
@@ -629,7 +643,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
 }
 
 struct WgPlan {
-    int a_t, b_t, thg, ks;
+    int a_t, b_t, thg, ks, wps;
     int ncib, ncob;
     int KoutP, KinVP, cinp32;
     int tiles_x, tiles_y, tiles_total, splits, tiles_per_split;
@@ -657,6 +671,17 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     if (p.ks > 1) p.thg = 16;                                // each pixel group keeps >= 4 rows (J = 9: one workgroup per CU)
     // the pre-split LDS image of TNR_MMA_BF16X3 takes 6 bytes per element: the 32 x 64 class halves its tile to stay inside 160 KB
     if (p.ks > 1 && d->mma == TNR_MMA_BF16X3 && p.a_t == 1 && p.b_t == 2) p.thg = 8;
+    const int wpg0 = 4 / p.ks;
+    p.wps = ((p.a_t * p.b_t * (s2d ? 4 : 9) + wpg0 - 1) / wpg0 >= 9) ? 1 : 2;      // WgCfg::WAVES_PER_SIMD
+    // TNR_MMA_BF16X3, 3x3 classes: half-height tiles, two workgroups per CU (see wgrad_tile_kernel; TNR_WG_X3_OCC=1 keeps one)
+    static const int x3_occ = [] { const char *e = getenv("TNR_WG_X3_OCC"); return e ? atoi(e) : 2; }();
+    if (d->mma == TNR_MMA_BF16X3 && !s2d && x3_occ == 2 && p.wps == 1) {
+        if (p.b_t == 4) p.b_t = 2;               // 32 x 128 jobs become two 32 x 64 jobs (the 128-wide halo tile alone is 95 KB)
+        const int ab2 = p.a_t * p.b_t;
+        p.ks = (ab2 == 1 || ab2 == 2) ? 4 / ab2 : 1;
+        p.thg = ab2 == 1 ? 8 : 4;                // <= 66 KB of pre-split LDS image per workgroup, >= 2 tile rows per pixel group
+        p.wps = 2;
+    }
     p.cinp32 = tnr_round_up(d->Cin, 32);
     p.KinVP = vch;
     p.KoutP = tnr_round_up(d->Cout, 32);
@@ -666,9 +691,7 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     p.tiles_x = tnr_cdiv(d->Wo, 16);
     p.tiles_y = tnr_cdiv(d->Ho, p.thg);
     p.tiles_total = p.tiles_x * p.tiles_y * d->N;
-    const int wpg = 4 / p.ks;
-    const int J = (p.a_t * p.b_t * p.ntaps + wpg - 1) / wpg;
-    p.resident = (J >= 9) ? 256 : 512;           // workgroups that fit the chip at once in this regime
+    p.resident = 256 * p.wps;                    // workgroups that fit the chip at once in this regime
     const int jobs = group_jobs > 0 ? group_jobs : p.ncib * p.ncob;
     int want = p.resident / jobs;                // one full wave of workgroups, never a straggler
     if (want < 1) want = 1;
@@ -683,22 +706,26 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     return 0;
 }
 
-template <int MODE, int A_T, int B_T, int THG, int BF>
+template <int MODE, int A_T, int B_T, int THG, int BF, int WPS = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD>
 int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
     // (TNR_MMA_BF16X3: both tiles pre-split into three bf16 planes, 6 bytes per element, pixels in blocks of 4: wg_x3_off)
     constexpr size_t lds_f32 = (size_t)(THG * 16 * 32 * A_T + (THG + KH) * (16 + KH - 1) * 32 * B_T) * sizeof(float);
     constexpr size_t lds_x3 = (size_t)(THG * 16 * 32 * A_T + (((THG + KH - 1) * (16 + KH - 1) + 3) / 4) * 4 * 32 * B_T) * 6;
-    constexpr size_t lds = BF == 2 ? (lds_x3 > lds_f32 ? lds_x3 : lds_f32) : lds_f32;
-    constexpr bool one_wg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD == 1;
+    using Cfg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>;
+    constexpr size_t lds_red = Cfg::KS > 1 ? (size_t)(Cfg::WPG * Cfg::J * 16 * 64 + Cfg::WPG * 64) * sizeof(float) : 0;   // pixel-group exchange
+    constexpr size_t lds_tile = BF == 2 ? lds_x3 : lds_f32;
+    constexpr size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
+    constexpr bool one_wg = WPS == 1;
     if constexpr (BF == 2 && lds > 160 * 1024) {       // (a tile class plan_wgrad never picks in this mode)
         tnr_set_error("wgrad_tile: tile class %d x %d x %d rows does not fit the LDS in TNR_MMA_BF16X3", A_T, B_T, THG);
         return TNR_EINVAL;
     } else {
+    // (TNR_MMA_BF16X3 classes inherited from the fp32 plan may exceed 80 KB: the LDS then limits them to one workgroup per CU)
     static_assert(lds <= ((one_wg || BF == 2) ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
-    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF>;
+    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF, WPS>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -721,6 +748,12 @@ int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
 template <int MODE>
 int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
     constexpr int THS = (MODE == TNR_CONV_4x4_S2) ? 8 : 16;   // tile rows of the pixel-split classes (plan_wgrad: ks > 1)
+    if constexpr (MODE != TNR_CONV_4x4_S2) {
+        if (k.bf == 2 && p.wps == 2 && p.b_t <= 2) {          // TNR_MMA_BF16X3: half-height tiles, two workgroups per CU (plan_wgrad)
+            if (p.a_t == 2) return p.b_t == 2 ? launch_wgrad_t<MODE, 2, 2, 4, 2, 2>(k, jobs, s) : launch_wgrad_t<MODE, 2, 1, 4, 2, 2>(k, jobs, s);
+            return p.b_t == 2 ? launch_wgrad_t<MODE, 1, 2, 4, 2, 2>(k, jobs, s) : launch_wgrad_t<MODE, 1, 1, 8, 2, 2>(k, jobs, s);
+        }
+    }
     if (p.a_t == 2) {
         if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, jobs, s);
         return launch_wgrad<MODE, 2, 1, THS>(k, jobs, s);
