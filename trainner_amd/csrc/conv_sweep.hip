@@ -28,6 +28,8 @@
 // Arithmetic (split, kept partial products and their order, channel and tap order, epilogue) is that of conv_tile_body<.., BF = 2>:
 // results are bit-identical to five tnr_conv_forward launches in TNR_MMA_BF16X3.
 #include <stddef.h>
+#include <type_traits>
+#include <utility>
 #include "conv_body.h"
 #include "conv_epilogue.h"
 #include "conv_handoff.h"
@@ -158,8 +160,12 @@ __device__ __forceinline__ void sweep_slot(f32x16 (&acc)[SW_NTILE], const float 
         for (int jj = 0; jj < NJ; ++jj) {
             const int u = tt * NJ + jj;
             // the fragments of the next unit are read before this unit's MFMAs issue (one register set each way)
+#ifndef SW_ABL_NOFA          /* (ablation builds: fragments read once per slot -- timing only, results invalid) */
             if (jj == 0 && tt + 1 < T) load_a(tap0 + tt + 1, (tt + 1) & 1);
+#endif
+#ifndef SW_ABL_NOFB
             if (u + 1 < T * NJ) load_b(u + 1, (u + 1) & 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < 6; ++p)
@@ -445,6 +451,286 @@ __global__ void __launch_bounds__(512, 1) conv_sweep_kernel(const SweepK c) {
 #endif
 }
 
+// =====================================================================================================================================
+// The four-wave form (default).  Same tile, same plan, same weight stream, same arithmetic as conv_sweep_kernel -- another division of
+// the work among the waves.  Measured on the eight-wave form (profiles/r03q_sweep_lds_ablation.txt, r03r_mfma_slots.txt): with every
+// memory operation removed it still ran at 2/3 of the matrix-core rate, because after each slot barrier BOTH waves of a SIMD execute
+// the slot's scalar prologue (cursor, addresses, DMA issue, fragment reads) at the same time while the matrix core idles, and each
+// wave's 32-pixel M-tile re-reads every weight fragment (LDS reads = 2/3 .. 1 of the MFMA time).  Here:
+//   * one wave per SIMD (256 threads, the whole 512-entry register file): a wave owns TWO tile rows (2 M-tiles x 6 N-tiles = 192
+//     accumulator registers), so a weight fragment read from LDS feeds 12 MFMAs instead of 6;
+//   * a chunk (9 taps x NJ N-tiles = three ring slots) is ONE straight-line block: tap offsets, LDS addresses of the units and the
+//     places of the side work are compile-time, the fragments of unit u + 1 are read in front of the MFMAs of unit u, and nothing
+//     but MFMAs and LDS reads is issued between the slot synchronisations;
+//   * the barrier that opens slot s + 1 stands in front of the LAST unit of slot s, so that the first fragments of the new slot are
+//     read under that unit's 12 MFMAs; the weight pieces of slot s + 2 are issued right behind it (their ring slot was consumed a
+//     whole slot ago);
+//   * the input chunk's operand split + LDS store (6 items per thread) is handed out over the last units of slots 1 and 2, and the
+//     epilogue of a completed stage runs at the top of the next chunk, behind that chunk's barrier.
+constexpr int S4_A_IT = (SW_A_ROWS * 4 + 255) / 256;                // staging items (float4) per thread and chunk: 6
+constexpr int S4_PIECES = (SW_SLOT_UNITS * 3 + 3) / 4;              // 1 KB LDS-DMA pieces per wave and slot: <= 7
+static_assert(S4_PIECES <= 7 && S4_A_IT == 6, "sw_wait_vm4 / the side-work plan");
+
+template <int B, class F, int... I>
+__device__ __forceinline__ void sw_static_for_seq(F &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, B + I>{}), ...);
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void sw_static_for(F &&f) {
+    sw_static_for_seq<B>(f, std::make_integer_sequence<int, (E > B ? E - B : 0)>{});
+}
+
+__device__ __forceinline__ void sw_wait_vm4(int n) {      // n wave-uniform, 0 .. 7
+    switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+}
+
+// One input chunk: N-tiles [J0, J0 + NJ) x 9 taps x 16 channels, three ring slots of 3 NJ units.  sync(s) opens slot s (1, 2);
+// side(u) is called behind the MFMAs of unit u.
+template <int J0, int NJ, class Sync, class Side>
+__device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const float *sa, const float *s_b_lane, const int (&apix0)[2],
+                                             const int half, Sync &&sync, Side &&side) {
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // the six kept partial products, smallest first
+    constexpr int NU = 9 * NJ, SU = 3 * NJ;
+    tnr_bf16x8 fa[2][2][3], fb[2][3];
+    auto load_a = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, dy = t / 3, dx = t % 3;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pp = apix0[m] + dy * SW_WT + dx;
+            const float *src = sa + pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) fa[t & 1][m][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+        }
+    };
+    auto load_b = [&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, sl = u / SU, i = u % SU;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+            fb[u & 1][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_b_lane + sl * SW_SLOT_FLOATS + i * SW_UNIT_FLOATS + 8 * sp);
+    };
+    load_a(std::integral_constant<int, 0>{});
+    load_b(std::integral_constant<int, 0>{});
+    sw_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, t = u / NJ, jj = u % NJ, sl = u / SU;
+        if constexpr (u % SU == SU - 1 && sl < 2) sync(std::integral_constant<int, sl + 1>{});
+        if constexpr (u + 1 < NU) {
+            if constexpr ((u + 1) % NJ == 0) load_a(std::integral_constant<int, t + 1>{});
+            load_b(std::integral_constant<int, u + 1>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        side(uc);
+    });
+}
+
+__global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_a = smem, *s_b = smem + 2 * SW_A_FLOATS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    int b = blockIdx.x;
+    const int g = gridDim.x;
+    if ((g & 7) == 0) b = (b & 7) * (g >> 3) + (b >> 3);          // (see conv_sweep_kernel)
+    const ConvK &x0 = c.st[0];
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x0.x), 0, (int)((unsigned)x0.N * x0.H * x0.W * x0.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.wq), 0, c.wq_bytes, 0x00020000);
+    sw_lds_float *ring = (sw_lds_float *)s_b;
+    const int apix0[2] = {(2 * wave) * SW_WT + li, (2 * wave + 1) * SW_WT + li};
+    const float *s_b_lane = s_b + li * SW_ROW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));
+    int pend_tile = -1;          // tile whose newest stage output still has to be published (wave-uniform)
+    unsigned pend_value = 0;
+    int pend_age = 0;
+
+    for (int tile = b; tile < c.tiles; tile += g) {
+        const int n = tile / c.tpi, rem = tile - n * c.tpi;
+        const int ty = rem / c.tiles_x, tx = rem - ty * c.tiles_x;
+        const int ty0 = ty * SW_TH, tx0 = tx * SW_TW;
+        // ---- staging plan of the input tile: item i = tid + 256 it -> halo pixel i / 4, channel quad i % 4
+        int in_off[S4_A_IT], a_dst[S4_A_IT];
+#pragma unroll
+        for (int it = 0; it < S4_A_IT; ++it) {
+            const int i = tid + it * 256, row = i >> 2, q = i & 3;
+            const int hr = row / SW_WT, hc = row - hr * SW_WT;
+            const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            const bool in = (row < SW_A_ROWS) & (Y >= 0) & (Y < x0.H) & (X >= 0) & (X < x0.W);
+            in_off[it] = in ? (((n * x0.H + Y) * x0.W + X) * x0.x_ct + x0.x_co + q * 4) : -1;
+            a_dst[it] = row < SW_A_ROWS ? row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1) : -1;
+        }
+        f32x4 rin[S4_A_IT];
+        auto a_load = [&](int ch) __attribute__((always_inline)) {          // system-coherent: the channels may have been written by another CU in this launch
+#pragma unroll
+            for (int it = 0; it < S4_A_IT; ++it) {
+                const unsigned bo = in_off[it] >= 0 ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;      // (past the end: the range check returns 0)
+                rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
+            }
+        };
+        auto a_store_item = [&](auto ic, int buf) __attribute__((always_inline)) {
+            constexpr int it = decltype(ic)::value;
+            if (a_dst[it] >= 0) {
+                tnr_f32x2 pc[3];
+                tnr_split4_bf16x3(rin[it], pc);
+                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it];
+                *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
+                *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
+                *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+            }
+        };
+        // weights: LDS-DMA, no registers; this wave's 1 KB pieces of a slot (piece q = bytes [1024 q, 1024 q + 1024), round-robin)
+        auto b_issue = [&](const SweepCur &cu, int slot) __attribute__((always_inline)) {
+            const int pieces = sw_nj_rt(cu.p) * 9;
+            const int src0 = cu.unit * (SW_UNIT_FLOATS * 4);          // wave-uniform: the load's scalar offset
+            sw_lds_float *dst = ring + slot * SW_SLOT_FLOATS;
+#pragma unroll
+            for (int i = 0; i < S4_PIECES; ++i) {
+                const int q = wave + 4 * i;
+                if (q < pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dst + q * 256, 16, lane * 16, src0 + q * 1024, 0, 0);
+            }
+        };
+        auto cur_advance = [&](SweepCur &cu) __attribute__((always_inline)) {                          // one slot = three taps of the pass's N-tiles
+            cu.unit += 3 * sw_nj_rt(cu.p);
+            if (++cu.sl == 3) {
+                cu.sl = 0;
+                if (++cu.ck == sw_nchunks(cu.p, c.nck0)) {
+                    cu.ck = 0;
+                    ++cu.p;
+                }
+            }
+        };
+
+        f32x16 acc[2][SW_NTILE];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < SW_NTILE; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+        // ---- prologue: input chunk 0 into LDS, weight slot 0 on its way
+        SweepCur ld{0, 0, 0, 0};         // the next slot to fetch
+        a_load(0);
+        __syncthreads();                 // the previous tile's last fragments are consumed
+        b_issue(ld, 0);
+        cur_advance(ld);
+        sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_store_item(ic, 0); });
+        int e = 0;                       // input chunks consumed so far in this tile
+        int young = 0;                   // vector-memory operations issued behind the weight pieces the next synchronisation waits for
+        bool has_next = false;
+
+        // slot synchronisation: the pieces of the slot about to be read have landed for every wave; the ring slot `fill` is free
+        auto slot_sync = [&](int fill, bool issue_now) __attribute__((always_inline)) {
+            const bool pub = pend_tile >= 0 && ++pend_age >= 3;
+            sw_wait_vm4(pub ? 0 : young);
+            __syncthreads();
+            if (pub) {
+                if (tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend_tile = -1;
+            }
+            young = 0;
+            if (issue_now && ld.valid()) {
+                b_issue(ld, fill);
+                cur_advance(ld);
+            }
+        };
+        // (the stage index is a compile-time constant at every accumulator access: a run-time switch or select over the array elements
+        //  is rewritten into one load at a computed address and the whole accumulator array then lives in scratch memory)
+        auto epilogue_of = [&](auto sc) __attribute__((always_inline)) {
+            constexpr int S = decltype(sc)::value;
+            const ConvK a = sweep_stage(S);
+            const __amdgpu_buffer_rsrc_t y_rs =
+                __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {              // one M-tile (tile row) at a time: fewer temporaries alive
+                if constexpr (S < 4) {
+                    f32x16 t[1][1];
+                    t[0][0] = acc[m][S];
+                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 1, true>(a, t, 0, n, ty0, tx0, 0, 2 * wave + m, li, half, y_rs);
+                } else {
+                    f32x16 t[1][2];
+                    t[0][0] = acc[m][4];
+                    t[0][1] = acc[m][5];
+                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 1, true>(a, t, 0, n, ty0, tx0, 0, 2 * wave + m, li, half, y_rs);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pend_tile = tile;
+            pend_value = c.base + (unsigned)S + 1u;
+            pend_age = 0;
+        };
+        auto sync = [&](auto sc) __attribute__((always_inline)) {        // in front of the last unit of slot s - 1: opens slot s, refills slot s + 1
+            constexpr int sl = decltype(sc)::value;
+            slot_sync((sl + 1) % SW_RING, true);
+        };
+        auto side = [&](auto uc, auto njc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value, NJ = decltype(njc)::value, SU = 3 * NJ;
+            // the next input chunk: split + LDS store of item i behind the last units of slots 1 and 2 (NJ = 1: one per unit)
+            constexpr int i = NJ == 1 ? u - 3 : (u >= 2 * SU - 4 && u <= 2 * SU - 2 ? u - (2 * SU - 4) : (u >= 3 * SU - 3 ? u - (3 * SU - 3) + 3 : -1));
+            if constexpr (i >= 0 && i < S4_A_IT) {
+                if (has_next) a_store_item(std::integral_constant<int, i>{}, (e + 1) & 1);
+            }
+        };
+
+        // The nine passes are unrolled in the source: every accumulator access and every stage index is a compile-time constant, and
+        // the control flow the register allocator sees is a plain sequence of chunk loops.
+        sw_static_for<0, SW_NPASS>([&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const int nchunks = sw_nchunks(p, c.nck0), ch_lo = sw_ch_lo(p, c.nck0);
+#pragma unroll 1
+            for (int ck = 0; ck < nchunks; ++ck) {
+                // ---- chunk top: slot 0 of this chunk has landed, the chunk's input tile is in LDS
+                slot_sync(1, false);
+                if constexpr (!sw_apass(p)) {        // the stage completed by pass a of this phase (this pass never touches its accumulators)
+                    if (ck == 0) epilogue_of(std::integral_constant<int, sw_phase(p)>{});
+                }
+                if (ld.valid()) {
+                    b_issue(ld, 1);
+                    cur_advance(ld);
+                }
+                const bool last_ck = ck + 1 == nchunks;
+                has_next = !(last_ck && p == SW_NPASS - 1);
+                if (has_next) {
+                    int ch_next = ch_lo + 16 * (ck + 1);
+                    if (last_ck) {
+                        ch_next = sw_ch_lo(p + 1 < SW_NPASS ? p + 1 : p, c.nck0);
+                        if constexpr (p + 1 < SW_NPASS && sw_apass(p + 1)) {
+                            // the first chunk of the next phase is the output of the stage this tile and its 8 neighbours finished
+                            // in pass a of the current phase
+                            const ChainWait w{c.progress, c.base + (unsigned)sw_phase(p + 1), n, ty, tx, c.tiles_x, c.tiles_y, c.err,
+                                              &pend_tile, pend_value};
+                            w();
+                        }
+                    }
+                    a_load(ch_next);
+                    young = S4_A_IT;
+                }
+                const float *sa = s_a + (e & 1) * SW_A_FLOATS;
+                auto side_p = [&](auto uc) __attribute__((always_inline)) { side(uc, std::integral_constant<int, sw_nj(p)>{}); };
+                sweep4_chunk<sw_j0(p), sw_nj(p)>(acc, sa, s_b_lane, apix0, half, sync, side_p);
+                ++e;
+            }
+        });
+        epilogue_of(std::integral_constant<int, 4>{});      // the last stage (pass 8 is a pass a)
+    }
+    // nothing in this launch waits for the last stage; publish it anyway so the counters stay consistent
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pend_tile >= 0 && tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Do the stages form a dense block the sweep kernel covers?  (5 stages over ONE input buffer, stage k reading channels [0, nf + 32 k)
 // and -- except the last -- writing the next 32 channels of that buffer; 32, 32, 32, 32, 64 output channels)
 bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
@@ -478,6 +764,8 @@ int sweep_cus() {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SW_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SW_LDS_BYTES) != hipSuccess || cus < 1)
             cus = -1;
     }
@@ -561,6 +849,8 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     // whole images per round of the grid, one tile per workgroup and round
     const int per_round = (cus / c.tpi) * c.tpi;
     const int grid = c.tiles < per_round ? c.tiles : per_round;
-    hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
+    static const int waves = [] { const char *e = getenv("TNR_SWEEP_WAVES"); return e ? atoi(e) : 4; }();      // 8: the eight-wave form
+    if (waves == 8) hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
+    else hipLaunchKernelGGL(conv_sweep4_kernel, dim3((unsigned)grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, c);
     return tnr_check_launch("conv_sweep");
 }
