@@ -100,14 +100,17 @@ print("chain error flag:", ops.chain_error_flag())
 lib = hip.load()
 if hasattr(lib, "tnr_debug_sweep_timeline"):       # -DSW_TIMELINE probe build: where wave 0 of a workgroup spends its cycles
     import ctypes as C
-    names = ["tile prologue", "neighbour wait", "A load issue", "vmcnt wait", "barrier", "DMA issue", "MFMA slot bodies", "A split + LDS store",
-             "epilogue", "", "", "", "", "", "kernel total", "slots"]
+    names = ["tile prologue", "neighbour wait", "A load issue", "vmcnt wait", "barrier", "DMA issue", "MFMA bodies (four-wave form: whole chunks, incl. 2 syncs + side work)",
+             "A split + LDS store", "epilogue", "  chunks with 3 N-tiles", "  chunks with 2 N-tiles", "  chunks with 1 N-tile", "", "", "kernel total", "slots"]
     run = block(16, 128, 128, seed=5, grad_shape=False)
     _, _, st = run("layers")
     ops.conv_chain(st)
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 16)()
     lib.tnr_debug_sweep_timeline(out, 1)
+    out2 = (C.c_ulonglong * 16)()
+    if hasattr(lib, "tnr_debug_sweep_units"):
+        lib.tnr_debug_sweep_units(out2, 1)
     reps = 5
     for _ in range(reps):
         ops.conv_chain(st)
@@ -117,4 +120,11 @@ if hasattr(lib, "tnr_debug_sweep_timeline"):       # -DSW_TIMELINE probe build: 
     print("sweep timeline: mean cycles per workgroup and launch (wave 0; 4 tiles per workgroup), %d slots" % (out[15] // wgs))
     for i, nm in enumerate(names):
         if nm and nm != "slots":
-            print("   %-22s %10.0f  (%5.1f %%)" % (nm, out[i] / wgs, 100.0 * out[i] / max(out[14], 1)))
+            print("   %-40s %10.0f  (%5.1f %%)" % (nm, out[i] / wgs, 100.0 * out[i] / max(out[14], 1)))
+    if hasattr(lib, "tnr_debug_sweep_units"):
+        lib.tnr_debug_sweep_units(out2, 0)
+        print("four-wave form, chunks with 3 N-tiles: mean cycles per unit (12 MFMAs = 384 cycles of matrix core) by unit class")
+        for i, nm in enumerate(["unit with the slot synchronisation", "first two units of a slot (weight DMA)", "units with an input-chunk item",
+                                "plain units", "plain units that read the next tap's A fragments"]):
+            if out2[8 + i]:
+                print("   %-50s %8.0f   (%d units per workgroup and launch)" % (nm, out2[i] / out2[8 + i], out2[8 + i] // wgs))

@@ -7,7 +7,7 @@ namespace {
 
 // Epilogue of a tile (the quad-transpose epilogue of conv_body.h as a function: same arithmetic, same order): `acc` holds the MFMA
 // results of wave `wave` (M-tile mi = pixels (wave * MT + mi) * 32 .. + 31 of the TW-wide tile at (ty0, tx0), channel block cb).
-template <int MODE, int TW, int NT, int MT, bool COH>
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1>
 __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
                                                   const int tx0, const int par, const int wave, const int li, const int half,
                                                   const __amdgpu_buffer_rsrc_t y_rs) {
@@ -80,10 +80,13 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
     // A unit = (mi, q): the NT float4s of pixel mi*32 + 8q + 4half + b.  Residual / mask loads of unit u+1 are issued
     // BEFORE the stores of unit u (two register sets): on gfx9 stores count in vmcnt like loads, so a load placed
     // after a store in program order makes its consumer wait for that store's acknowledgement.
+    // DEPTH: how many units ahead the loads run (register sets = DEPTH + 1).  1 suits kernels whose co-resident waves cover the latency;
+    // the one-wave-per-SIMD sweep kernel asks for all of them up front.
     constexpr int UNITS = MT * 4;
-    bool ok[2];
-    size_t pixi[2];
-    f32x4 q1[2][NT], q2[2][NT], qm[2][NT];
+    constexpr int AHEAD = DEPTH < UNITS ? DEPTH : UNITS, SETS = AHEAD + 1 < UNITS ? AHEAD + 1 : UNITS;
+    bool ok[SETS];
+    size_t pixi[SETS];
+    f32x4 q1[SETS][NT], q2[SETS][NT], qm[SETS][NT];
     auto prep = [&](int u, int set) {
         const int mi = u >> 2, q = u & 3;
         const int p = (wave * MT + mi) * 32 + 8 * q + 4 * half + qb;
@@ -148,11 +151,12 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
             }
         }
     };
-    prep(0, 0);
+#pragma unroll
+    for (int u = 0; u < AHEAD; ++u) prep(u, u % SETS);
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
-        if (u + 1 < UNITS) prep(u + 1, (u + 1) & 1);
-        finish(u, u & 1);
+        if (u + AHEAD < UNITS) prep(u + AHEAD, (u + AHEAD) % SETS);
+        finish(u, u % SETS);
     }
 }
 

@@ -39,12 +39,13 @@ namespace {
 constexpr int SW_TH = 8, SW_TW = 32, SW_HT = SW_TH + 2, SW_WT = SW_TW + 2;
 constexpr int SW_ROW = TNR_X3_ROW;                                  // floats per LDS row: three planes of 16 bf16
 constexpr int SW_A_ROWS = SW_HT * SW_WT;                            // 340 halo pixels
-constexpr int SW_A_FLOATS = SW_A_ROWS * SW_ROW;
+constexpr int SW_A_ALLOC_ROWS = 384;                                // rows per LDS buffer: every staging item (512 x 3 or 256 x 6 float4) has a row of its own,
+constexpr int SW_A_FLOATS = SW_A_ALLOC_ROWS * SW_ROW;               // so the four-wave form stores without lane masks (rows >= 340 are never read)
 constexpr int SW_UNIT_FLOATS = 32 * SW_ROW;                         // one tap x one N-tile x 16 channels
 constexpr int SW_SLOT_UNITS = 9;
 constexpr int SW_SLOT_FLOATS = SW_SLOT_UNITS * SW_UNIT_FLOATS;
 constexpr int SW_RING = 3;                                          // weight slots in LDS: slot k + 2 is fetched while slot k is consumed
-constexpr size_t SW_LDS_BYTES = (size_t)(2 * SW_A_FLOATS + SW_RING * SW_SLOT_FLOATS) * sizeof(float);      // 148 224 B
+constexpr size_t SW_LDS_BYTES = (size_t)(2 * SW_A_FLOATS + SW_RING * SW_SLOT_FLOATS) * sizeof(float);      // 156 672 B
 constexpr int SW_NPASS = 9, SW_NSTAGE = 5, SW_NTILE = 6;
 constexpr int SW_A_IT = (SW_A_ROWS * 4 + 511) / 512;                // staging items (float4) per thread and chunk: 3
 constexpr int SW_B_PIECES = (SW_SLOT_UNITS * 3 + 7) / 8;            // 1 KB LDS-DMA pieces per wave and slot: <= 4
@@ -208,6 +209,7 @@ typedef __attribute__((address_space(3))) float sw_lds_float;
 
 #ifdef SW_TIMELINE   /* probe build (tools/build_variant.py sw_tl -DSW_TIMELINE): cycles wave 0 of every workgroup spends per part of the loop */
 __device__ unsigned long long sw_tl[16];
+__device__ unsigned long long sw_tl2[16];      // four-wave form, chunks with 3 N-tiles: cycles / count per unit class
 #define SW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define SW_ADD(i, d) do { tl[i] += (d); } while (0)
 #else
@@ -493,47 +495,72 @@ __device__ __forceinline__ void sw_wait_vm4(int n) {      // n wave-uniform, 0 .
     }
 }
 
-// One input chunk: N-tiles [J0, J0 + NJ) x 9 taps x 16 channels, three ring slots of 3 NJ units.  sync(s) opens slot s (1, 2);
-// side(u) is called behind the MFMAs of unit u.
-template <int J0, int NJ, class Sync, class Side>
+// One input chunk: N-tiles [J0, J0 + NJ) x 9 taps x 16 channels, three ring slots of 3 NJ units.  sync(s) opens slot s (1, 2).
+// With one wave per SIMD an instruction costs nothing only while an MFMA the wave has already issued is still executing (32 cycles
+// each), so everything else is handed out over the 12 MFMAs of a unit, a few instructions behind each:
+//     MFMA 0 .. 2   the three planes of the next unit's weight fragment (ds_read_b128)
+//     MFMA 3 .. 8   the six reads of the next tap's input fragments (units in front of a new tap)
+//     MFMA 2, 5, 8, 11   one 1 KB piece of the weight DMA (the two units behind a slot synchronisation)
+//     MFMA 4 .. 8   one step of an input-chunk item (hi plane, mid plane, lo plane + store, store, store: see the kernel)
+// (profiles/r03t_sweep4_timeline.txt: issued in blocks between the units these cost 50 .. 100 cycles per plain unit, 150 per DMA
+// unit and 520 per item against the unit's 384 cycles of matrix core.)
+template <int J0, int NJ, class Sync, class Item, class Dma, class Tick>
 __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const float *sa, const float *s_b_lane, const int (&apix0)[2],
-                                             const int half, Sync &&sync, Side &&side) {
+                                             const int half, Sync &&sync, Item &&item_step, Dma &&dma_step, Tick &&tick) {
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // the six kept partial products, smallest first
     constexpr int NU = 9 * NJ, SU = 3 * NJ;
     tnr_bf16x8 fa[2][2][3], fb[2][3];
-    auto load_a = [&](auto tc) __attribute__((always_inline)) {
+    const float *a_src[2][2];          // [tap parity][M-tile]: LDS address of the tap's fragment rows
+    auto addr_a = [&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value, dy = t / 3, dx = t % 3;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int pp = apix0[m] + dy * SW_WT + dx;
-            const float *src = sa + pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) fa[t & 1][m][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+            a_src[t & 1][m] = sa + pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
         }
     };
-    auto load_b = [&](auto uc) __attribute__((always_inline)) {
-        constexpr int u = decltype(uc)::value, sl = u / SU, i = u % SU;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
-            fb[u & 1][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_b_lane + sl * SW_SLOT_FLOATS + i * SW_UNIT_FLOATS + 8 * sp);
+    auto read_a = [&](auto tc, int m, int sp) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        fa[t & 1][m][sp] = *reinterpret_cast<const tnr_bf16x8 *>(a_src[t & 1][m] + 8 * sp);
     };
-    load_a(std::integral_constant<int, 0>{});
-    load_b(std::integral_constant<int, 0>{});
+    auto read_b = [&](auto uc, int sp) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, sl = u / SU, i = u % SU;
+        fb[u & 1][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_b_lane + sl * SW_SLOT_FLOATS + i * SW_UNIT_FLOATS + 8 * sp);
+    };
+    addr_a(std::integral_constant<int, 0>{});
+#pragma unroll
+    for (int k = 0; k < 6; ++k) read_a(std::integral_constant<int, 0>{}, k / 3, k % 3);
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp) read_b(std::integral_constant<int, 0>{}, sp);
     sw_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, t = u / NJ, jj = u % NJ, sl = u / SU;
-        if constexpr (u % SU == SU - 1 && sl < 2) sync(std::integral_constant<int, sl + 1>{});
-        if constexpr (u + 1 < NU) {
-            if constexpr ((u + 1) % NJ == 0) load_a(std::integral_constant<int, t + 1>{});
-            load_b(std::integral_constant<int, u + 1>{});
+#ifdef SW_TIMELINE
+        const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+#endif
+        constexpr bool SYNC_UNIT = (u % SU == SU - 1 && sl < 2);
+        constexpr bool DMA_UNIT = (u % SU) <= 1 || SYNC_UNIT;
+        constexpr bool NEXT_TAP = u + 1 < NU && (u + 1) % NJ == 0;
+        // input-chunk item i: behind the last units of slots 1 and 2 (NJ = 1: one per unit from unit 3)
+        constexpr int ITEM = NJ == 1 ? u - 3 : (u >= 2 * SU - 4 && u <= 2 * SU - 2 ? u - (2 * SU - 4) : (u >= 3 * SU - 3 ? u - (3 * SU - 3) + 3 : -1));
+        if constexpr (SYNC_UNIT) sync(std::integral_constant<int, sl + 1>{});
+        if constexpr (NEXT_TAP) addr_a(std::integral_constant<int, (t + 1 < 9 ? t + 1 : 8)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        sw_static_for<0, 12>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value, p = i / 2, m = i % 2;
+            acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
+            if constexpr (u + 1 < NU && i < 3) read_b(std::integral_constant<int, (u + 1 < NU ? u + 1 : u)>{}, i);
+            if constexpr (NEXT_TAP && i >= 3 && i < 9) read_a(std::integral_constant<int, (t + 1 < 9 ? t + 1 : 8)>{}, (i - 3) / 3, (i - 3) % 3);
+            if constexpr (DMA_UNIT && i % 3 == 2) dma_step();
+            if constexpr (ITEM >= 0 && ITEM < S4_A_IT && i >= 4 && i < 9) item_step(std::integral_constant<int, (ITEM >= 0 && ITEM < S4_A_IT ? ITEM : 0)>{}, std::integral_constant<int, (i >= 4 && i < 9 ? i - 4 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#ifdef SW_TIMELINE
+        if constexpr (NJ == 3) {
+            // class: 0 unit with the slot sync, 1 first two units of a slot (DMA), 2 units with an input-chunk item, 3 plain, 4 new-tap units among plain
+            constexpr int cls = SYNC_UNIT ? 0 : ((u % SU) <= 1 ? 1 : (ITEM >= 0 && ITEM < S4_A_IT ? 2 : (NEXT_TAP ? 4 : 3)));
+            tick(cls, __builtin_amdgcn_s_memtime() - tu0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 6; ++p)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        side(uc);
+#endif
     });
 }
 
@@ -555,8 +582,14 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     int pend_tile = -1;          // tile whose newest stage output still has to be published (wave-uniform)
     unsigned pend_value = 0;
     int pend_age = 0;
+#ifdef SW_TIMELINE
+    unsigned long long tl[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tl2[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int tile = b; tile < c.tiles; tile += g) {
+        SW_T(t_tile0);
         const int n = tile / c.tpi, rem = tile - n * c.tpi;
         const int ty = rem / c.tiles_x, tx = rem - ty * c.tiles_x;
         const int ty0 = ty * SW_TH, tx0 = tx * SW_TW;
@@ -569,8 +602,9 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
             const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
             const bool in = (row < SW_A_ROWS) & (Y >= 0) & (Y < x0.H) & (X >= 0) & (X < x0.W);
             in_off[it] = in ? (((n * x0.H + Y) * x0.W + X) * x0.x_ct + x0.x_co + q * 4) : -1;
-            a_dst[it] = row < SW_A_ROWS ? row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1) : -1;
+            a_dst[it] = row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);        // (row < SW_A_ALLOC_ROWS: always a valid address)
         }
+        static_assert(S4_A_IT * 256 <= SW_A_ALLOC_ROWS * 4, "a row per staging item");
         f32x4 rin[S4_A_IT];
         auto a_load = [&](int ch) __attribute__((always_inline)) {          // system-coherent: the channels may have been written by another CU in this launch
 #pragma unroll
@@ -579,16 +613,27 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                 rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
             }
         };
-        auto a_store_item = [&](auto ic, int buf) __attribute__((always_inline)) {
-            constexpr int it = decltype(ic)::value;
-            if (a_dst[it] >= 0) {
-                tnr_f32x2 pc[3];
-                tnr_split4_bf16x3(rin[it], pc);
-                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it];
-                *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
-                *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
-                *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+        // item `it` in five steps (see sweep4_chunk), each over the item's four channels at once so that no instruction waits for the one
+        // in front of it: 0 hi plane and first residual, 1 mid plane and second residual, 2 lo plane + store hi, 3 store mid, 4 store lo
+        // (tnr_split4_bf16x3's arithmetic)
+        tnr_bf16x4 ih, im, il;
+        f32x4 ir;
+        auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {
+            constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
+            if constexpr (k == 0) {
+                ih = __builtin_convertvector(rin[it], tnr_bf16x4);
+                ir = rin[it] - __builtin_convertvector(ih, f32x4);
+            } else if constexpr (k == 1) {
+                im = __builtin_convertvector(ir, tnr_bf16x4);
+                ir = ir - __builtin_convertvector(im, f32x4);
+            } else {
+                if constexpr (k == 2) il = __builtin_convertvector(ir, tnr_bf16x4);
+                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
+                *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
             }
+        };
+        auto a_store_item = [&](auto ic, int buf) __attribute__((always_inline)) {
+            sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, buf); });
         };
         // weights: LDS-DMA, no registers; this wave's 1 KB pieces of a slot (piece q = bytes [1024 q, 1024 q + 1024), round-robin)
         auto b_issue = [&](const SweepCur &cu, int slot) __attribute__((always_inline)) {
@@ -627,61 +672,85 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         b_issue(ld, 0);
         cur_advance(ld);
         sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_store_item(ic, 0); });
+        { SW_T(t_pro); SW_ADD(0, t_pro - t_tile0); }
         int e = 0;                       // input chunks consumed so far in this tile
-        int young = 0;                   // vector-memory operations issued behind the weight pieces the next synchronisation waits for
         bool has_next = false;
+        auto tick = [&](int cls, unsigned long long dt) __attribute__((always_inline)) {
+#ifdef SW_TIMELINE
+            tl2[cls] += dt;
+            tl2[8 + cls] += 1;
+#endif
+        };
+        // weight DMA in progress (wave-uniform): pieces dq, dq + 4, .. < dpieces of the slot at stream offset dsrc go to LDS at dbase
+        int dq = 0, dpieces = 0, dsrc = 0;
+        sw_lds_float *dbase = ring;
+        auto dma_step = [&]() __attribute__((always_inline)) {
+            if (dq < dpieces) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dbase + dq * 256, 16, lane * 16, dsrc + dq * 1024, 0, 0);
+                dq += 4;
+            }
+        };
 
-        // slot synchronisation: the pieces of the slot about to be read have landed for every wave; the ring slot `fill` is free
-        auto slot_sync = [&](int fill, bool issue_now) __attribute__((always_inline)) {
+        // slot synchronisation: the pieces of the slot about to be read have landed for every wave (every piece was issued at least
+        // 2/3 of a slot ago; vector-memory operations complete in order, so waiting for all of them also covers the input-chunk loads
+        // issued a slot ago); the ring slot `fill` is free and its DMA is set up -- the pieces are issued from inside the next two units
+        auto slot_sync = [&](int fill) __attribute__((always_inline)) {
             const bool pub = pend_tile >= 0 && ++pend_age >= 3;
-            sw_wait_vm4(pub ? 0 : young);
+            SW_T(t_s0);
+            while (dq < dpieces) dma_step();         // (never taken: every slot has room for its pieces)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SW_T(t_s1);
             __syncthreads();
+            SW_T(t_s2);
+            SW_ADD(3, t_s1 - t_s0);
+            SW_ADD(4, t_s2 - t_s1);
             if (pub) {
                 if (tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pend_tile = -1;
             }
-            young = 0;
-            if (issue_now && ld.valid()) {
-                b_issue(ld, fill);
+            if (ld.valid()) {
+                dq = wave;
+                dpieces = sw_nj_rt(ld.p) * 9;
+                dsrc = ld.unit * (SW_UNIT_FLOATS * 4);
+                dbase = ring + fill * SW_SLOT_FLOATS;
                 cur_advance(ld);
+            } else {
+                dpieces = 0;
             }
         };
         // (the stage index is a compile-time constant at every accumulator access: a run-time switch or select over the array elements
         //  is rewritten into one load at a computed address and the whole accumulator array then lives in scratch memory)
         auto epilogue_of = [&](auto sc) __attribute__((always_inline)) {
             constexpr int S = decltype(sc)::value;
+            SW_T(t_e0);
             const ConvK a = sweep_stage(S);
             const __amdgpu_buffer_rsrc_t y_rs =
                 __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+            if constexpr (S < 4) {
+                f32x16 t[2][1];
+                t[0][0] = acc[0][S];
+                t[1][0] = acc[1][S];
+                conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 2, true, 8>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
+            } else {
+                f32x16 t[2][2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {              // one M-tile (tile row) at a time: fewer temporaries alive
-                if constexpr (S < 4) {
-                    f32x16 t[1][1];
-                    t[0][0] = acc[m][S];
-                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 1, true>(a, t, 0, n, ty0, tx0, 0, 2 * wave + m, li, half, y_rs);
-                } else {
-                    f32x16 t[1][2];
-                    t[0][0] = acc[m][4];
-                    t[0][1] = acc[m][5];
-                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 1, true>(a, t, 0, n, ty0, tx0, 0, 2 * wave + m, li, half, y_rs);
+                for (int m = 0; m < 2; ++m) {
+                    t[m][0] = acc[m][4];
+                    t[m][1] = acc[m][5];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 2, true, 8>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
             }
             pend_tile = tile;
             pend_value = c.base + (unsigned)S + 1u;
             pend_age = 0;
+            { SW_T(t_e1); SW_ADD(8, t_e1 - t_e0); }
         };
         auto sync = [&](auto sc) __attribute__((always_inline)) {        // in front of the last unit of slot s - 1: opens slot s, refills slot s + 1
             constexpr int sl = decltype(sc)::value;
-            slot_sync((sl + 1) % SW_RING, true);
+            slot_sync((sl + 1) % SW_RING);
         };
-        auto side = [&](auto uc, auto njc) __attribute__((always_inline)) {
-            constexpr int u = decltype(uc)::value, NJ = decltype(njc)::value, SU = 3 * NJ;
-            // the next input chunk: split + LDS store of item i behind the last units of slots 1 and 2 (NJ = 1: one per unit)
-            constexpr int i = NJ == 1 ? u - 3 : (u >= 2 * SU - 4 && u <= 2 * SU - 2 ? u - (2 * SU - 4) : (u >= 3 * SU - 3 ? u - (3 * SU - 3) + 3 : -1));
-            if constexpr (i >= 0 && i < S4_A_IT) {
-                if (has_next) a_store_item(std::integral_constant<int, i>{}, (e + 1) & 1);
-            }
+        auto item_step = [&](auto ic, auto kc) __attribute__((always_inline)) {
+            if (has_next) item_step_buf(ic, kc, (e + 1) & 1);
         };
 
         // The nine passes are unrolled in the source: every accumulator access and every stage index is a compile-time constant, and
@@ -692,13 +761,9 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
 #pragma unroll 1
             for (int ck = 0; ck < nchunks; ++ck) {
                 // ---- chunk top: slot 0 of this chunk has landed, the chunk's input tile is in LDS
-                slot_sync(1, false);
+                slot_sync(1);
                 if constexpr (!sw_apass(p)) {        // the stage completed by pass a of this phase (this pass never touches its accumulators)
                     if (ck == 0) epilogue_of(std::integral_constant<int, sw_phase(p)>{});
-                }
-                if (ld.valid()) {
-                    b_issue(ld, 1);
-                    cur_advance(ld);
                 }
                 const bool last_ck = ck + 1 == nchunks;
                 has_next = !(last_ck && p == SW_NPASS - 1);
@@ -711,15 +776,19 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                             // in pass a of the current phase
                             const ChainWait w{c.progress, c.base + (unsigned)sw_phase(p + 1), n, ty, tx, c.tiles_x, c.tiles_y, c.err,
                                               &pend_tile, pend_value};
+                            SW_T(t_w0);
                             w();
+                            { SW_T(t_w1); SW_ADD(1, t_w1 - t_w0); }
                         }
                     }
+                    SW_T(t_al0);
                     a_load(ch_next);
-                    young = S4_A_IT;
+                    { SW_T(t_al1); SW_ADD(2, t_al1 - t_al0); }
                 }
                 const float *sa = s_a + (e & 1) * SW_A_FLOATS;
-                auto side_p = [&](auto uc) __attribute__((always_inline)) { side(uc, std::integral_constant<int, sw_nj(p)>{}); };
-                sweep4_chunk<sw_j0(p), sw_nj(p)>(acc, sa, s_b_lane, apix0, half, sync, side_p);
+                SW_T(t_c0);
+                sweep4_chunk<sw_j0(p), sw_nj(p)>(acc, sa, s_b_lane, apix0, half, sync, item_step, dma_step, tick);
+                { SW_T(t_c1); SW_ADD(6, t_c1 - t_c0); SW_ADD(15, 1ull); SW_ADD(9 + (sw_nj(p) == 3 ? 0 : (sw_nj(p) == 2 ? 1 : 2)), t_c1 - t_c0); }
                 ++e;
             }
         });
@@ -729,6 +798,13 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (pend_tile >= 0 && tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SW_TIMELINE
+    if (tid == 0) {
+        tl[14] = __builtin_amdgcn_s_memtime() - tl_begin;
+        for (int i = 0; i < 16; ++i) atomicAdd(&sw_tl[i], tl[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&sw_tl2[i], tl2[i]);
+    }
+#endif
 }
 
 // Do the stages form a dense block the sweep kernel covers?  (5 stages over ONE input buffer, stage k reading channels [0, nf + 32 k)
@@ -775,6 +851,14 @@ int sweep_cus() {
 }  // namespace
 
 #ifdef SW_TIMELINE
+extern "C" int tnr_debug_sweep_units(unsigned long long *out16, int reset) {
+    if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(sw_tl2), sizeof(sw_tl2)) != hipSuccess) return TNR_ELAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sw_tl2), z, sizeof(z)) != hipSuccess) return TNR_ELAUNCH;
+    }
+    return TNR_OK;
+}
 extern "C" int tnr_debug_sweep_timeline(unsigned long long *out16, int reset) {
     if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(sw_tl), sizeof(sw_tl)) != hipSuccess) return TNR_ELAUNCH;
     if (reset) {
