@@ -686,7 +686,9 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         sw_lds_float *dbase = ring;
         auto dma_step = [&]() __attribute__((always_inline)) {
             if (dq < dpieces) {
+#ifndef S4_ABL_NODMA        /* (ablation builds: timing only, results invalid) */
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, dbase + dq * 256, 16, lane * 16, dsrc + dq * 1024, 0, 0);
+#endif
                 dq += 4;
             }
         };
