@@ -92,7 +92,8 @@ __device__ __forceinline__ void wg_static_for(F &&f) {
 // WPS: workgroups per CU (= waves per SIMD).  The accumulator count picks it (WgCfg) except for the TNR_MMA_BF16X3 half-height classes
 // (plan_wgrad): two workgroups of 4-row tiles, so that one workgroup's refill (global loads, the operand split, LDS writes: ~1/3 of a
 // tile's time with one workgroup per CU, during which the matrix core idles) runs under the other's MFMA phase.
-template <int MODE, int A_T, int B_T, int THG, int BF, int WPS>
+// DB (TNR_MMA_BF16X3, plain 3x3 only): ONE workgroup per CU with TWO LDS tile sets -- the pipelined form described at wg_db_phase below.
+template <int MODE, int A_T, int B_T, int THG, int BF, int WPS, bool DB = false>
 __global__ void __launch_bounds__(256, WPS)
 wgrad_tile_kernel(const WgK ga) {
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
@@ -322,190 +323,407 @@ wgrad_tile_kernel(const WgK ga) {
         }
     };
 
-    if (PIPE && t_begin < t_end) load_batch(t_begin, 0);
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        if (PIPE) {
-            __syncthreads();  // previous tile's fragments are consumed
-            store_batch(0);
-            __syncthreads();
-            if (!SPREAD && tile + 1 < t_end) load_batch(tile + 1, 0);  // in flight during the MFMA phase below
-        } else {
-            load_batch(tile, 0);
-            __syncthreads();
-            store_batch(0);
+    if constexpr (DB) {
+        // ============================ the pipelined form (TNR_MMA_BF16X3, zero-padded 3x3) ============================
+        // What the two-workgroup form still loses (profiles/r03o): a workgroup's refill -- global loads, the operand split, LDS
+        // stores, two barriers -- is hidden only by the OTHER workgroup's MFMAs, which the matrix core does not interleave with its
+        // own (tools/probes/mfma_chain.hip), and each fragment's six transposing reads sit in a block in front of a pair of tiles.
+        // Here: one wave per SIMD and, as in conv_sweep4_kernel, everything that is not an MFMA is handed out BEHIND the MFMAs, a
+        // few instructions each (the wave issues them while the MFMA it just issued executes):
+        //   * LDS holds two tile sets; while the MFMAs of pixel tile i read set i & 1, the float4 items of tile i + 1 are loaded
+        //     (one item behind every second MFMA of the first rows), split and stored into the other set (five steps per item in
+        //     the second half of the phase) -- one barrier per tile;
+        //   * the x halo tile is stored with rows of 20 pixels (5 blocks of 4): a tile row is a CONSTANT address step, so every
+        //     fragment read is base register + immediate and the phase is straight-line code with no address arithmetic;
+        //   * the reads of the next pair of tiles' fragments (12) and of the next row's gradient fragment (6) are spread over
+        //     the current pair's MFMAs.
+        static_assert(BF == 2 && MODE == TNR_CONV_3x3 && WPS == 1, "pipelined form: bf16x3, plain 3x3, one workgroup per CU");
+        constexpr int WTP = 20;                                       // padded halo row (pixels) in LDS
+        constexpr int G_BYTES = PX * COB * 6, X_BYTES = HT * WTP * CIB * 6, TILES_BYTES = G_BYTES + X_BYTES;
+        constexpr int SET_BYTES = TILES_BYTES + 3072;               // + a dump area for the staging slots beyond the last item (no lane masks on the stores)
+        constexpr int XBLK = (CIB / 32) * 768, GBLK = (COB / 32) * 768;   // bytes per block of 4 pixels
+        constexpr int NP = (J + 1) / 2, MPR = 6 * J, NM = ROWS * MPR;     // pairs per row, MFMAs per row / per tile
+        constexpr int G0 = NM - 5 * N_IT - 6;                             // first MFMA that carries an item step
+        static_assert(G0 >= 2 * N_IT, "the phase is too short for the staging plan");
+        char *const lds = reinterpret_cast<char *>(smem);
+        const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.g), 0,
+                                                                              (int)((unsigned)a.N * a.Ho * a.Wo * a.g_ct * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0,
+                                                                              (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+        // ---- staging plan, once per kernel: item k of this thread -> element offset from the tile origin (or invalid), its position
+        // in the tile (border test) and its byte address in a tile set
+        int it_src[N_IT], it_yx[N_IT], it_dst[N_IT];
 #pragma unroll
-            for (int bt = 1; bt < NBATCH; ++bt) {
-                load_batch(tile, bt);
-                store_batch(bt);
+        for (int k = 0; k < N_IT; ++k) {
+            if (k < G_IT) {
+                const int i = tid + k * 256;
+                const int pp = i / (COB / 4), c4 = i - pp * (COB / 4);
+                const int r = pp / TWG, cc = pp - r * TWG;
+                const int co = cob * COB + c4 * 4;
+                const bool v = i < G_ITEMS && co < a.Cout;
+                it_src[k] = v ? (r * a.Wo + cc) * a.g_ct + a.g_co + co : -1;
+                it_yx[k] = r | (cc << 8);
+                it_dst[k] = i < G_ITEMS ? wg_x3_off(pp, c4 * 4, COB) : TILES_BYTES + tid * 8;
+            } else {
+                const int i = tid + (k - G_IT) * 256;
+                const int pix = i / (CIB / 4), c4 = i - pix * (CIB / 4);
+                const int hr = pix / WT, hc = pix - hr * WT;
+                const int ch = (cib * B_T + (c4 >> 3)) * 32 + (c4 & 7) * 4;
+                const bool v = i < X_ITEMS && ch < a.Cin;
+                it_src[k] = v ? ((hr - 1) * a.W + (hc - 1)) * a.x_ct + a.x_co + ch : (1 << 30);
+                it_yx[k] = hr | (hc << 8);
+                it_dst[k] = i < X_ITEMS ? G_BYTES + wg_x3_off(hr * WTP + hc, c4 * 4, CIB) : TILES_BYTES + tid * 8;
             }
+        }
+        int ld_ty0 = 0, ld_tx0 = 0, ld_gbase = 0, ld_xbase = 0;      // the tile being loaded (wave-uniform)
+        bool ld_valid = true;       // false behind the last tile: the loads and stores still run (straight-line code: a branch around them makes
+                                    // the compiler wait for ALL pending loads in front of every load), on zeros
+        auto load_setup = [&](int tile) __attribute__((always_inline)) {
+            const TileAt ta = tile_at(tile);
+            ld_ty0 = ta.ty0; ld_tx0 = ta.tx0;
+            ld_gbase = ((ta.n * a.Ho + ta.ty0) * a.Wo + ta.tx0) * a.g_ct;
+            ld_xbase = ((ta.n * a.H + ta.ty0) * a.W + ta.tx0) * a.x_ct;
+        };
+        auto item_load = [&](auto kc) __attribute__((always_inline)) {       // (an offset past the end reads zeros: borders and padding)
+            constexpr int k = decltype(kc)::value;
+            const int y = it_yx[k] & 255, xx = it_yx[k] >> 8;
+            if constexpr (k < G_IT) {
+                const bool ok = ld_valid & (it_src[k] >= 0) & (ld_ty0 + y < a.Ho) & (ld_tx0 + xx < a.Wo);
+                const unsigned bo = ok ? (unsigned)(ld_gbase + it_src[k]) * 4u : 0xfffffff0u;
+                rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rs, (int)bo, 0, 0));
+            } else {
+                const int Y = ld_ty0 + y - 1, X = ld_tx0 + xx - 1;
+                const bool ok = ld_valid & (it_src[k] != (1 << 30)) & ((unsigned)Y < (unsigned)a.H) & ((unsigned)X < (unsigned)a.W);
+                const unsigned bo = ok ? (unsigned)(ld_xbase + it_src[k]) * 4u : 0xfffffff0u;
+                rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
+            }
+        };
+        // item k in five steps, each over the item's four channels at once: 0 hi plane + first residual, 1 mid plane + second
+        // residual, 2 lo plane + store hi, 3 store mid, 4 store lo (split4's arithmetic)
+        wg_bf16x4 ih, im, il;
+        f32x4 ir;
+        auto item_step = [&](auto kc, auto sc, char *set) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value, st = decltype(sc)::value;
+            if constexpr (st == 0) {
+                ih = __builtin_convertvector(rr[k], wg_bf16x4);
+                ir = rr[k] - __builtin_convertvector(ih, f32x4);
+            } else if constexpr (st == 1) {
+                im = __builtin_convertvector(ir, wg_bf16x4);
+                ir = ir - __builtin_convertvector(im, f32x4);
+            } else {
+                if constexpr (st == 2) il = __builtin_convertvector(ir, wg_bf16x4);
+                *reinterpret_cast<wg_f32x2 *>(set + it_dst[k] + 256 * (st - 2)) = __builtin_bit_cast(wg_f32x2, st == 2 ? ih : (st == 3 ? im : il));
+            }
+        };
+        // ---- fragment addresses, once per kernel: lane roles of the transposing read as in the two-workgroup form
+        const int cg = (lane >> 4) & 1, m4 = (lane >> 2) & 3, q4 = lane & 3;
+        const int lch = 16 * cg + 4 * q4;
+        const int ga_off = ((pg * ROWS * 4 + 2 * half) * (COB / 32) + aa_w) * 768 + m4 * 64 + lch * 2;      // row r: + r * 4 * GBLK
+        int xb_off[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int tap = t_tap[j] >> 10, bb = t_tap[j] & 31;
+            const int ty = tap / KH, tx = tap - ty * KH;
+            const int q0 = tx + 8 * half + m4;
+            xb_off[j] = G_BYTES + ((pg * ROWS + ty) * (WTP / 4) + (q0 >> 2)) * XBLK + (q0 & 3) * 64 + bb * 768 + lch * 2;   // row r: + r * 5 * XBLK
+        }
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+        // one transposing read = 4 pixels of a plane: half `hh` (0: pixels 0 .. 3 of the lane's 8, 1: pixels 4 .. 7) of plane sp
+        auto rd = [&](const char *base, int imm) __attribute__((always_inline)) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + imm));
+        };
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        wg_s16x4 ra[2][3][2], rb[2][2][3][2];      // raw halves: [set][..][plane][half]
+        auto pack = [&](const wg_s16x4 lo4, const wg_s16x4 hi4) __attribute__((always_inline)) {
+            const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+            return __builtin_bit_cast(wg_bf16x8, v);
+        };
+
+        if (t_begin < t_end) {
+            // ---- prologue: tile t_begin into set 0
+            load_setup(t_begin);
+            wg_static_for<0, N_IT>([&](auto kc) __attribute__((always_inline)) { item_load(kc); });
+            wg_static_for<0, N_IT>([&](auto kc) __attribute__((always_inline)) {
+                wg_static_for<0, 5>([&](auto sc) __attribute__((always_inline)) { item_step(kc, sc, lds); });
+            });
             __syncthreads();
         }
-        // ---- K loop: two pixels per MFMA, software-pipelined one k-step deep: the fragments of step
-        // k+1 (one A value, J B values per lane) are read into the second register set BEFORE the J MFMAs
-        // of step k are issued, so the LDS latency hides under >= J*64 matrix-core cycles even with a
-        // single wave per SIMD.  A tile row (16 pixels = 8 k-steps) is fully unrolled: every LDS address
-        // is row base + compile-time offset, including the first step of the next row.
-        {
-            // integer float-offsets into smem[] (keeps the accesses provably LDS: ds_read with immediates)
-            int go = half * COB + li + aa_w * 32 + pg * ROWS * TWG * COB;
-            int xo[J];
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const int cur = (tile - t_begin) & 1;
+            const char *set = lds + cur * SET_BYTES;
+            char *oset = lds + (cur ^ 1) * SET_BYTES;
+            ld_valid = tile + 1 < t_end;
+            load_setup(ld_valid ? tile + 1 : tile);
+            const char *gab = set + ga_off;
+            const char *xbb[J];
 #pragma unroll
-            for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
-            if constexpr (BF == 2) {
-                // TNR_MMA_BF16X3: both tiles are pre-split in LDS (wg_x3_off); a fragment = 6 transposing reads (2 x 4 pixels x 3
-                // planes), six MFMAs per output tile and tile row.  The J tiles of a wave are taken two at a time (two independent
-                // accumulator chains); the fragments of the next pair are read while the current pair's 12 MFMAs run.
-                constexpr int NP = (J + 1) / 2;
-                constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
-                // lane roles of the transposing read: 16-lane group -> (pixel half h = lane >> 5, channel half cg); inside the group
-                // lane 4 m + q supplies pixel m, channels 4 q .. 4 q + 3
-                const int cg = (lane >> 4) & 1, m4 = (lane >> 2) & 3, q4 = lane & 3;
-                const int lch = 16 * cg + 4 * q4;                                    // channel inside the 32-channel block
-                auto frag = [&](const char *base, wg_bf16x8 (&out)[3], int rd_stride) {
+            for (int j = 0; j < J; ++j) xbb[j] = set + xb_off[j];
+            // read id -> one transposing read.  A fragment of row r: ids 0 .. 5 = (plane, half); B fragment of tile j, row r likewise
+            auto read_a = [&](auto rc, auto idc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
+                ra[r & 1][sp][hh] = rd(gab, r * 4 * GBLK + 256 * sp + hh * GBLK);
+            };
+            auto read_b = [&](auto rc, auto jc, auto idc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value, j = decltype(jc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
+                rb[(j >> 1) & 1][j & 1][sp][hh] = rd(xbb[j], r * 5 * XBLK + 256 * sp + hh * XBLK);
+            };
+            // the fragments of row 0, pair 0 (and its gradient fragment): nothing to hide them under
+            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_a(std::integral_constant<int, 0>{}, idc); });
+            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, idc); });
+            if constexpr (J > 1)
+                wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, idc); });
+            __builtin_amdgcn_sched_barrier(0);
+            wg_static_for<0, ROWS>([&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                wg_static_for<0, NP>([&](auto jpc) __attribute__((always_inline)) {
+                    constexpr int jp = decltype(jpc)::value;
+                    constexpr int j0 = 2 * jp, nt = (j0 + 1 < J) ? 2 : 1, nm = 6 * nt;        // tiles / MFMAs of this pair
+                    constexpr int gbase = r * MPR + jp * 12;
+                    // next pair (possibly in the next row); reads to spread over this pair's MFMAs
+                    constexpr bool last_pair = jp + 1 == NP, last_row = r + 1 == ROWS;
+                    constexpr int nr = last_pair ? r + 1 : r, njp = last_pair ? 0 : jp + 1;
+                    constexpr int nj0 = 2 * njp, nnt = (nj0 + 1 < J) ? 2 : 1;
+                    constexpr bool have_next = !(last_pair && last_row);
+                    constexpr int NRD = have_next ? (6 * nnt + (last_pair ? 6 : 0)) : 0;
+                    // (front-loaded: the last read is issued >= 4 MFMAs before the pair that consumes it starts)
+                    constexpr int RDEN = nm > 5 ? nm - 4 : 2, RPH = (NRD + RDEN - 1) / RDEN;   // reads per MFMA
+                    // operands of this pair
+                    wg_bf16x8 fa[3], fbv[2][3];
 #pragma unroll
                     for (int sp = 0; sp < 3; ++sp) {
-                        const wg_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp));
-                        const wg_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp + rd_stride));
-                        typedef short s16x8 __attribute__((ext_vector_type(8)));
-                        const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                        out[sp] = __builtin_bit_cast(wg_bf16x8, v);
+                        fa[sp] = pack(ra[r & 1][sp][0], ra[r & 1][sp][1]);
+#pragma unroll
+                        for (int q = 0; q < nt; ++q) fbv[q][sp] = pack(rb[jp & 1][q][sp][0], rb[jp & 1][q][sp][1]);
                     }
-                };
-                // A (gradient tile, 16 pixels per row: the pixel phase is the lane's m): constant per-lane offset + a row stride
-                const char *ga_ptr = s_gb + ((pg * ROWS * 4 + 2 * half) * (COB / 32) + aa_w) * 768 + m4 * 64 + lch * 2;
-                constexpr int GA_ROW = 4 * (COB / 32) * 768, GA_RD = (COB / 32) * 768, XB_RD = (CIB / 32) * 768;
-                // B (input halo tile): pixel = (row + ty) * WT + tx + 8 half + m (+ 4 for the second read)
-                // wave-uniform part (SGPRs) + one per-lane term: 2 address registers instead of 2 J
-                int xpix[J], xblk[J];
-                const int lpix = 8 * half + m4, lblk = lch * 2;
+                    if constexpr (jp == 0) {
+                        if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const int tap = t_tap[j] >> 10, bb = t_tap[j] & 31;
-                    const int ty = tap / KH, tx = tap - ty * KH;
-                    xpix[j] = __builtin_amdgcn_readfirstlane((pg * ROWS + ty) * WT + tx);
-                    xblk[j] = __builtin_amdgcn_readfirstlane(bb * 768);
-                }
-                auto xaddr = [&](int j) {
-                    const int P = xpix[j] + lpix;
-                    return s_xb + (P >> 2) * ((CIB / 32) * 768) + (P & 3) * 64 + xblk[j] + lblk;
-                };
-                // (two workgroups per CU: the other workgroup's wave covers the LDS latency, one fragment set is enough -- 24 registers)
-                constexpr int NSET = WPS == 1 ? 2 : 1;
-                wg_bf16x8 ca[3], cb[NSET][2][3];
-                auto read_pair = [&](int jp, int set) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int j = 2 * jp + q < J ? 2 * jp + q : J - 1;
-                        frag(xaddr(j), cb[set][q], XB_RD);
-                    }
-                };
-#pragma unroll 1
-                for (int r = 0; r < ROWS; ++r) {
-                    frag(ga_ptr, ca, GA_RD);
-                    if (NSET == 2) read_pair(0, 0);
-                    if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
-#pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) bsum += ((float)ca[0][kk] + (float)ca[1][kk]) + (float)ca[2][kk];
-                    }
-#pragma unroll
-                    for (int jp = 0; jp < NP; ++jp) {
-                        if (NSET == 1) read_pair(jp, 0);
-                        else if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const int cs = NSET == 1 ? 0 : (jp & 1);
-#pragma unroll
-                        for (int p = 0; p < 6; ++p) {
-                            acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][0][TB[p]], acc[2 * jp], 0, 0, 0);
-                            if (2 * jp + 1 < J)
-                                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
+                            for (int kk = 0; kk < 8; ++kk) bsum += ((float)fa[0][kk] + (float)fa[1][kk]) + (float)fa[2][kk];
                         }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    wg_static_for<0, nm>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value, pq = nt == 2 ? i / 2 : i, q = nt == 2 ? i % 2 : 0;
+                        constexpr int g = gbase + i;
+                        acc[j0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[pq]], fbv[q][TB[pq]], acc[j0 + q], 0, 0, 0);
+                        // fragment reads of the next pair
+#ifdef WG_ABL_NOREADS
+                        if constexpr (r == 0 && jp == 0)
+#endif
+                        wg_static_for<0, RPH>([&](auto kc) __attribute__((always_inline)) {
+                            constexpr int id = i * RPH + decltype(kc)::value;
+                            if constexpr (id < NRD) {
+                                if constexpr (id < 6 * nnt) {
+                                    read_b(std::integral_constant<int, (have_next ? nr : 0)>{}, std::integral_constant<int, nj0 + id / 6>{},
+                                           std::integral_constant<int, id % 6>{});
+                                } else {
+                                    read_a(std::integral_constant<int, (have_next ? nr : 0)>{}, std::integral_constant<int, id - 6 * nnt>{});
+                                }
+                            }
+                        });
+                        // the next pixel tile: loads behind every second MFMA from the start, item steps in the tail of the phase
+#ifndef WG_ABL_NOITEMS       /* (ablation builds: timing only, results invalid) */
+                        if constexpr ((g & 1) == 0 && g / 2 < N_IT) {
+                            item_load(std::integral_constant<int, (g / 2 < N_IT ? g / 2 : 0)>{});
+                        }
+                        if constexpr (g >= G0 && g < G0 + 5 * N_IT) {
+                            item_step(std::integral_constant<int, (g >= G0 && g < G0 + 5 * N_IT ? (g - G0) / 5 : 0)>{},
+                                      std::integral_constant<int, (g >= G0 ? (g - G0) % 5 : 0)>{}, oset);
+                        }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
-                    }
-                    ga_ptr += GA_ROW;
-#pragma unroll
-                    for (int j = 0; j < J; ++j) xpix[j] += WT;
+                    });
+                });
+            });
+            __syncthreads();          // the other set is complete, this one is consumed
+        }
+    } else {
+    if (PIPE && t_begin < t_end) load_batch(t_begin, 0);
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            if (PIPE) {
+                __syncthreads();  // previous tile's fragments are consumed
+                store_batch(0);
+                __syncthreads();
+                if (!SPREAD && tile + 1 < t_end) load_batch(tile + 1, 0);  // in flight during the MFMA phase below
+            } else {
+                load_batch(tile, 0);
+                __syncthreads();
+                store_batch(0);
+    #pragma unroll
+                for (int bt = 1; bt < NBATCH; ++bt) {
+                    load_batch(tile, bt);
+                    store_batch(bt);
                 }
-            } else if constexpr (BF) {
-                float ra[8], rb[8][J];
-                wg_bf16x8 ca, cb[J];
-                auto read_row = [&]() {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        ra[kk] = smem[go + 2 * kk * COB];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) rb[kk][j] = smem[xo[j] + 2 * kk * CIB];
+                __syncthreads();
+            }
+            // ---- K loop: two pixels per MFMA, software-pipelined one k-step deep: the fragments of step
+            // k+1 (one A value, J B values per lane) are read into the second register set BEFORE the J MFMAs
+            // of step k are issued, so the LDS latency hides under >= J*64 matrix-core cycles even with a
+            // single wave per SIMD.  A tile row (16 pixels = 8 k-steps) is fully unrolled: every LDS address
+            // is row base + compile-time offset, including the first step of the next row.
+            {
+                // integer float-offsets into smem[] (keeps the accesses provably LDS: ds_read with immediates)
+                int go = half * COB + li + aa_w * 32 + pg * ROWS * TWG * COB;
+                int xo[J];
+    #pragma unroll
+                for (int j = 0; j < J; ++j) xo[j] = PX * COB + half * CIB + li + t_boff[j] + pg * ROWS * WT * CIB;
+                if constexpr (BF == 2) {
+                    // TNR_MMA_BF16X3: both tiles are pre-split in LDS (wg_x3_off); a fragment = 6 transposing reads (2 x 4 pixels x 3
+                    // planes), six MFMAs per output tile and tile row.  The J tiles of a wave are taken two at a time (two independent
+                    // accumulator chains); the fragments of the next pair are read while the current pair's 12 MFMAs run.
+                    constexpr int NP = (J + 1) / 2;
+                    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+                    // lane roles of the transposing read: 16-lane group -> (pixel half h = lane >> 5, channel half cg); inside the group
+                    // lane 4 m + q supplies pixel m, channels 4 q .. 4 q + 3
+                    const int cg = (lane >> 4) & 1, m4 = (lane >> 2) & 3, q4 = lane & 3;
+                    const int lch = 16 * cg + 4 * q4;                                    // channel inside the 32-channel block
+                    auto frag = [&](const char *base, wg_bf16x8 (&out)[3], int rd_stride) {
+    #pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) {
+                            const wg_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp));
+                            const wg_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + 256 * sp + rd_stride));
+                            typedef short s16x8 __attribute__((ext_vector_type(8)));
+                            const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                            out[sp] = __builtin_bit_cast(wg_bf16x8, v);
+                        }
+                    };
+                    // A (gradient tile, 16 pixels per row: the pixel phase is the lane's m): constant per-lane offset + a row stride
+                    const char *ga_ptr = s_gb + ((pg * ROWS * 4 + 2 * half) * (COB / 32) + aa_w) * 768 + m4 * 64 + lch * 2;
+                    constexpr int GA_ROW = 4 * (COB / 32) * 768, GA_RD = (COB / 32) * 768, XB_RD = (CIB / 32) * 768;
+                    // B (input halo tile): pixel = (row + ty) * WT + tx + 8 half + m (+ 4 for the second read)
+                    // wave-uniform part (SGPRs) + one per-lane term: 2 address registers instead of 2 J
+                    int xpix[J], xblk[J];
+                    const int lpix = 8 * half + m4, lblk = lch * 2;
+    #pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const int tap = t_tap[j] >> 10, bb = t_tap[j] & 31;
+                        const int ty = tap / KH, tx = tap - ty * KH;
+                        xpix[j] = __builtin_amdgcn_readfirstlane((pg * ROWS + ty) * WT + tx);
+                        xblk[j] = __builtin_amdgcn_readfirstlane(bb * 768);
                     }
-                };
-                auto pack_row = [&]() {
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        bsum += ra[kk];
-                        ca[kk] = (__bf16)ra[kk];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) cb[j][kk] = (__bf16)rb[kk][j];
+                    auto xaddr = [&](int j) {
+                        const int P = xpix[j] + lpix;
+                        return s_xb + (P >> 2) * ((CIB / 32) * 768) + (P & 3) * 64 + xblk[j] + lblk;
+                    };
+                    // (two workgroups per CU: the other workgroup's wave covers the LDS latency, one fragment set is enough -- 24 registers)
+                    constexpr int NSET = WPS == 1 ? 2 : 1;
+                    wg_bf16x8 ca[3], cb[NSET][2][3];
+                    auto read_pair = [&](int jp, int set) {
+    #pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int j = 2 * jp + q < J ? 2 * jp + q : J - 1;
+                            frag(xaddr(j), cb[set][q], XB_RD);
+                        }
+                    };
+    #pragma unroll 1
+                    for (int r = 0; r < ROWS; ++r) {
+                        frag(ga_ptr, ca, GA_RD);
+                        if (NSET == 2) read_pair(0, 0);
+                        if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
+    #pragma unroll
+                            for (int kk = 0; kk < 8; ++kk) bsum += ((float)ca[0][kk] + (float)ca[1][kk]) + (float)ca[2][kk];
+                        }
+    #pragma unroll
+                        for (int jp = 0; jp < NP; ++jp) {
+                            if (NSET == 1) read_pair(jp, 0);
+                            else if (jp + 1 < NP) read_pair(jp + 1, (jp + 1) & 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int cs = NSET == 1 ? 0 : (jp & 1);
+    #pragma unroll
+                            for (int p = 0; p < 6; ++p) {
+                                acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][0][TB[p]], acc[2 * jp], 0, 0, 0);
+                                if (2 * jp + 1 < J)
+                                    acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[TA[p]], cb[cs][1][TB[p]], acc[2 * jp + 1], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ga_ptr += GA_ROW;
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) xpix[j] += WT;
                     }
-                };
-                read_row();
-                pack_row();
-#pragma unroll 1
-                for (int r = 0; r < ROWS; ++r) {
-                    go += TWG * COB;
-#pragma unroll
-                    for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
-                    if (r + 1 < ROWS) read_row();
-                    if constexpr (SPREAD) {
-                        if (tile + 1 < t_end) {
-                            if constexpr (ROWS >= SPREAD_N) {
-                                if (r == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
-                                if (r == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
-                                if (r == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
-                            } else if (r == 0) {
-                                load_batch(tile + 1, 0);
+                } else if constexpr (BF) {
+                    float ra[8], rb[8][J];
+                    wg_bf16x8 ca, cb[J];
+                    auto read_row = [&]() {
+    #pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            ra[kk] = smem[go + 2 * kk * COB];
+    #pragma unroll
+                            for (int j = 0; j < J; ++j) rb[kk][j] = smem[xo[j] + 2 * kk * CIB];
+                        }
+                    };
+                    auto pack_row = [&]() {
+    #pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) {
+                            bsum += ra[kk];
+                            ca[kk] = (__bf16)ra[kk];
+    #pragma unroll
+                            for (int j = 0; j < J; ++j) cb[j][kk] = (__bf16)rb[kk][j];
+                        }
+                    };
+                    read_row();
+                    pack_row();
+    #pragma unroll 1
+                    for (int r = 0; r < ROWS; ++r) {
+                        go += TWG * COB;
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
+                        if (r + 1 < ROWS) read_row();
+                        if constexpr (SPREAD) {
+                            if (tile + 1 < t_end) {
+                                if constexpr (ROWS >= SPREAD_N) {
+                                    if (r == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
+                                    if (r == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
+                                    if (r == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
+                                } else if (r == 0) {
+                                    load_batch(tile + 1, 0);
+                                }
                             }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca, cb[j], acc[j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (r + 1 < ROWS) pack_row();
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca, cb[j], acc[j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (r + 1 < ROWS) pack_row();
-                }
-            } else {
-            float fa[2], fb[2][J];
-            fa[0] = smem[go];
-#pragma unroll
-            for (int j = 0; j < J; ++j) fb[0][j] = smem[xo[j]];
-#pragma unroll 1
-            for (int r = 0; r < ROWS; ++r) {
-#pragma unroll
-                for (int k = 0; k < TWG / 2; ++k) {
-                    const int cur = k & 1, nxt = cur ^ 1;
-                    // step k+1 of this row, or step 0 of the next row (row THG is valid LDS: never consumed)
-                    const int goff = (k + 1 < TWG / 2) ? 2 * (k + 1) * COB : TWG * COB;
-                    const int xoff = (k + 1 < TWG / 2) ? 2 * (k + 1) * CIB : WT * CIB;
-                    fa[nxt] = smem[go + goff];
-#pragma unroll
-                    for (int j = 0; j < J; ++j) fb[nxt][j] = smem[xo[j] + xoff];
-                    if constexpr (SPREAD) {
-                        if (r == 0 && tile + 1 < t_end) {
-                            if (k == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
-                            if (k == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
-                            if (k == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
+                } else {
+                float fa[2], fb[2][J];
+                fa[0] = smem[go];
+    #pragma unroll
+                for (int j = 0; j < J; ++j) fb[0][j] = smem[xo[j]];
+    #pragma unroll 1
+                for (int r = 0; r < ROWS; ++r) {
+    #pragma unroll
+                    for (int k = 0; k < TWG / 2; ++k) {
+                        const int cur = k & 1, nxt = cur ^ 1;
+                        // step k+1 of this row, or step 0 of the next row (row THG is valid LDS: never consumed)
+                        const int goff = (k + 1 < TWG / 2) ? 2 * (k + 1) * COB : TWG * COB;
+                        const int xoff = (k + 1 < TWG / 2) ? 2 * (k + 1) * CIB : WT * CIB;
+                        fa[nxt] = smem[go + goff];
+    #pragma unroll
+                        for (int j = 0; j < J; ++j) fb[nxt][j] = smem[xo[j] + xoff];
+                        if constexpr (SPREAD) {
+                            if (r == 0 && tile + 1 < t_end) {
+                                if (k == 0) load_group(tile + 1, std::integral_constant<int, 0>{});
+                                if (k == 1) load_group(tile + 1, std::integral_constant<int, 1>{});
+                                if (k == 2) load_group(tile + 1, std::integral_constant<int, 2>{});
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
+                        bsum += fa[cur];
+    #pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][j], acc[j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    bsum += fa[cur];
-#pragma unroll
-                    for (int j = 0; j < J; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][j], acc[j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    go += TWG * COB;
+    #pragma unroll
+                    for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
                 }
-                go += TWG * COB;
-#pragma unroll
-                for (int j = 0; j < J; ++j) xo[j] += WT * CIB;
-            }
+                }
             }
         }
+    
     }
 
     // ---- pixel groups: group p = 1 .. KS-1 hands its accumulators (and bias sums) to group 0 through LDS, in order
@@ -643,7 +861,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
 }
 
 struct WgPlan {
-    int a_t, b_t, thg, ks, wps;
+    int a_t, b_t, thg, ks, wps, db;
     int ncib, ncob;
     int KoutP, KinVP, cinp32;
     int tiles_x, tiles_y, tiles_total, splits, tiles_per_split;
@@ -674,13 +892,20 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     const int wpg0 = 4 / p.ks;
     p.wps = ((p.a_t * p.b_t * (s2d ? 4 : 9) + wpg0 - 1) / wpg0 >= 9) ? 1 : 2;      // WgCfg::WAVES_PER_SIMD
     // TNR_MMA_BF16X3, 3x3 classes: half-height tiles, two workgroups per CU (see wgrad_tile_kernel; TNR_WG_X3_OCC=1 keeps one)
-    static const int x3_occ = [] { const char *e = getenv("TNR_WG_X3_OCC"); return e ? atoi(e) : 2; }();
-    if (d->mma == TNR_MMA_BF16X3 && !s2d && x3_occ == 2 && p.wps == 1) {
+    static const int x3_occ = [] { const char *e = getenv("TNR_WG_X3_OCC"); return e ? atoi(e) : 3; }();
+    p.db = 0;
+    if (d->mma == TNR_MMA_BF16X3 && !s2d && x3_occ >= 2 && p.wps == 1) {
         if (p.b_t == 4) p.b_t = 2;               // 32 x 128 jobs become two 32 x 64 jobs (the 128-wide halo tile alone is 95 KB)
         const int ab2 = p.a_t * p.b_t;
         p.ks = (ab2 == 1 || ab2 == 2) ? 4 / ab2 : 1;
-        p.thg = ab2 == 1 ? 8 : 4;                // <= 66 KB of pre-split LDS image per workgroup, >= 2 tile rows per pixel group
+        p.thg = ab2 == 1 ? 8 : 4;                // <= 66 KB of pre-split LDS image per tile set, >= 2 tile rows per pixel group
         p.wps = 2;
+        // TNR_WG_X3_OCC=3 (default): the pipelined one-workgroup form with two tile sets (wgrad_tile_kernel<.., DB>), zero-padded 3x3 only
+        if (x3_occ == 3 && d->mode == TNR_CONV_3x3 && d->pad_mode == 0 && p.b_t <= 2 &&
+            (int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->Ho * d->Wo * d->g.ctot < (1LL << 30)) {
+            p.wps = 1;
+            p.db = 1;
+        }
     }
     p.cinp32 = tnr_round_up(d->Cin, 32);
     p.KinVP = vch;
@@ -706,7 +931,7 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     return 0;
 }
 
-template <int MODE, int A_T, int B_T, int THG, int BF, int WPS = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD>
+template <int MODE, int A_T, int B_T, int THG, int BF, int WPS = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>::WAVES_PER_SIMD, bool DB = false>
 int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     // + one halo row: the k-loop's last prefetch reads one row past the x tile (never consumed)
@@ -715,7 +940,8 @@ int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     constexpr size_t lds_x3 = (size_t)(THG * 16 * 32 * A_T + (((THG + KH - 1) * (16 + KH - 1) + 3) / 4) * 4 * 32 * B_T) * 6;
     using Cfg = WgCfg<A_T, B_T, (MODE == TNR_CONV_4x4_S2 ? 4 : 9)>;
     constexpr size_t lds_red = Cfg::KS > 1 ? (size_t)(Cfg::WPG * Cfg::J * 16 * 64 + Cfg::WPG * 64) * sizeof(float) : 0;   // pixel-group exchange
-    constexpr size_t lds_tile = BF == 2 ? lds_x3 : lds_f32;
+    constexpr size_t lds_db = 2 * ((size_t)(THG * 16 * 32 * A_T + (THG + KH - 1) * 20 * 32 * B_T) * 6 + 3072);      // two tile sets (halo rows of 20 pixels) + their dump areas
+    constexpr size_t lds_tile = DB ? lds_db : (BF == 2 ? lds_x3 : lds_f32);
     constexpr size_t lds = lds_tile > lds_red ? lds_tile : lds_red;
     constexpr bool one_wg = WPS == 1;
     if constexpr (BF == 2 && lds > 160 * 1024) {       // (a tile class plan_wgrad never picks in this mode)
@@ -725,7 +951,7 @@ int launch_wgrad_t(const WgK &k, int jobs, hipStream_t s) {
     // (TNR_MMA_BF16X3 classes inherited from the fp32 plan may exceed 80 KB: the LDS then limits them to one workgroup per CU)
     static_assert(lds <= ((one_wg || BF == 2) ? 160 : 80) * 1024, "wgrad tile exceeds the LDS budget of its occupancy regime");
     static bool attr_done = false;
-    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF, WPS>;
+    auto fn = wgrad_tile_kernel<MODE, A_T, B_T, THG, BF, WPS, DB>;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess) {
@@ -748,6 +974,12 @@ int launch_wgrad(const WgK &k, int jobs, hipStream_t s) {
 template <int MODE>
 int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
     constexpr int THS = (MODE == TNR_CONV_4x4_S2) ? 8 : 16;   // tile rows of the pixel-split classes (plan_wgrad: ks > 1)
+    if constexpr (MODE == TNR_CONV_3x3) {
+        if (k.bf == 2 && p.db) {                              // TNR_MMA_BF16X3: the pipelined form (plan_wgrad)
+            if (p.a_t == 2) return p.b_t == 2 ? launch_wgrad_t<MODE, 2, 2, 4, 2, 1, true>(k, jobs, s) : launch_wgrad_t<MODE, 2, 1, 4, 2, 1, true>(k, jobs, s);
+            return p.b_t == 2 ? launch_wgrad_t<MODE, 1, 2, 4, 2, 1, true>(k, jobs, s) : launch_wgrad_t<MODE, 1, 1, 8, 2, 1, true>(k, jobs, s);
+        }
+    }
     if constexpr (MODE != TNR_CONV_4x4_S2) {
         if (k.bf == 2 && p.wps == 2 && p.b_t <= 2) {          // TNR_MMA_BF16X3: half-height tiles, two workgroups per CU (plan_wgrad)
             if (p.a_t == 2) return p.b_t == 2 ? launch_wgrad_t<MODE, 2, 2, 4, 2, 2>(k, jobs, s) : launch_wgrad_t<MODE, 2, 1, 4, 2, 2>(k, jobs, s);
@@ -810,7 +1042,7 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
         const tnr_wgrad_desc &d0 = descs[0], &di = descs[i];
         TNR_REQUIRE(di.mode == d0.mode && di.N == d0.N && di.H == d0.H && di.W == d0.W && di.Ho == d0.Ho && di.Wo == d0.Wo,
                     "wgrad_group: layer %d does not share the pixel geometry of layer 0", i);
-        TNR_REQUIRE(plans[i].a_t == plans[0].a_t && plans[i].b_t == plans[0].b_t && plans[i].thg == plans[0].thg && plans[i].ks == plans[0].ks,
+        TNR_REQUIRE(plans[i].a_t == plans[0].a_t && plans[i].b_t == plans[0].b_t && plans[i].thg == plans[0].thg && plans[i].ks == plans[0].ks && plans[i].db == plans[0].db,
                     "wgrad_group: layer %d (%d->%d channels) is not in the tile class of layer 0 (%d->%d)", i, di.Cin,
                     di.Cout, d0.Cin, d0.Cout);
     }
