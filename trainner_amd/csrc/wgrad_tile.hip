@@ -894,6 +894,7 @@ int plan_wgrad(const tnr_wgrad_desc *d, WgPlan &p, int group_jobs) {
     // TNR_MMA_BF16X3, 3x3 classes: half-height tiles, two workgroups per CU (see wgrad_tile_kernel; TNR_WG_X3_OCC=1 keeps one)
     static const int x3_occ = [] { const char *e = getenv("TNR_WG_X3_OCC"); return e ? atoi(e) : 3; }();
     p.db = 0;
+    if (d->mma == TNR_MMA_BF16X3 && s2d && x3_occ >= 2 && p.a_t == 2 && p.b_t == 2) p.thg = 4;       // (dispatch_wgrad: two workgroups per CU)
     if (d->mma == TNR_MMA_BF16X3 && !s2d && x3_occ >= 2 && p.wps == 1) {
         if (p.b_t == 4) p.b_t = 2;               // 32 x 128 jobs become two 32 x 64 jobs (the 128-wide halo tile alone is 95 KB)
         const int ab2 = p.a_t * p.b_t;
@@ -987,6 +988,10 @@ int dispatch_wgrad(const WgK &k, const WgPlan &p, int jobs, hipStream_t s) {
         }
     }
     if (p.a_t == 2) {
+        if constexpr (MODE == TNR_CONV_4x4_S2) {
+            // TNR_MMA_BF16X3: the 8-row tile's pre-split image is 109 KB (one workgroup per CU, nothing hides the refill); 4 rows: 58 KB, two
+            if (p.b_t == 2 && k.bf == 2 && p.thg == 4) return launch_wgrad_t<MODE, 2, 2, 4, 2, 2>(k, jobs, s);
+        }
         if (p.b_t == 2) return launch_wgrad<MODE, 2, 2, 8>(k, jobs, s);
         return launch_wgrad<MODE, 2, 1, THS>(k, jobs, s);
     }
