@@ -306,6 +306,7 @@ def main():
 
     model = make_model(args.batch, args.crop, rank, world, args.netd, args.amp)
     assert model.dp.world_size == world and (world == 1 or model.dp.active)
+    world_observed = model.dp.observed_world_size()      # a collective when world > 1: EVERY rank calls it (rank 0 prints it)
     LR, HR = synthetic(args.batch, args.crop, 1000 + rank, device)      # this rank's shard of the global batch
     data = {"LR": LR, "HR": HR}
 
@@ -380,7 +381,7 @@ def main():
             traffic, traffic_src = pmc_traffic(fam, "f32" if args.amp else args.mma)
             peak = PEAK_BF16_MFMA_TFLOPS if args.amp else (PEAK_BF16X3_TFLOPS if args.mma == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
             if fam == "conv_chain" and args.mma == "bf16x3" and not args.amp and ops.CONV_SWEEP:
-                kname = "conv_sweep_kernel (a dense block's 5 convolutions per launch, forward and data-gradient; bf16x3)"
+                kname = "conv_sweep4_kernel (a dense block's 5 convolutions per launch, forward and data-gradient; bf16x3)"
             roof = {"bound": "mfma", "kernel": kname,
                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(tf / peak, 4), "peak_note": (
@@ -442,7 +443,7 @@ def main():
             "config": {"workload": "ESRGAN RRDBNet-23 x4 + Discriminator_VGG(%d) + VGG19-conv5_4, batch %d/GPU, %d->%d, "
                                    "L1+perceptual+RaGAN, clip+Adam (BASELINE configs[1])" % (args.crop, args.batch, args.crop // 4, args.crop),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                       "world_size_observed": model.dp.observed_world_size(),
+                       "world_size_observed": world_observed,
                        "mma": "bf16 operands (use_amp)" if args.amp else MMA_TEXT[args.mma],
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none"},
