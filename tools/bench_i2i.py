@@ -48,11 +48,7 @@ datasets:
 path:
   root: {root}
 network_G:
-  which_model_G: resnet_net
-  n_blocks: 9
-  ngf: 64
-  norm_type: instance
-network_D:
+{netg}network_D:
   which_model_D: patchgan
   in_nc: {d_in}
   nf: 64
@@ -123,6 +119,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--amp", action="store_true")
+    ap.add_argument("--netg", choices=["resnet", "unet"], default="resnet",
+                    help="resnet: ResnetGenerator-9 (BASELINE configs[4]); unet: the reference's Pix2Pix default unet_net (8 downs at 256, BatchNorm)")
     args = ap.parse_args()
     from trainner_amd import hip, ops
     from trainner_amd.models import create_model
@@ -133,7 +131,9 @@ def main():
     cyc = args.model == "cyclegan"
     yml = os.path.join(root, "bench.yml")
     with open(yml, "w") as f:          # the reference's options/i2i/train_{pix2pix,cyclegan}.yml with the ResNet generator
-        f.write(YAML.format(model=args.model, amp="true" if args.amp else "false", pool=50 if cyc else 0, batch=args.batch, crop=args.size,
+        netg = ("  which_model_G: resnet_net\n  n_blocks: 9\n  ngf: 64\n  norm_type: instance\n" if args.netg == "resnet" else
+                "  which_model_G: unet_net\n  ngf: 64\n  norm_type: batch\n")
+        f.write(YAML.format(netg=netg, model=args.model, amp="true" if args.amp else "false", pool=50 if cyc else 0, batch=args.batch, crop=args.size,
                             root=root, d_in=3 if cyc else 6, pixel_weight=10 if cyc else 100,
                             idt="  lambda_identity: 0.5\n" if cyc else ""))
     torch.manual_seed(1234)
@@ -161,10 +161,12 @@ def main():
         "metric": "images/sec (G+D step), %s %dx%d" % (args.model, args.size, args.size), "value": round(imgs / dt, 2), "unit": "img/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
         "higher_is_better": True, "dtype": "bf16" if args.amp else "f32", "data": "synthetic", "variant": True,
-        "config": {"workload": "%s: ResnetGenerator-9 (ngf 64, InstanceNorm) + PatchGAN (ndf 64), batch %d, %dx%d, "
-                               "vanilla GAN (standard form) + L1%s (BASELINE configs[4])"
-                               % (args.model, args.batch, args.size, args.size, ", identity 0.5, pool 50" if args.model == "cyclegan" else "")},
-        "conv_gflop_per_img": round(fl / 1e9, 1), "step_tflops": round(fl * imgs / dt / 1e12, 2),
+        "config": {"workload": "%s: %s + PatchGAN (ndf 64), batch %d, %dx%d, vanilla GAN (standard form) + L1%s (BASELINE configs[4])"
+                               % (args.model, "ResnetGenerator-9 (ngf 64, InstanceNorm)" if args.netg == "resnet" else "UnetGenerator (8 downs, ngf 64, BatchNorm)",
+                                  args.batch, args.size, args.size, ", identity 0.5, pool 50" if args.model == "cyclegan" else ""),
+                   "mma": os.environ.get("TNR_MMA", "bf16x3")},
+        "conv_gflop_per_img": round(fl / 1e9, 1) if args.netg == "resnet" else None,
+        "step_tflops": round(fl * imgs / dt / 1e12, 2) if args.netg == "resnet" else None,
         "losses": {k: round(v, 5) for k, v in log.items()}}))
 
 
