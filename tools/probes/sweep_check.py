@@ -62,69 +62,74 @@ def block(N, H, W, seed, grad_shape, with_r2=True):
     return run
 
 
-ok = True
-assert ops.MMA == hip.MMA_BF16X3
-TIME_ONLY = "--time-only" in sys.argv
-for shape in [] if TIME_ONLY else [(4, 16, 16), (1, 16, 32), (2, 40, 72), (1, 8, 32), (2, 24, 24), (1, 10, 20), (4, 32, 32), (3, 128, 128), (20, 128, 128), (5, 64, 96)]:
+def main():
+    ok = True
+    assert ops.MMA == hip.MMA_BF16X3
+    TIME_ONLY = "--time-only" in sys.argv
+    for shape in [] if TIME_ONLY else [(4, 16, 16), (1, 16, 32), (2, 40, 72), (1, 8, 32), (2, 24, 24), (1, 10, 20), (4, 32, 32), (3, 128, 128), (20, 128, 128), (5, 64, 96)]:
+        for grad_shape in (False, True):
+            run = block(*shape, seed=11, grad_shape=grad_shape, with_r2=(shape[0] % 2 == 1))
+            rb, ro, _ = run("layers")
+            for rep in range(2):
+                for how in ("chain", "sweep"):
+                    gb, go, _ = run(how)
+                    eb, eo = torch.equal(gb, rb), torch.equal(go, ro)
+                    if not (eb and eo):
+                        ok = False
+                        db = (gb - rb).abs()
+                        bad = (db > 0).nonzero()
+                        first = bad[0].tolist() if len(bad) else None
+                        per_group = [float(db[..., lo:hi].max()) for lo, hi in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 192))]
+                        print("MISMATCH", shape, "grad" if grad_shape else "fwd", how, "rep", rep, "buf max|d| per group", per_group,
+                              "out max|d| %.3e" % float((go - ro).abs().max()), "first bad", first, "nbad", len(bad))
+            print(shape, "grad" if grad_shape else "fwd", "done; chain error flag", ops.chain_error_flag(), flush=True)
+    if not TIME_ONLY:
+        print("BIT-EQUALITY", "OK" if ok else "FAILED")
+
+    N, H, W = 16, 128, 128
+    fl = sum(2.0 * N * H * W * 9 * ci * co for ci, co in [(nf + k * gc, gc) for k in range(4)] + [(nf + 4 * gc, nf)])
     for grad_shape in (False, True):
-        run = block(*shape, seed=11, grad_shape=grad_shape, with_r2=(shape[0] % 2 == 1))
-        rb, ro, _ = run("layers")
-        for rep in range(2):
-            for how in ("chain", "sweep"):
-                gb, go, _ = run(how)
-                eb, eo = torch.equal(gb, rb), torch.equal(go, ro)
-                if not (eb and eo):
-                    ok = False
-                    db = (gb - rb).abs()
-                    bad = (db > 0).nonzero()
-                    first = bad[0].tolist() if len(bad) else None
-                    per_group = [float(db[..., lo:hi].max()) for lo, hi in ((0, 64), (64, 96), (96, 128), (128, 160), (160, 192))]
-                    print("MISMATCH", shape, "grad" if grad_shape else "fwd", how, "rep", rep, "buf max|d| per group", per_group,
-                          "out max|d| %.3e" % float((go - ro).abs().max()), "first bad", first, "nbad", len(bad))
-        print(shape, "grad" if grad_shape else "fwd", "done; chain error flag", ops.chain_error_flag(), flush=True)
-if not TIME_ONLY:
-    print("BIT-EQUALITY", "OK" if ok else "FAILED")
+        run = block(N, H, W, seed=5, grad_shape=grad_shape)
+        _, _, st = run("layers")
+        for how in (("sweep",) if TIME_ONLY else ("chain", "sweep")):
+            ops.CONV_SWEEP = how == "sweep"
+            us = timeit(lambda: ops.conv_chain(st))
+            print("%-5s %-6s %8.1f us  %6.1f TFLOP/s fp32-equivalent" % ("grad" if grad_shape else "fwd", how, us, fl / us / 1e6), flush=True)
+        ops.CONV_SWEEP = True
+    print("chain error flag:", ops.chain_error_flag())
 
-N, H, W = 16, 128, 128
-fl = sum(2.0 * N * H * W * 9 * ci * co for ci, co in [(nf + k * gc, gc) for k in range(4)] + [(nf + 4 * gc, nf)])
-for grad_shape in (False, True):
-    run = block(N, H, W, seed=5, grad_shape=grad_shape)
-    _, _, st = run("layers")
-    for how in (("sweep",) if TIME_ONLY else ("chain", "sweep")):
-        ops.CONV_SWEEP = how == "sweep"
-        us = timeit(lambda: ops.conv_chain(st))
-        print("%-5s %-6s %8.1f us  %6.1f TFLOP/s fp32-equivalent" % ("grad" if grad_shape else "fwd", how, us, fl / us / 1e6), flush=True)
-    ops.CONV_SWEEP = True
-print("chain error flag:", ops.chain_error_flag())
-
-lib = hip.load()
-if hasattr(lib, "tnr_debug_sweep_timeline"):       # -DSW_TIMELINE probe build: where wave 0 of a workgroup spends its cycles
-    import ctypes as C
-    names = ["tile prologue", "neighbour wait", "A load issue", "vmcnt wait", "barrier", "DMA issue", "MFMA bodies (four-wave form: whole chunks, incl. 2 syncs + side work)",
-             "A split + LDS store", "epilogue", "  chunks with 3 N-tiles", "  chunks with 2 N-tiles", "  chunks with 1 N-tile", "", "", "kernel total", "slots"]
-    run = block(16, 128, 128, seed=5, grad_shape=False)
-    _, _, st = run("layers")
-    ops.conv_chain(st)
-    torch.cuda.synchronize()
-    out = (C.c_ulonglong * 16)()
-    lib.tnr_debug_sweep_timeline(out, 1)
-    out2 = (C.c_ulonglong * 16)()
-    if hasattr(lib, "tnr_debug_sweep_units"):
-        lib.tnr_debug_sweep_units(out2, 1)
-    reps = 5
-    for _ in range(reps):
+    lib = hip.load()
+    if hasattr(lib, "tnr_debug_sweep_timeline"):       # -DSW_TIMELINE probe build: where wave 0 of a workgroup spends its cycles
+        import ctypes as C
+        names = ["tile prologue", "neighbour wait", "A load issue", "vmcnt wait", "barrier", "DMA issue", "MFMA bodies (four-wave form: whole chunks, incl. 2 syncs + side work)",
+                 "A split + LDS store", "epilogue", "  chunks with 3 N-tiles", "  chunks with 2 N-tiles", "  chunks with 1 N-tile", "", "", "kernel total", "slots"]
+        run = block(16, 128, 128, seed=5, grad_shape=False)
+        _, _, st = run("layers")
         ops.conv_chain(st)
-    torch.cuda.synchronize()
-    lib.tnr_debug_sweep_timeline(out, 0)
-    wgs = 256 * reps
-    print("sweep timeline: mean cycles per workgroup and launch (wave 0; 4 tiles per workgroup), %d slots" % (out[15] // wgs))
-    for i, nm in enumerate(names):
-        if nm and nm != "slots":
-            print("   %-40s %10.0f  (%5.1f %%)" % (nm, out[i] / wgs, 100.0 * out[i] / max(out[14], 1)))
-    if hasattr(lib, "tnr_debug_sweep_units"):
-        lib.tnr_debug_sweep_units(out2, 0)
-        print("four-wave form, chunks with 3 N-tiles: mean cycles per unit (12 MFMAs = 384 cycles of matrix core) by unit class")
-        for i, nm in enumerate(["unit with the slot synchronisation", "first two units of a slot (weight DMA)", "units with an input-chunk item",
-                                "plain units", "plain units that read the next tap's A fragments"]):
-            if out2[8 + i]:
-                print("   %-50s %8.0f   (%d units per workgroup and launch)" % (nm, out2[i] / out2[8 + i], out2[8 + i] // wgs))
+        torch.cuda.synchronize()
+        out = (C.c_ulonglong * 16)()
+        lib.tnr_debug_sweep_timeline(out, 1)
+        out2 = (C.c_ulonglong * 16)()
+        if hasattr(lib, "tnr_debug_sweep_units"):
+            lib.tnr_debug_sweep_units(out2, 1)
+        reps = 5
+        for _ in range(reps):
+            ops.conv_chain(st)
+        torch.cuda.synchronize()
+        lib.tnr_debug_sweep_timeline(out, 0)
+        wgs = 256 * reps
+        print("sweep timeline: mean cycles per workgroup and launch (wave 0; 4 tiles per workgroup), %d slots" % (out[15] // wgs))
+        for i, nm in enumerate(names):
+            if nm and nm != "slots":
+                print("   %-40s %10.0f  (%5.1f %%)" % (nm, out[i] / wgs, 100.0 * out[i] / max(out[14], 1)))
+        if hasattr(lib, "tnr_debug_sweep_units"):
+            lib.tnr_debug_sweep_units(out2, 0)
+            print("four-wave form, chunks with 3 N-tiles: mean cycles per unit (12 MFMAs = 384 cycles of matrix core) by unit class")
+            for i, nm in enumerate(["unit with the slot synchronisation", "first two units of a slot (weight DMA)", "units with an input-chunk item",
+                                    "plain units", "plain units that read the next tap's A fragments"]):
+                if out2[8 + i]:
+                    print("   %-50s %8.0f   (%d units per workgroup and launch)" % (nm, out2[i] / out2[8 + i], out2[8 + i] // wgs))
+
+
+if __name__ == "__main__":
+    main()

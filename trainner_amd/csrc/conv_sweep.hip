@@ -88,6 +88,8 @@ struct SweepK {
     unsigned *progress;                // [tiles]: base + (stages of that tile whose output is visible)
     unsigned base;
     unsigned *err;
+    int nxcd;                          // 8: one dispenser per XCD (contiguous shares), 1: one for the whole grid
+    unsigned *disp;                    // [9] tile dispensers of the four-wave form (one per XCD) + finished-workgroup count; zero between launches
     const float *wq;                   // pre-split weight stream (tnr_conv_sweep_pack)
     int wq_bytes;
     ConvK st[SW_NSTAGE];
@@ -569,9 +571,26 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     float *s_a = smem, *s_b = smem + 2 * SW_A_FLOATS;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
-    int b = blockIdx.x;
+    // Tiles are DISPENSED, not dealt: a workgroup takes the next tile from an atomic counter (one for the whole grid by default;
+    // TNR_SWEEP_DISPENSERS=8: one per XCD over contiguous shares, so that the halo re-reads of neighbouring tiles meet in one L2 -- no
+    // faster in the measurements).  With the static deal (tile = b + grid * k) the hand-off needs EVERY workgroup of the grid resident:
+    // with one CU held by another kernel (tools/probes/sweep_hog.py, profiles/r03ad_sweep_hog*.txt) the eight-wave form ran 4.0x
+    // slower and this form 1.5x with per-XCD shares, 1.10x with one dispenser -- the tiles of the missing workgroup stall all their
+    // neighbours until a CU comes free.  Dispensed in order, a tile's neighbours are always taken by workgroups that ARE running; a
+    // handful of resident workgroups is enough for progress, and a CU (or an XCD) that runs slower simply takes fewer tiles.
     const int g = gridDim.x;
-    if ((g & 7) == 0) b = (b & 7) * (g >> 3) + (b >> 3);          // (see conv_sweep_kernel)
+    const bool xcd_split = (g & 7) == 0 && c.nxcd == 8;
+    const int xcd = xcd_split ? ((int)blockIdx.x & 7) : 0, per_x = xcd_split ? (g >> 3) : g;
+    __shared__ int s_next_tile;
+    auto next_tile = [&]() __attribute__((always_inline)) {
+        if (tid == 0) {
+            const int slot = (int)atomicAdd(c.disp + xcd, 1u);
+            const int kk = slot / per_x, ii = slot - kk * per_x;
+            s_next_tile = xcd * per_x + ii + g * kk;
+        }
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(s_next_tile);
+    };
     const ConvK &x0 = c.st[0];
     const __amdgpu_buffer_rsrc_t x_rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x0.x), 0, (int)((unsigned)x0.N * x0.H * x0.W * x0.x_ct * 4u), 0x00020000);
@@ -588,7 +607,7 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     const unsigned long long tl_begin = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (int tile = b; tile < c.tiles; tile += g) {
+    for (int tile = next_tile(); tile < c.tiles; tile = next_tile()) {
         SW_T(t_tile0);
         const int n = tile / c.tpi, rem = tile - n * c.tpi;
         const int ty = rem / c.tiles_x, tx = rem - ty * c.tiles_x;
@@ -800,6 +819,10 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (pend_tile >= 0 && tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && atomicAdd(c.disp + 8, 1u) == (unsigned)g - 1u) {      // the last workgroup out leaves the dispensers at zero for the next launch
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(c.disp + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef SW_TIMELINE
     if (tid == 0) {
         tl[14] = __builtin_amdgcn_s_memtime() - tl_begin;
@@ -914,6 +937,9 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     TNR_REQUIRE(c.tpi <= cus, "conv_sweep: the %d tiles of an image exceed the %d co-resident workgroups", c.tpi, cus);
     c.progress = ws;
     c.err = ws + ws_bytes / 4 - 1;
+    static const int nxcd = [] { const char *e = getenv("TNR_SWEEP_DISPENSERS"); return e ? atoi(e) : 1; }();
+    c.nxcd = nxcd == 1 ? 1 : 8;
+    c.disp = ws + (ws_bytes / 4 - 1 - 4 - 16);      // (inside conv_chain's per-CU counter area, which no sweep launch touches; zero-initialised)
     c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
     c.wq = static_cast<const float *>(image);
     c.wq_bytes = sw_total_units(c.nck0) * SW_UNIT_FLOATS * (int)sizeof(float);
