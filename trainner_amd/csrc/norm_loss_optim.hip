@@ -209,7 +209,38 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
         invstd += (size_t)blockIdx.y * C;
         sums += (size_t)blockIdx.y * 2 * C;
     }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stride % G == 0) {
+        // a thread keeps its channel group over the whole loop (every power-of-two channel count): the per-channel constants are
+        // computed once, with the same expressions as below (bit-identical), and the pixel index advances by a constant --
+        // no 64-bit division, no double-precision loads per element (3.8 TB/s before)
+        const int cg = (int)(e0 % G);
+        float is4[4], gm4[4], kk4[4], mu4[4], ga4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cg * 4 + k;
+            is4[k] = invstd[c];
+            gm4[k] = (float)sums[2 * c + 0] * inv_n;
+            kk4[k] = (float)sums[2 * c + 1] * is4[k] * is4[k] * inv_n;
+            mu4[k] = mean[c];
+            ga4[k] = gamma ? gamma[c] : 1.f;
+        }
+        const int64_t pstep = stride / G;
+        for (int64_t p = e0 / G; p < pixels; p += pstep) {
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gy + p * g_ct + g_co + cg * 4);
+            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
+            const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + p * z_ct + z_co + cg * 4);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = gv[k] * (yv[k] > 0.f ? 1.f : mslope);
+                o[k] = (g - gm4[k] - (zv[k] - mu4[k]) * kk4[k]) * is4[k] * ga4[k];
+            }
+            *reinterpret_cast<f32x4 *>(gz + p * o_ct + o_co + cg * 4) = o;
+        }
+        return;
+    }
+    for (int64_t e = e0; e < total; e += stride) {
         const int cg = (int)(e % G);
         const int64_t p = e / G;
         const f32x4 gv = *reinterpret_cast<const f32x4 *>(gy + p * g_ct + g_co + cg * 4);
