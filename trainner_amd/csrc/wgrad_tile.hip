@@ -433,7 +433,11 @@ wgrad_tile_kernel(const WgK ga) {
             return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_lds_s16x4 *)(base + imm));
         };
         typedef short s16x8 __attribute__((ext_vector_type(8)));
-        wg_s16x4 ra[2][3][2], rb[2][2][3][2];      // raw halves: [set][..][plane][half]
+        // raw halves.  B fragments are CACHED per halo row: tap (ty, tx) of tile row r reads halo row r + ty, which tap (ty - 1, tx) of row
+        // r + 1 reads again -- a tile row brings in ONE new halo row (3 fragments, one per tx) instead of 9 fragments (-45 % transposing
+        // reads at 4 rows, the kernel's first limiter: profiles/r03y_wgrad_ablation.txt).  [halo row mod 3][tx][plane][half]
+        static_assert(J == 9 && WPG == AB, "every wave owns the 9 taps of one (cout half, cin block) pair: tile j = tap j");
+        wg_s16x4 ra[2][3][2], rbx[3][3][3][2];
         auto pack = [&](const wg_s16x4 lo4, const wg_s16x4 hi4) __attribute__((always_inline)) {
             const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             return __builtin_bit_cast(wg_bf16x8, v);
@@ -463,15 +467,14 @@ wgrad_tile_kernel(const WgK ga) {
                 constexpr int r = decltype(rc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
                 ra[r & 1][sp][hh] = rd(gab, r * 4 * GBLK + 256 * sp + hh * GBLK);
             };
-            auto read_b = [&](auto rc, auto jc, auto idc) __attribute__((always_inline)) {
-                constexpr int r = decltype(rc)::value, j = decltype(jc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
-                rb[(j >> 1) & 1][j & 1][sp][hh] = rd(xbb[j], r * 5 * XBLK + 256 * sp + hh * XBLK);
+            auto read_x = [&](auto xrc, auto txc, auto idc) __attribute__((always_inline)) {        // halo row xr (relative to the pixel group), tap column tx
+                constexpr int xr = decltype(xrc)::value, tx = decltype(txc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
+                rbx[xr % 3][tx][sp][hh] = rd(xbb[tx], xr * 5 * XBLK + 256 * sp + hh * XBLK);
             };
             // the fragments of row 0, pair 0 (and its gradient fragment): nothing to hide them under
             wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_a(std::integral_constant<int, 0>{}, idc); });
-            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, idc); });
-            if constexpr (J > 1)
-                wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, idc); });
+            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, idc); });
+            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, idc); });
             __builtin_amdgcn_sched_barrier(0);
             wg_static_for<0, ROWS>([&](auto rc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value;
@@ -479,21 +482,20 @@ wgrad_tile_kernel(const WgK ga) {
                     constexpr int jp = decltype(jpc)::value;
                     constexpr int j0 = 2 * jp, nt = (j0 + 1 < J) ? 2 : 1, nm = 6 * nt;        // tiles / MFMAs of this pair
                     constexpr int gbase = r * MPR + jp * 12;
-                    // next pair (possibly in the next row); reads to spread over this pair's MFMAs
-                    constexpr bool last_pair = jp + 1 == NP, last_row = r + 1 == ROWS;
-                    constexpr int nr = last_pair ? r + 1 : r, njp = last_pair ? 0 : jp + 1;
-                    constexpr int nj0 = 2 * njp, nnt = (nj0 + 1 < J) ? 2 : 1;
-                    constexpr bool have_next = !(last_pair && last_row);
-                    constexpr int NRD = have_next ? (6 * nnt + (last_pair ? 6 : 0)) : 0;
-                    // (front-loaded: the last read is issued >= 4 MFMAs before the pair that consumes it starts)
-                    constexpr int RDEN = nm > 5 ? nm - 4 : 2, RPH = (NRD + RDEN - 1) / RDEN;   // reads per MFMA
+                    // reads spread over this pair's MFMAs.  Row 0 fills the cache pair by pair (the fragments of pair jp + 1, front-loaded: the
+                    // last read is issued >= 4 MFMAs before its pair starts; the gradient fragment of row 1 behind pair 3); a row r >= 1
+                    // brings in halo row r + 2 and the gradient fragment of row r + 1, one read per MFMA of its pairs 0 and 1 (first
+                    // needed by pair 3)
+                    constexpr int nj0 = 2 * (jp + 1), nnt = (nj0 + 1 < J) ? 2 : 1;
+                    constexpr int NRD = (r == 0 && jp + 1 < NP) ? (6 * nnt + ((jp + 2 == NP && ROWS > 1) ? 6 : 0)) : 0;
+                    constexpr int RDEN = nm > 5 ? nm - 4 : 2, RPH = (NRD + RDEN - 1) / RDEN;   // reads per MFMA (row 0)
                     // operands of this pair
                     wg_bf16x8 fa[3], fbv[2][3];
 #pragma unroll
                     for (int sp = 0; sp < 3; ++sp) {
                         fa[sp] = pack(ra[r & 1][sp][0], ra[r & 1][sp][1]);
 #pragma unroll
-                        for (int q = 0; q < nt; ++q) fbv[q][sp] = pack(rb[jp & 1][q][sp][0], rb[jp & 1][q][sp][1]);
+                        for (int q = 0; q < nt; ++q) fbv[q][sp] = pack(rbx[(r + (j0 + q) / 3) % 3][(j0 + q) % 3][sp][0], rbx[(r + (j0 + q) / 3) % 3][(j0 + q) % 3][sp][1]);
                     }
                     if constexpr (jp == 0) {
                         if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
@@ -506,21 +508,23 @@ wgrad_tile_kernel(const WgK ga) {
                         constexpr int i = decltype(ic)::value, pq = nt == 2 ? i / 2 : i, q = nt == 2 ? i % 2 : 0;
                         constexpr int g = gbase + i;
                         acc[j0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[pq]], fbv[q][TB[pq]], acc[j0 + q], 0, 0, 0);
-                        // fragment reads of the next pair
-#ifdef WG_ABL_NOREADS
-                        if constexpr (r == 0 && jp == 0)
-#endif
-                        wg_static_for<0, RPH>([&](auto kc) __attribute__((always_inline)) {
-                            constexpr int id = i * RPH + decltype(kc)::value;
-                            if constexpr (id < NRD) {
-                                if constexpr (id < 6 * nnt) {
-                                    read_b(std::integral_constant<int, (have_next ? nr : 0)>{}, std::integral_constant<int, nj0 + id / 6>{},
-                                           std::integral_constant<int, id % 6>{});
-                                } else {
-                                    read_a(std::integral_constant<int, (have_next ? nr : 0)>{}, std::integral_constant<int, id - 6 * nnt>{});
+                        if constexpr (r == 0) {
+                            wg_static_for<0, RPH>([&](auto kc) __attribute__((always_inline)) {
+                                constexpr int id = i * RPH + decltype(kc)::value;
+                                if constexpr (id < NRD) {
+                                    if constexpr (id < 6 * nnt) {
+                                        constexpr int jn = nj0 + id / 6;
+                                        read_x(std::integral_constant<int, jn / 3>{}, std::integral_constant<int, jn % 3>{}, std::integral_constant<int, id % 6>{});
+                                    } else {
+                                        read_a(std::integral_constant<int, 1>{}, std::integral_constant<int, id - 6 * nnt>{});
+                                    }
                                 }
-                            }
-                        });
+                            });
+                        } else {
+                            constexpr int m = jp * 12 + i;             // MFMA index inside the row
+                            if constexpr (m < 18) read_x(std::integral_constant<int, r + 2>{}, std::integral_constant<int, (m < 18 ? m / 6 : 0)>{}, std::integral_constant<int, m % 6>{});
+                            else if constexpr (m < 24 && r + 1 < ROWS) read_a(std::integral_constant<int, (r + 1 < ROWS ? r + 1 : r)>{}, std::integral_constant<int, (m >= 18 && m < 24 ? m - 18 : 0)>{});
+                        }
                         // the next pixel tile: loads behind every second MFMA from the start, item steps in the tail of the phase
 #ifndef WG_ABL_NOITEMS       /* (ablation builds: timing only, results invalid) */
                         if constexpr ((g & 1) == 0 && g / 2 < N_IT) {
