@@ -280,6 +280,28 @@ def test_conv_chain_equals_per_layer_launches(shape):
     close(ref_buf[..., nf:nf + gc].permute(0, 3, 1, 2), y1, what="chain stage 0")
 
 
+@pytest.mark.parametrize("grad_shape", [False, True])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (1, 10, 20), (2, 24, 24), (5, 64, 96), (9, 128, 128)])
+def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode):
+    """tnr_conv_sweep (TNR_MMA_BF16X3: a dense block, or its gradient mirror with LeakyReLU' masks, in one launch; conv_sweep.hip) against five
+    per-layer launches, bit for bit: a single tile, ragged tiles in both directions, several images per round of the grid, and
+    (9,128,128) = 576 tiles dispensed to 256 workgroups (more than two rounds, the last one partial).  Forward-shaped: bias + LeakyReLU
+    stages, residual + skip epilogue; gradient-shaped: mask epilogues, no biases, beta1 residual.  Repeated launches reuse the progress
+    counters and the tile dispenser."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the sweep kernel is the dense block of the bf16x3 arithmetic")
+    from tools.probes.sweep_check import block
+    run = block(*shape, seed=31, grad_shape=grad_shape, with_r2=(shape[0] % 2 == 1))
+    rb, ro, _ = run("layers")
+    for rep in range(3):
+        gb, go, _ = run("sweep")
+        assert torch.equal(gb, rb), "dense buffer differs (rep %d)" % rep
+        assert torch.equal(go, ro), "block output differs (rep %d)" % rep
+    assert ops.chain_error_flag() == 0
+
+
 @pytest.mark.parametrize("case", [("3x3", 2, 8, 8, 256, 96), ("3x3", 16, 4, 4, 512, 512), ("s2", 2, 16, 16, 128, 64),
                                   ("s2", 4, 8, 8, 512, 160), ("dgrad3", 2, 8, 8, 96, 256)])
 def test_conv_small_im2col_splitk(case):
