@@ -170,8 +170,16 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // instead of once per tap and M-tile; the weight slab stays fp32 (split at the fragment read: one fragment per tap and N-tile).
     constexpr bool X3R = (BF == 2) && (TNR_X3_REFILL != 0);
     constexpr int ROWA = X3R ? TNR_X3_ROW : PST;
+    // X3W: the four-tap modes (4x4 stride 2 as 2x2 taps over the parity planes, and its data-gradient) have room for the weight slab in
+    // the split layout as well (4 x 64 rows x 96 B = 24.6 KB beside a 28.5 / 32.6 KB input tile: still two workgroups per CU) -- the
+    // stager splits a weight element once per chunk and the MFMA phase carries no vector arithmetic at all, as in conv_x3w8.h
+#ifndef TNR_X3_WSPLIT
+#define TNR_X3_WSPLIT 1
+#endif
+    constexpr bool X3W = X3R && (S2D || DG2) && (TNR_X3_WSPLIT != 0);
+    constexpr int ROWW = X3W ? TNR_X3_ROW : PST;
     float *s_in = smem;                  // HT*WT*ROWA
-    float *s_w = smem + HT * WT * ROWA;  // NTAPS*NC*PST
+    float *s_w = smem + HT * WT * ROWA;  // NTAPS*NC*ROWW
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, half = lane >> 5;
@@ -345,6 +353,17 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
         for (int it = 0; it < W_IT; ++it) {
             const int i = tid + it * 256;
+            if constexpr (X3W) {
+                if (i < W_ITEMS) {
+                    const int row = tnr_stage_row(i), q = i & 3;
+                    tnr_f32x2 pc[3];
+                    tnr_split4_bf16x3(rw[it], pc);
+                    float *dst = s_w + row * ROWW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
+                    *reinterpret_cast<tnr_f32x2 *>(dst) = pc[0];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 8) = pc[1];
+                    *reinterpret_cast<tnr_f32x2 *>(dst + 16) = pc[2];
+                }
+            } else
             if (i < W_ITEMS) *reinterpret_cast<f32x4 *>(s_w + tnr_stage_row(i) * PST + (i & 3) * 4) = rw[it];
         }
     };
@@ -423,7 +442,8 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
             // for tap t+1 are loaded right after the MFMAs of group g for tap t were issued, with the other group's MFMAs
             // (>= 384 matrix-core cycles) covering the LDS latency -- one register set, no raw A registers.
             constexpr int NG = (MT >= 2) ? 2 : 1, G0 = MT / NG;
-            tnr_bf16x8 ca[MT][3], cb_[NT][3];
+            constexpr int NBSET = X3W ? 2 : 1;
+            tnr_bf16x8 ca[MT][3], cb_[NBSET][NT][3];
             f32x4 rb[NT][2];
             auto tap_pos = [&](int t, int &pix, int &woff) {
                 int pos_y, pos_x;
@@ -459,15 +479,23 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 tap_pos(t, pix, woff);
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) {
-                    rb[nn][0] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
-                    rb[nn][1] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + 4);
+                    if constexpr (X3W) {      // row t * NC + nn * 32 + li of the split slab: the swizzle bit is that of li (NC, 32 are multiples of 16)
+                        const float *src = s_w + (t * NC + nn * 32 + li) * ROWW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) cb_[t & 1][nn][sp] = *reinterpret_cast<const tnr_bf16x8 *>(src + 8 * sp);
+                    } else {
+                        rb[nn][0] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST);
+                        rb[nn][1] = *reinterpret_cast<const f32x4 *>(s_w + woff + nn * 32 * PST + 4);
+                    }
                 }
             };
             auto split_b = [&]() {
+                if constexpr (!X3W) {
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) tnr_split_bf16x3(rb[nn][0], rb[nn][1], cb_[nn]);
+                    for (int nn = 0; nn < NT; ++nn) tnr_split_bf16x3(rb[nn][0], rb[nn][1], cb_[0][nn]);
+                }
             };
-            auto mma_group = [&](int m0, int m1) {
+            auto mma_group = [&](int m0, int m1, int bset) {
                 // the six kept partial products, smallest first; the accumulators of the group keep dependent MFMAs apart
                 constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -476,7 +504,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                     for (int mi = m0; mi < m1; ++mi)
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn)
-                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][TA[p]], cb_[nn][TB[p]], acc[mi][nn], 0, 0, 0);
+                            acc[mi][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca[mi][TA[p]], cb_[bset][nn][TB[p]], acc[mi][nn], 0, 0, 0);
             };
             read_b(0);
             load_a(0, 0, MT);
@@ -492,11 +520,11 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                mma_group(0, G0);
+                mma_group(0, G0, X3W ? (t & 1) : 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < NTAPS) load_a(t + 1, 0, G0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (NG == 2) mma_group(G0, MT);
+                if (NG == 2) mma_group(G0, MT, X3W ? (t & 1) : 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < NTAPS) {
                     if (NG == 2) load_a(t + 1, G0, MT);

@@ -84,7 +84,8 @@ int launch_conv_t(const ConvK &k, int tiles, hipStream_t s) {
     constexpr int KH = (MODE == TNR_CONV_4x4_S2) ? 2 : 3;
     constexpr int NTAPS = (MODE == TNR_CONV_4x4_S2 || MODE == TNR_DGRAD_4x4_S2) ? 4 : 9;
     constexpr int ROWA = (BF == 2 && TNR_X3_REFILL != 0) ? TNR_X3_ROW : TNR_PST;      // (conv_body.h: input rows of the split-operand form)
-    constexpr size_t lds_main = (size_t)((TH + KH - 1) * (TW + KH - 1) * ROWA + NTAPS * NT * 32 * TNR_PST) * sizeof(float);
+    constexpr int ROWW = (BF == 2 && TNR_X3_REFILL != 0 && TNR_X3_WSPLIT != 0 && NTAPS == 4) ? TNR_X3_ROW : TNR_PST;       // (conv_body.h: X3W)
+    constexpr size_t lds_main = (size_t)((TH + KH - 1) * (TW + KH - 1) * ROWA + NTAPS * NT * 32 * ROWW) * sizeof(float);
     constexpr size_t lds_epi = (size_t)4 * MT * 32 * NT * 32 * sizeof(float);   // output transpose tiles of the 4 waves
 #ifdef TNR_DEBUG_LDS_PAD   /* experiment knob: force one workgroup per CU */
     constexpr size_t lds = (lds_main > lds_epi ? lds_main : lds_epi) + TNR_DEBUG_LDS_PAD;
