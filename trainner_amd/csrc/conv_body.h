@@ -42,16 +42,12 @@ typedef float tnr_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 tnr_bf16x4 __attribute__((ext_vector_type(4)));
 // the same split for one staging item (4 channels): three 8-byte pieces for the hi / mid / lo planes of an LDS row
 __device__ __forceinline__ void tnr_split4_bf16x3(const f32x4 v, tnr_f32x2 (&out)[3]) {
-    tnr_bf16x4 h, m, l;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16 hh = (__bf16)v[i];
-        const float r1 = v[i] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        h[i] = hh;
-        m[i] = mm;
-        l[i] = (__bf16)(r1 - (float)mm);
-    }
+    // vector form (packed conversions and subtractions over the four channels: ~18 instead of ~45 vector instructions per item;
+    // element for element the same operations: h = bf16(v), m = bf16(v - h), l = bf16((v - h) - m))
+    const tnr_bf16x4 h = __builtin_convertvector(v, tnr_bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    const tnr_bf16x4 m = __builtin_convertvector(r1, tnr_bf16x4);
+    const tnr_bf16x4 l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), tnr_bf16x4);
     out[0] = __builtin_bit_cast(tnr_f32x2, h);
     out[1] = __builtin_bit_cast(tnr_f32x2, m);
     out[2] = __builtin_bit_cast(tnr_f32x2, l);
