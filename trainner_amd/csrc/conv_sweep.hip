@@ -540,7 +540,13 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
         const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
 #endif
         constexpr bool SYNC_UNIT = (u % SU == SU - 1 && sl < 2);
-        constexpr bool DMA_UNIT = (u % SU) <= 1 || SYNC_UNIT;
+#ifndef S4_DMA_UNITS
+#define S4_DMA_UNITS 2      /* units behind a synchronisation that carry DMA pieces (with the synchronisation unit itself) */
+#endif
+#ifndef S4_DMA_EVERY
+#define S4_DMA_EVERY 3      /* one piece behind every n-th MFMA of such a unit */
+#endif
+        constexpr bool DMA_UNIT = (u % SU) < S4_DMA_UNITS || SYNC_UNIT;
         constexpr bool NEXT_TAP = u + 1 < NU && (u + 1) % NJ == 0;
         // input-chunk item i: behind the last units of slots 1 and 2 (NJ = 1: one per unit from unit 3)
         constexpr int ITEM = NJ == 1 ? u - 3 : (u >= 2 * SU - 4 && u <= 2 * SU - 2 ? u - (2 * SU - 4) : (u >= 3 * SU - 3 ? u - (3 * SU - 3) + 3 : -1));
@@ -552,7 +558,7 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
             acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
             if constexpr (u + 1 < NU && i < 3) read_b(std::integral_constant<int, (u + 1 < NU ? u + 1 : u)>{}, i);
             if constexpr (NEXT_TAP && i >= 3 && i < 9) read_a(std::integral_constant<int, (t + 1 < 9 ? t + 1 : 8)>{}, (i - 3) / 3, (i - 3) % 3);
-            if constexpr (DMA_UNIT && i % 3 == 2) dma_step();
+            if constexpr (DMA_UNIT && i % S4_DMA_EVERY == S4_DMA_EVERY - 1) dma_step();
             if constexpr (ITEM >= 0 && ITEM < S4_A_IT && i >= 4 && i < 9) item_step(std::integral_constant<int, (ITEM >= 0 && ITEM < S4_A_IT ? ITEM : 0)>{}, std::integral_constant<int, (i >= 4 && i < 9 ? i - 4 : 0)>{});
             __builtin_amdgcn_sched_barrier(0);
         });
