@@ -378,11 +378,26 @@ wgrad_tile_kernel(const WgK ga) {
         int ld_ty0 = 0, ld_tx0 = 0, ld_gbase = 0, ld_xbase = 0;      // the tile being loaded (wave-uniform)
         bool ld_valid = true;       // false behind the last tile: the loads and stores still run (straight-line code: a branch around them makes
                                     // the compiler wait for ALL pending loads in front of every load), on zeros
-        auto load_setup = [&](int tile) __attribute__((always_inline)) {
+        // (the tiles of a split are consecutive: the coordinates advance by counting -- tile_at's two divisions are ~70 scalar instructions
+        //  at the top of every tile, where nothing hides them)
+        int l_n = 0, l_ty = 0, l_tx = 0;
+        auto load_setup_first = [&](int tile) __attribute__((always_inline)) {
             const TileAt ta = tile_at(tile);
-            ld_ty0 = ta.ty0; ld_tx0 = ta.tx0;
-            ld_gbase = ((ta.n * a.Ho + ta.ty0) * a.Wo + ta.tx0) * a.g_ct;
-            ld_xbase = ((ta.n * a.H + ta.ty0) * a.W + ta.tx0) * a.x_ct;
+            l_n = ta.n; l_ty = ta.ty0 / THG; l_tx = ta.tx0 / TWG;
+        };
+        auto load_setup_next = [&]() __attribute__((always_inline)) {
+            if (++l_tx == a.tiles_x) {
+                l_tx = 0;
+                if (++l_ty == a.tiles_y) {
+                    l_ty = 0;
+                    ++l_n;
+                }
+            }
+        };
+        auto load_setup = [&]() __attribute__((always_inline)) {
+            ld_ty0 = l_ty * THG; ld_tx0 = l_tx * TWG;
+            ld_gbase = ((l_n * a.Ho + ld_ty0) * a.Wo + ld_tx0) * a.g_ct;
+            ld_xbase = ((l_n * a.H + ld_ty0) * a.W + ld_tx0) * a.x_ct;
         };
         auto item_load = [&](auto kc) __attribute__((always_inline)) {       // (an offset past the end reads zeros: borders and padding)
             constexpr int k = decltype(kc)::value;
@@ -445,7 +460,8 @@ wgrad_tile_kernel(const WgK ga) {
 
         if (t_begin < t_end) {
             // ---- prologue: tile t_begin into set 0
-            load_setup(t_begin);
+            load_setup_first(t_begin);
+            load_setup();
             wg_static_for<0, N_IT>([&](auto kc) __attribute__((always_inline)) { item_load(kc); });
             wg_static_for<0, N_IT>([&](auto kc) __attribute__((always_inline)) {
                 wg_static_for<0, 5>([&](auto sc) __attribute__((always_inline)) { item_step(kc, sc, lds); });
@@ -457,11 +473,12 @@ wgrad_tile_kernel(const WgK ga) {
             const char *set = lds + cur * SET_BYTES;
             char *oset = lds + (cur ^ 1) * SET_BYTES;
             ld_valid = tile + 1 < t_end;
-            load_setup(ld_valid ? tile + 1 : tile);
+            if (ld_valid) load_setup_next();
+            load_setup();
             const char *gab = set + ga_off;
-            const char *xbb[J];
+            const char *xbb[3];
 #pragma unroll
-            for (int j = 0; j < J; ++j) xbb[j] = set + xb_off[j];
+            for (int j = 0; j < 3; ++j) xbb[j] = set + xb_off[j];
             // read id -> one transposing read.  A fragment of row r: ids 0 .. 5 = (plane, half); B fragment of tile j, row r likewise
             auto read_a = [&](auto rc, auto idc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
@@ -471,10 +488,25 @@ wgrad_tile_kernel(const WgK ga) {
                 constexpr int xr = decltype(xrc)::value, tx = decltype(txc)::value, id = decltype(idc)::value, sp = id >> 1, hh = id & 1;
                 rbx[xr % 3][tx][sp][hh] = rd(xbb[tx], xr * 5 * XBLK + 256 * sp + hh * XBLK);
             };
-            // the fragments of row 0, pair 0 (and its gradient fragment): nothing to hide them under
-            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_a(std::integral_constant<int, 0>{}, idc); });
-            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, idc); });
-            wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, idc); });
+            // (the fragments of row 0, pair 0 and its gradient fragment were read behind the last MFMAs of the previous tile; see below)
+            if (tile == t_begin) {
+                wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_a(std::integral_constant<int, 0>{}, idc); });
+                wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, idc); });
+                wg_static_for<0, 6>([&](auto idc) __attribute__((always_inline)) { read_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, idc); });
+            }
+            // the same 18 reads for the NEXT tile, out of the other set (complete behind this tile's barrier)
+            const char *gab_n = oset + ga_off;
+            const char *xbb_n[2] = {oset + xb_off[0], oset + xb_off[1]};
+            auto read_next = [&](auto idc) __attribute__((always_inline)) {
+                constexpr int id = decltype(idc)::value;
+                if constexpr (id < 6) {
+                    constexpr int sp = id >> 1, hh = id & 1;
+                    ra[0][sp][hh] = rd(gab_n, 256 * sp + hh * GBLK);
+                } else {
+                    constexpr int tx = (id - 6) / 6, k = (id - 6) % 6, sp = k >> 1, hh = k & 1;
+                    rbx[0][tx][sp][hh] = rd(xbb_n[tx], 256 * sp + hh * XBLK);
+                }
+            };
             __builtin_amdgcn_sched_barrier(0);
             wg_static_for<0, ROWS>([&](auto rc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value;
@@ -497,6 +529,11 @@ wgrad_tile_kernel(const WgK ga) {
 #pragma unroll
                         for (int q = 0; q < nt; ++q) fbv[q][sp] = pack(rbx[(r + (j0 + q) / 3) % 3][(j0 + q) % 3][sp][0], rbx[(r + (j0 + q) / 3) % 3][(j0 + q) % 3][sp][1]);
                     }
+                    // The tile's barrier stands in front of the LAST pair (6 MFMAs; its operands are in registers, every store into the other
+                    // set was issued at least 7 MFMAs ago, and nothing reads this set any more): the first fragments of the next tile
+                    // are read behind those 6 MFMAs instead of in front of an idle matrix core at the top of the next tile.
+                    static_assert(((ROWS - 1) & 1) == 1, "the next tile's gradient fragment goes into register set 0");
+                    if constexpr (r + 1 == ROWS && jp + 1 == NP) __syncthreads();
                     if constexpr (jp == 0) {
                         if (want_bias) {           // hi + mid + lo reconstructs the fp32 value exactly
 #pragma unroll
@@ -508,6 +545,9 @@ wgrad_tile_kernel(const WgK ga) {
                         constexpr int i = decltype(ic)::value, pq = nt == 2 ? i / 2 : i, q = nt == 2 ? i % 2 : 0;
                         constexpr int g = gbase + i;
                         acc[j0 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[pq]], fbv[q][TB[pq]], acc[j0 + q], 0, 0, 0);
+                        if constexpr (r + 1 == ROWS && jp + 1 == NP) {
+                            wg_static_for<0, 3>([&](auto kc) __attribute__((always_inline)) { read_next(std::integral_constant<int, 3 * i + decltype(kc)::value>{}); });
+                        }
                         if constexpr (r == 0) {
                             wg_static_for<0, RPH>([&](auto kc) __attribute__((always_inline)) {
                                 constexpr int id = i * RPH + decltype(kc)::value;
@@ -539,8 +579,8 @@ wgrad_tile_kernel(const WgK ga) {
                     });
                 });
             });
-            __syncthreads();          // the other set is complete, this one is consumed
         }
+        __syncthreads();              // (the pixel-group exchange below reuses the tile sets)
     } else {
     if (PIPE && t_begin < t_end) load_batch(t_begin, 0);
         for (int tile = t_begin; tile < t_end; ++tile) {
