@@ -19,12 +19,17 @@
 // and its 8 neighbours' fresh output: 3x3 halo) is fetched during the last chunk of pass b.  Same hand-off protocol as conv_chain.hip
 // (conv_handoff.h).
 //
-// Geometry: one workgroup of 8 waves per CU; tile 8 x 32 pixels, wave w owns tile row w (one 32-pixel M-tile) x up to six N-tiles
-// (96 accumulator VGPRs); input chunk = 16 channels of the 10 x 34 halo tile as 96-byte rows of three bf16 planes (split once, by the
-// stager, double-buffered: 2 x 32.6 KB); weights stream through a two-slot ring of <= 12 units (unit = one tap x one N-tile x 16
-// channels = 32 rows x 96 B = 3 KB; 2 x 36 KB) in exactly the order the MFMA loop consumes them -- one workgroup barrier per slot.
-// Deadlock freedom: a round of the grid covers WHOLE images (dependencies never cross images) with one tile per workgroup, all
-// co-resident (grid <= CU count), so a waited-for tile always belongs to a running workgroup at an earlier program point.
+// Geometry: tile 8 x 32 pixels, one workgroup per CU, in two forms.  Four-wave form (conv_sweep4_kernel, the default): one wave per
+// SIMD, wave w owns tile rows 2 w, 2 w + 1 (two 32-pixel M-tiles) x up to six N-tiles (192 accumulator registers); see the comment in
+// front of it.  Eight-wave form (conv_sweep_kernel, TNR_SWEEP_WAVES=8): wave w owns tile row w x up to six N-tiles (96 accumulator
+// VGPRs).  Both: input chunk = 16 channels of the 10 x 34 halo tile as 96-byte rows of three bf16 planes (split once, by the stager,
+// double-buffered: 2 x 36.9 KB with a row of its own per staging slot); weights stream through a three-slot ring of 9 units (unit =
+// one tap x one N-tile x 16 channels = 32 rows x 96 B = 3 KB; 3 x 27 KB) in exactly the order the MFMA loop consumes them -- one
+// workgroup barrier per slot.
+// Deadlock freedom: the grid is at most one workgroup per CU and covers WHOLE images per round (dependencies never cross images).
+// Eight-wave form: tiles dealt statically, so every workgroup must be resident (a waited-for tile always belongs to a running workgroup
+// at an earlier program point).  Four-wave form: tiles DISPENSED in order from an atomic counter -- a waited-for tile was taken by a
+// workgroup that is running; progress needs only tiles_x + 2 resident workgroups.  Waits are bounded either way (error word).
 // Arithmetic (split, kept partial products and their order, channel and tap order, epilogue) is that of conv_tile_body<.., BF = 2>:
 // results are bit-identical to five tnr_conv_forward launches in TNR_MMA_BF16X3.
 #include <stddef.h>
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(512, 1) conv_sweep_kernel(const SweepK c) {
 //     epilogue of a completed stage runs at the top of the next chunk, behind that chunk's barrier.
 constexpr int S4_A_IT = (SW_A_ROWS * 4 + 255) / 256;                // staging items (float4) per thread and chunk: 6
 constexpr int S4_PIECES = (SW_SLOT_UNITS * 3 + 3) / 4;              // 1 KB LDS-DMA pieces per wave and slot: <= 7
-static_assert(S4_PIECES <= 7 && S4_A_IT == 6, "sw_wait_vm4 / the side-work plan");
+static_assert(S4_PIECES <= 8 && S4_A_IT == 6, "the DMA / side-work plan: 8 DMA steps behind a synchronisation, 6 items per chunk");
 
 template <int B, class F, int... I>
 __device__ __forceinline__ void sw_static_for_seq(F &f, std::integer_sequence<int, I...>) {
@@ -482,19 +487,6 @@ __device__ __forceinline__ void sw_static_for_seq(F &f, std::integer_sequence<in
 template <int B, int E, class F>
 __device__ __forceinline__ void sw_static_for(F &&f) {
     sw_static_for_seq<B>(f, std::make_integer_sequence<int, (E > B ? E - B : 0)>{});
-}
-
-__device__ __forceinline__ void sw_wait_vm4(int n) {      // n wave-uniform, 0 .. 7
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    }
 }
 
 // One input chunk: N-tiles [J0, J0 + NJ) x 9 taps x 16 channels, three ring slots of 3 NJ units.  sync(s) opens slot s (1, 2).
