@@ -194,7 +194,8 @@ int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32
  * pre-split (three bf16 planes) from `image`, which tnr_conv_sweep_pack builds from the stages' packed fp32 weights (d->wp) and
  * which stays valid until those change.  tnr_conv_sweep_image_bytes returns 0 when the stages are not such a block (or an
  * image's tiles exceed the co-resident workgroups): use tnr_conv_chain then.  ws / epoch as for tnr_conv_chain (same buffer,
- * same counter).  Results are bit-identical to tnr_conv_chain / five tnr_conv_forward calls in TNR_MMA_BF16X3.            */
+ * same counter; the buffer also holds the launch's tile dispenser, which every launch leaves at zero: one launch at a time per ws,
+ * i.e. one ws per stream).  Results are bit-identical to tnr_conv_chain / five tnr_conv_forward calls in TNR_MMA_BF16X3.    */
 int64_t tnr_conv_sweep_image_bytes(const tnr_conv_desc *stages, int32_t n);
 int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, void *stream);
 int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void *image, uint32_t *ws, int64_t ws_bytes, uint32_t epoch,
