@@ -124,11 +124,11 @@ def main():
                 print("   %-40s %10.0f  (%5.1f %%)" % (nm, out[i] / wgs, 100.0 * out[i] / max(out[14], 1)))
         if hasattr(lib, "tnr_debug_sweep_units"):
             lib.tnr_debug_sweep_units(out2, 0)
-            print("four-wave form, chunks with 3 N-tiles: mean cycles per unit (12 MFMAs = 384 cycles of matrix core) by unit class")
-            for i, nm in enumerate(["unit with the slot synchronisation", "first two units of a slot (weight DMA)", "units with an input-chunk item",
-                                    "plain units", "plain units that read the next tap's A fragments"]):
-                if out2[8 + i]:
-                    print("   %-50s %8.0f   (%d units per workgroup and launch)" % (nm, out2[i] / out2[8 + i], out2[8 + i] // wgs))
+            print("four-wave form: mean cycles per unit (12 MFMAs = 384 cycles of matrix core) by unit class")
+        names2 = ["unit with the slot synchronisation", "first two units of a slot (weight DMA)", "units with an input-chunk item", "plain units"]
+        for i in range(8):
+            if out2[8 + i]:
+                print("   %d N-tiles: %-45s %8.0f   (%d units per workgroup and launch)" % (3 if i < 4 else 2, names2[i % 4], out2[i] / out2[8 + i], out2[8 + i] // wgs))
 
 
 if __name__ == "__main__":

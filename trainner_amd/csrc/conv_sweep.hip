@@ -555,10 +555,10 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
             __builtin_amdgcn_sched_barrier(0);
         });
 #ifdef SW_TIMELINE
-        if constexpr (NJ == 3) {
-            // class: 0 unit with the slot sync, 1 first two units of a slot (DMA), 2 units with an input-chunk item, 3 plain, 4 new-tap units among plain
-            constexpr int cls = SYNC_UNIT ? 0 : ((u % SU) <= 1 ? 1 : (ITEM >= 0 && ITEM < S4_A_IT ? 2 : (NEXT_TAP ? 4 : 3)));
-            tick(cls, __builtin_amdgcn_s_memtime() - tu0);
+        if constexpr (NJ == 3 || NJ == 2) {
+            // class: 0 unit with the slot sync, 1 first two units of a slot (DMA), 2 units with an input-chunk item, 3 plain (NJ = 2: classes 4 .. 7)
+            constexpr int cls = SYNC_UNIT ? 0 : ((u % SU) <= 1 ? 1 : (ITEM >= 0 && ITEM < S4_A_IT ? 2 : 3));
+            tick(cls + (NJ == 2 ? 4 : 0), __builtin_amdgcn_s_memtime() - tu0);
         }
 #endif
     });
