@@ -216,12 +216,26 @@ def pmc_traffic(family="conv_tile_3x3", mode=None):
         return None, None
     try:
         with open(files[-1]) as fh:
-            e = json.load(fh)[family]
-            src = "%s (rocprofv3 --pmc passes of this command, recorded; file mtime %s)" % (
-                os.path.relpath(files[-1], ROOT), time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(files[-1]))))
-            return (round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None), src
+            rec = json.load(fh)
+        if not _pmc_record_current(rec):
+            return None, "%s was recorded on other kernel sources (stamp %s, this tree %s): not quoted" % (
+                os.path.relpath(files[-1], ROOT), rec.get("kernel_source_hash"), _source_hash())
+        e = rec[family]
+        src = "%s (rocprofv3 --pmc passes of this command on these kernel sources, stamp %s)" % (os.path.relpath(files[-1], ROOT), rec["kernel_source_hash"])
+        return (round(e["hbm_bytes_per_launch"]) if e.get("dispatches") else None), src
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def _source_hash():
+    from trainner_amd.build import source_hash
+    return source_hash()
+
+
+def _pmc_record_current(rec):
+    """A recorded counter is quoted only if it was measured on THIS tree's kernels (tools/pmc_stamp.py writes the hash of
+    trainner_amd/csrc + include/trainner_hip.h into the record; records without a stamp predate it)."""
+    return rec.get("kernel_source_hash") == _source_hash()
 
 
 def pmc_mfma_busy(family, mode):
@@ -233,8 +247,11 @@ def pmc_mfma_busy(family, mode):
         return None
     try:
         with open(files[-1]) as fh:
-            e = json.load(fh).get(family)
-        return None if e is None else {"value": e["mfma_busy"], "source": os.path.relpath(files[-1], ROOT)}
+            rec = json.load(fh)
+        if not _pmc_record_current(rec):
+            return None
+        e = rec.get(family)
+        return None if e is None else {"value": e["mfma_busy"], "source": os.path.relpath(files[-1], ROOT), "kernel_source_hash": rec["kernel_source_hash"]}
     except (OSError, KeyError, ValueError):
         return None
 

@@ -113,6 +113,16 @@ typedef struct tnr_conv_desc {
      * an unpadded convolution (the ResnetGenerator's residual blocks, ResNet_arch.py:118-146): the stager reads row -1 as row 1
      * and row H as row H - 2, so the reflection-padded tensor is never materialised.                                      */
     int32_t pad_mode;
+    /* ESRGAN+ GaussianNoise (block.py:587-600; ResidualDenseBlock_5C.forward RRDBNet_arch.py:160-163: `noise(x5*0.2 + x)`, on by
+     * default, defaults.py:59): the epilogue value is multiplied by m = 1 + noise_sigma * n, n ~ N(0, 1), one draw per output element
+     * -- `x + n * (sigma * x)` with the gradient through both terms, i.e. d/dx = m.  noise_pos: 0 none; 1 after the r1 step (forward:
+     * v = (act(acc + bias) * alpha + beta1 r1) * m, then the r2 step: the RRDB residual sees the noised tensor); 2 after the r2 step
+     * (backward: the gradient written by this launch enters a noised tensor).  n is never stored: it is a counter-based function of
+     * (noise_key0, noise_key1, (noise_pix0 + output pixel) * Cout / 4 + channel / 4) -- see tnr_gauss_mult, which evaluates the same
+     * function on a plain tensor -- so the backward pass regenerates the forward pass's draw bit for bit from the same key.
+     * noise_pix0: first pixel of this rank's shard in the global batch (data-parallel ranks draw what one process would draw on the
+     * concatenated batch).  Cout % 4 == 0; never combined with split-K; tnr_conv_sweep accepts it on the last stage only.          */
+    float noise_sigma; int32_t noise_pos; uint32_t noise_key0, noise_key1, noise_pix0;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -167,6 +177,11 @@ int tnr_pack_weights(const tnr_pack_item *items_dev, int32_t n, int64_t max_out,
 int tnr_pack_dense_dims(int32_t nf, int32_t gc, int32_t t, int32_t *KoutP, int32_t *KinP, int64_t *n_out);
 int tnr_pack_dense_dgrad(const tnr_dense_pack_item *items_dev, int32_t n, int64_t max_out, void *stream);
 int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
+/* dst[p][c] = (src ? src[p][c] : 1) * (1 + sigma * n(key0, key1, (pix0 + p) * C / 4 + c / 4)) for `pixels` pixels of C channels: the
+ * multiplier field of tnr_conv_desc.noise_* on a plain NHWC tensor (dst may alias src).  Used where the gradient of a noised tensor
+ * is needed next to the plain one (the RRDB skip, RRDBNet_arch.py:96), and by tests to read the engine's draw.  C % 4 == 0.          */
+int tnr_gauss_mult(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, float sigma, uint32_t key0, uint32_t key1, uint32_t pix0,
+                   void *stream);
 int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d);   /* 0 when the launch would not be split */
 /* out[(n*Ho + oy)*Wo + ox][(ky*kw + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside):
  * the patch matrix of a k x k convolution as an NHWC "image" of Ho*Wo*N pixels with kh*kw*C channels, for

@@ -128,7 +128,8 @@ def gates_of_rrdbnet(saved, nf=64, gc=32):
 
 
 def rrdbnet_forward_gated(lr, sd, nb, gates, upscale=4):
-    """sr_oracle.rrdbnet_forward (upconv) in the dtype of lr / sd with every LeakyReLU branch taken from `gates`."""
+    """sr_oracle.rrdbnet_forward (upconv) in the dtype of lr / sd with every LeakyReLU branch taken from `gates`;
+    gates.get("noise"): the ESRGAN+ multiplier fields of the dense blocks (sr_oracle.rdb5c_forward's `m`), in that dtype."""
     import math
     n_up = int(math.log(upscale, 2))
     fea = O._conv(lr, sd, "model.0")
@@ -142,6 +143,8 @@ def rrdbnet_forward_gated(lr, sd, nb, gates, upscale=4):
             for k in range(1, 5):
                 feats.append(_gate(O._conv(torch.cat(feats, 1), sd, "%s.conv%d.0" % (pre, k)), gates["rdb"][i][k - 1], O.LRELU))
             t = O._conv(torch.cat(feats, 1), sd, pre + ".conv5.0") * 0.2 + x0
+            if gates.get("noise") is not None:
+                t = t * gates["noise"][i]
             i += 1
         t = t * 0.2 + x_rrdb
     y = fea + O._conv(t, sd, "model.1.sub.%d" % nb)

@@ -40,6 +40,11 @@ CASES = {
     "esrgan_nb2_crop64_k10": dict(yaml=dict(nb=2, batch=4, crop=64, d_nf=16), steps=10, seed=61),
     # Real-ESRGAN's discriminator: network_D: unet -> UNetDiscriminator, per-pixel logits, 2 steps
     "esrgan_nb1_unet": dict(yaml=dict(nb=1, batch=2, crop=64, d_nf=16, d_type="unet"), steps=2, seed=71),
+    # ESRGAN+ GaussianNoise ON (the reference's default, defaults.py:59): the reference's own module, with its draw taken from the
+    # engine's counter-based field (ref_harness._substitute_gaussian_draw) -- pins where the noise sits and how its gradient flows
+    "esrgan_nb2_crop64_gauss": dict(yaml=dict(nb=2, batch=2, crop=64, d_nf=16, gaussian=True), steps=3, seed=91, noise_seed=4242),
+    # BASELINE.json configs[3]'s networks at full depth: RRDBNet-23 + UNetDiscriminator (discriminators.py:686-779), 128 -> ... crop 128
+    "esrgan_nb23_unet_crop128_b2": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64, d_type="unet"), steps=1, seed=95),
 }
 
 G_SEED, D_SEED, F_SEED = 101, 202, 77
@@ -58,7 +63,7 @@ def probe_state(sd):
 
 def run_case(name, spec):
     yml = R.esrgan_yaml(name="golden_" + name, **spec["yaml"])
-    opt, model = R.build_reference_model(yml, seed=0)
+    opt, model = R.build_reference_model(yml, seed=0, noise_seed=spec.get("noise_seed"))
     detrand.fill_state_dict_(model.netG.state_dict(), G_SEED)
     has_d = bool(getattr(model, "cri_gan", False))
     if has_d:

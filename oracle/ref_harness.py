@@ -44,12 +44,12 @@ def reference_env():
 
 def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, model_G="esrgan",
                 gan=True, feature=True, pixel_weight=1e-2, grad_clip=True, upsample_mode=None,
-                out_root=None, gpu_ids="[]", d_type="discriminator_vgg", amp=False):
+                out_root=None, gpu_ids="[]", d_type="discriminator_vgg", amp=False, gaussian=False):
     """A train_sr.yml-shaped config (codes/options/sr/train_sr.yml:1-195) for CPU."""
     out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
     os.makedirs(out_root, exist_ok=True)
     if model_G == "esrgan":
-        netg = "network_G:\n  type: esrgan\n  gaussian: false\n  nb: %d\n  nf: %d\n" % (nb, nf)
+        netg = "network_G:\n  type: esrgan\n  gaussian: %s\n  nb: %d\n  nf: %d\n" % ("true" if gaussian else "false", nb, nf)
         if upsample_mode:
             netg += "  upsample_mode: %s\n" % upsample_mode
     else:
@@ -86,8 +86,46 @@ def esrgan_yaml(name="oracle_esrgan", batch=2, crop=128, nb=2, nf=64, d_nf=64, m
     return path
 
 
-def build_reference_model(yaml_path, seed=0):
-    """-> (opt, model) built by the reference's own options.parse / create_model."""
+class _EngineDraw:
+    """Stands where GaussianNoise keeps its 0-dim `noise` tensor (block.py:592): `.repeat(*size).normal_()` (:597) -- the reference's
+    draw from torch's global generator -- returns the field the ENGINE draws for this block instead (oracle/gauss_noise.py restates
+    csrc/gauss_noise.h; key = (noise_seed, this block's call count, block index)).  The reference's forward (:594-599: training only,
+    scale = sigma * x, x + n * scale) runs unmodified around it."""
+
+    def __init__(self, seed, block):
+        self.seed, self.block, self.calls, self.size = seed, block, 0, None
+
+    def repeat(self, *size):
+        self.size = size
+        return self
+
+    def normal_(self):
+        from . import gauss_noise
+        N, C, H, W = self.size
+        call, self.calls = self.calls, self.calls + 1
+        return gauss_noise.normals_nchw(N, C, H, W, self.seed, call, self.block)
+
+
+def _substitute_gaussian_draw(noise_seed):
+    """gaussian: true on CPU.  Two substitutions, neither in the module's arithmetic: the constructor's unconditional
+    `.to(torch.device('cuda'))` (block.py:592) and the source of the N(0, 1) draw (_EngineDraw).  Blocks are numbered in
+    construction order = RRDBNet's forward order (RRDBNet_arch.py:27-29,72-79)."""
+    import torch
+    from models.modules.architectures import block as B
+    count = [0]
+
+    def init(self, sigma=0.1, is_relative_detach=False):
+        torch.nn.Module.__init__(self)
+        self.sigma, self.is_relative_detach = sigma, is_relative_detach
+        self.noise = _EngineDraw(noise_seed, count[0])
+        count[0] += 1
+
+    B.GaussianNoise.__init__ = init
+
+
+def build_reference_model(yaml_path, seed=0, noise_seed=None):
+    """-> (opt, model) built by the reference's own options.parse / create_model.  noise_seed: see _substitute_gaussian_draw
+    (required for `gaussian: true`, which the reference cannot construct on CPU)."""
     with reference_env():
         for m in [k for k in sys.modules if k.split(".")[0] in
                   ("models", "options", "utils", "dataops", "data", "cv2", "torchvision")]:
@@ -95,6 +133,8 @@ def build_reference_model(yaml_path, seed=0):
         import options.options as O
         from models import create_model
         from utils import util
+        if noise_seed is not None:
+            _substitute_gaussian_draw(noise_seed)
         with open(os.devnull, "w") as dn, contextlib.redirect_stdout(dn):
             opt = O.parse(yaml_path, is_train=True)
         util.set_random_seed(seed)

@@ -25,36 +25,40 @@ def _conv(x, sd, key, stride=1, pad=1):
     return F.conv2d(x, sd[key + ".weight"], sd[key + ".bias"], stride=stride, padding=pad)
 
 
-def rdb5c_forward(x, sd, pre):
+def rdb5c_forward(x, sd, pre, m=None):
     """ResidualDenseBlock_5C.forward (models/modules/architectures/RRDBNet_arch.py:150-163):
-    four conv3x3+LeakyReLU(0.2) over growing concatenations, a fifth plain conv, x5*0.2 + x."""
+    four conv3x3+LeakyReLU(0.2) over growing concatenations, a fifth plain conv, x5*0.2 + x.
+    m: the ESRGAN+ GaussianNoise of the block (`self.noise(x5.mul(0.2) + x)`, :160-161; block.py:594-599: x + n * (sigma * x) in
+    training mode, gradient through both terms) as the multiplier field m = 1 + sigma * n -- the draw itself is an INPUT here
+    (the reference takes it from torch's global generator, the engine from its counter-based field), None = no noise."""
     feats = [x]
     for i in range(1, 5):
         y = _conv(torch.cat(feats, 1), sd, "%s.conv%d.0" % (pre, i))
         feats.append(F.leaky_relu(y, LRELU))
     x5 = _conv(torch.cat(feats, 1), sd, pre + ".conv5.0")
-    return x5 * 0.2 + x
+    y = x5 * 0.2 + x
+    return y if m is None else y * m
 
 
-def rrdb_forward(x, sd, pre):
-    """RRDB.forward (RRDBNet_arch.py:89-96): three dense blocks then out*0.2 + x."""
+def rrdb_forward(x, sd, pre, ms=None):
+    """RRDB.forward (RRDBNet_arch.py:89-96): three dense blocks then out*0.2 + x.  ms: their three noise multipliers."""
     out = x
     for r in (1, 2, 3):
-        out = rdb5c_forward(out, sd, "%s.RDB%d" % (pre, r))
+        out = rdb5c_forward(out, sd, "%s.RDB%d" % (pre, r), None if ms is None else ms[r - 1])
     return out * 0.2 + x
 
 
-def rrdbnet_forward(lr, sd, nb, upscale=4, upsample_mode="upconv"):
+def rrdbnet_forward(lr, sd, nb, upscale=4, upsample_mode="upconv", noise=None):
     """RRDBNet (RRDBNet_arch.py:23-49) with the flattened `B.sequential` indices
     (block.py:198-211): model.0 fea_conv; model.1 ShortcutBlock(sub.0..nb-1 RRDBs, sub.nb
     LR_conv); then per upscale stage [Upsample, conv, LeakyReLU] (upconv_block, block.py:390-404)
     or [conv, PixelShuffle, LeakyReLU] (pixelshuffle_block, block.py:374-387); HR_conv0+LeakyReLU;
-    HR_conv1."""
+    HR_conv1.  noise: 3 * nb multiplier fields [N, nf, h, w] in block order (rdb5c_forward), None = gaussian_noise off."""
     n_up = int(math.log(upscale, 2))
     fea = _conv(lr, sd, "model.0")
     t = fea
     for b in range(nb):
-        t = rrdb_forward(t, sd, "model.1.sub.%d" % b)
+        t = rrdb_forward(t, sd, "model.1.sub.%d" % b, None if noise is None else noise[3 * b:3 * b + 3])
     t = _conv(t, sd, "model.1.sub.%d" % nb)
     y = fea + t                                             # ShortcutBlock (block.py:184-195)
     idx = 2
@@ -364,10 +368,11 @@ class OracleSRStep:
         self.fake_H = None
         self.last_g_grads = None
         self.last_d_grads = None
+        self.noise = None          # ESRGAN+ multiplier fields of the NEXT netG call (rrdbnet_forward's `noise`), set by the caller
 
     def netG(self, lr_img):
         if self.arch == "rrdb_net":
-            return rrdbnet_forward(lr_img, self.g, self.nb, 4, self.upsample_mode)
+            return rrdbnet_forward(lr_img, self.g, self.nb, 4, self.upsample_mode, noise=self.noise)
         return srresnet_forward(lr_img, self.g, self.nb, 4)
 
     def netD(self, x):

@@ -92,7 +92,7 @@ def _mm(t):
 
 
 def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False):
+         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False, noise=None):
     xin = _mm(_nchw(x))
     w = None if wp.kind == ops.PACK_DENSE_DGRAD else _mm(wp.w.detach())
     if wp.kind == ops.PACK_DENSE_DGRAD:
@@ -108,11 +108,23 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
         out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, padding=1)
     else:
         out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, stride=2, padding=1)
-    _epilogue(out, y, bias, act, slope, alpha, r1, r1_ch, beta1, r2, alpha2, mask, m_lo, m_hi, m_slope)
+    _epilogue(out, y, bias, act, slope, alpha, r1, r1_ch, beta1, r2, alpha2, mask, m_lo, m_hi, m_slope, noise)
+
+
+def _noise_mult(nz, N, H, W, Cc):
+    """[N, C, H, W] multiplier field of an ops.Noise (oracle/gauss_noise.py restates csrc/gauss_noise.h)."""
+    from oracle import gauss_noise
+    m = gauss_noise.multiplier(N * H * W, Cc, nz.sigma, nz.key0, nz.key1, nz.pix0)
+    return torch.from_numpy(m).view(N, H, W, Cc).permute(0, 3, 1, 2)
+
+
+def gauss_mult(dst, src, noise):
+    m = _noise_mult(noise, dst.N, dst.H, dst.W, dst.C)
+    dst.dense().copy_((m if src is None else _nchw(src) * m).permute(0, 2, 3, 1))
 
 
 def _epilogue(out, y, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None, beta1=1.0, r2=None, alpha2=1.0,
-              mask=None, m_lo=0, m_hi=None, m_slope=0.2):
+              mask=None, m_lo=0, m_hi=None, m_slope=0.2, noise=None):
     out = _fit(out, y.C)
     if bias is not None:
         out = out + _fit(bias.detach().view(1, -1, 1, 1), y.C)
@@ -124,8 +136,12 @@ def _epilogue(out, y, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None
     if r1 is not None:
         ch = r1.C if r1_ch is None else r1_ch
         out = torch.cat([out[:, :ch] + beta1 * _nchw(r1)[:, :ch], out[:, ch:]], 1)
+    if noise is not None and noise.pos == 1:
+        out = out * _noise_mult(noise, y.N, y.H, y.W, y.C)
     if r2 is not None:
         out = out * alpha2 + _nchw(r2)[:, :y.C]
+    if noise is not None and noise.pos == 2:
+        out = out * _noise_mult(noise, y.N, y.H, y.W, y.C)
     if mask is not None:
         hi = y.C if m_hi is None else m_hi
         mm = _mask(_nchw(mask)[:, m_lo:hi], m_slope)
@@ -502,7 +518,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
               alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0), reflect=it.get("reflect", False))
 
 
-_NAMES = ["bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["gauss_mult", "bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

@@ -26,6 +26,10 @@ def test_rrdbnet_schedule(mode):
     TN.test_rrdbnet_forward_backward(mode)
 
 
+def test_rrdbnet_gaussian_noise_schedule():
+    TN.test_rrdbnet_gaussian_noise()
+
+
 def test_srresnet_schedule():
     TN.test_srresnet_forward_backward()
 
@@ -53,7 +57,7 @@ def test_vgg_schedule():
 
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb2_crop64_k10",
-                                  "esrgan_nb1_unet"])
+                                  "esrgan_nb1_unet", "esrgan_nb2_crop64_gauss"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 
@@ -114,6 +118,12 @@ def test_freezeD_layers_are_not_trained(tmp_path):
     assert "features.5.weight" in moved and "classifier.2.weight" in moved
 
 
-def test_step_gate_pinned_fp64_trajectory(tmp_path):
+def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
+    """options/sr/train_sr.yml as the reference ships it (gaussian noise, AMP, pretrained G, RRDBNet-23) over the emulated C ABI."""
+    TS.test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian):
     """The gate-pinned float64 arbitration of three consecutive steps (tests/test_gpu_step.py) over the emulated C ABI."""
-    TS.test_step_gate_pinned_fp64_trajectory(tmp_path)
+    TS.test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian)

@@ -302,6 +302,109 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
     assert ops.chain_error_flag() == 0
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# ESRGAN+ GaussianNoise (block.py:587-600): the counter-based multiplier field of csrc/gauss_noise.h
+# ------------------------------------------------------------------------------------------------------------------------
+def _device_field(ops, N, H, W, Cc, nz, src=None):
+    dst = torch.empty((N, H, W, Cc), device=DEV)
+    ops.gauss_mult(ops.View(dst), None if src is None else ops.View(src), nz)
+    torch.cuda.synchronize()
+    return dst
+
+
+def test_gauss_field_is_the_documented_function():
+    """tnr_gauss_mult against oracle/gauss_noise.py (the integer hash bit for bit, Box-Muller in float32 with libm): the device's
+    v_log / v_sqrt / v_sin / v_cos are a few ulp from libm, so |dm| <= 2e-6 at sigma 0.1; the field of a rank's shard (pix0) is the
+    slice of the global field; a channel window of a wider buffer is written in place; src * m is ONE rounding of the product."""
+    ops = _ops()
+    from oracle import gauss_noise
+    N, H, W, Cc = 3, 20, 36, 64
+    key = ops.noise_key(4242, 7, 11)
+    assert (key & 0xFFFFFFFF, key >> 32) == gauss_noise.noise_key(4242, 7, 11)
+    nz = ops.Noise(0.1, key)
+    got = _device_field(ops, N, H, W, Cc, nz).cpu()
+    ref = torch.from_numpy(gauss_noise.multiplier(N * H * W, Cc, 0.1, nz.key0, nz.key1)).view(N, H, W, Cc)
+    assert (got - ref).abs().max().item() <= 2e-6
+    shard = ops.Noise(0.1, key, pix0=2 * H * W)
+    assert torch.equal(_device_field(ops, 1, H, W, Cc, shard).cpu(), got[2:3])
+    wide = torch.full((N, H, W, 192), 7.0, device=DEV)
+    src = rnd(N, H, W, Cc, seed=5).to(DEV)
+    ops.gauss_mult(ops.View(wide, 64, Cc), ops.View(src), nz)
+    assert torch.equal(wide[..., 64:128].cpu(), src.cpu() * got) and float(wide[..., :64].min()) == 7.0 and float(wide[..., 128:].max()) == 7.0
+
+
+def test_gauss_field_statistics():
+    """n = (m - 1) / sigma over 16.8 M elements (one dense block at batch 16, 128 x 128): mean 0, variance 1, kurtosis 3, |n| <= 4.86
+    (16-bit radius); no correlation between two blocks' fields, two training forwards' fields, neighbouring channels (the four
+    lanes of a quad come from two hashes), neighbouring pixels; relative noise: std of x * m - x is 0.1 |x|."""
+    ops = _ops()
+    N, H, W, Cc = 16, 128, 128, 64
+    f = [((_device_field(ops, N, H, W, Cc, ops.Noise(0.1, ops.noise_key(9, call, blk))) - 1.0) / 0.1).double() for call, blk in ((0, 0), (0, 1), (1, 0))]
+    n = f[0]
+    cnt = n.numel()
+    se = 1.0 / math.sqrt(cnt)
+    assert abs(n.mean().item()) < 5 * se and abs(n.var().item() - 1.0) < 5 * math.sqrt(2.0) * se
+    assert abs((n ** 4).mean().item() - 3.0) < 5 * math.sqrt(96.0) * se and n.abs().max().item() <= 4.86
+
+    def corr(a, b):
+        return ((a * b).mean() / (a.std() * b.std())).item()
+
+    assert abs(corr(f[0], f[1])) < 5 * se and abs(corr(f[0], f[2])) < 5 * se
+    q = n.view(-1, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(corr(q[:, i], q[:, j])) < 5 * 2 * se, (i, j)
+    assert abs(corr(n[:, :, :-1], n[:, :, 1:])) < 5 * se and abs(corr(n[:, :-1], n[:, 1:])) < 5 * se and abs(corr(n[..., :-4], n[..., 4:])) < 5 * se
+    x = rnd(N, H, W, Cc, seed=3, lo=0.5, hi=2.0).to(DEV)
+    y = _device_field(ops, N, H, W, Cc, ops.Noise(0.1, ops.noise_key(9, 0, 0)), src=x)
+    rel = ((y - x) / x).double()
+    assert abs(rel.std().item() - 0.1) < 1e-4 and abs(rel.mean().item()) < 1e-4
+
+
+@pytest.mark.parametrize("pos", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 20, 37, 96, 32), (1, 33, 33, 192, 64)])
+def test_conv_epilogue_noise_multiplier(shape, pos):
+    """tnr_conv_desc.noise_*: the per-layer kernels' epilogue multiplies by the field of tnr_gauss_mult -- after the r1 step
+    (pos 1: noise(x5*0.2 + x), then the RRDB residual) or after the r2 step (pos 2) -- bit for bit (same function, one rounding
+    per operation): compared with the same convolution without noise and WITHOUT r2, finished in torch."""
+    ops = _ops()
+    N, H, W, Cin, Cout = shape
+    w = rnd(Cout, Cin, 3, 3, seed=41, lo=-0.05, hi=0.05).to(DEV)
+    wp, _ = pack(ops, w, ops.PACK_FWD)
+    b = rnd(Cout, seed=42).to(DEV)
+    xb = rnd(N, H, W, Cin, seed=43).to(DEV)
+    r1, r2 = rnd(N, H, W, Cout, seed=44).to(DEV), rnd(N, H, W, Cout, seed=45).to(DEV)
+    nz = ops.Noise(0.1, ops.noise_key(1, 2, 3), pos=pos, pix0=1234)
+    z, y = torch.empty((N, H, W, Cout), device=DEV), torch.empty((N, H, W, Cout), device=DEV)
+    ops.conv(ops.View(xb), wp, ops.View(z), bias=b, alpha=0.2, r1=ops.View(r1))
+    ops.conv(ops.View(xb), wp, ops.View(y), bias=b, alpha=0.2, r1=ops.View(r1), r2=ops.View(r2), alpha2=0.2, noise=nz)
+    m = _device_field(ops, N, H, W, Cout, nz)
+    ref = (z * m) * 0.2 + r2 if pos == 1 else (z * 0.2 + r2) * m
+    assert torch.equal(y.cpu(), ref.cpu())
+    y2 = torch.empty_like(y)
+    ops.conv(ops.View(xb), wp, ops.View(y2), bias=b, alpha=0.2, r1=ops.View(r1), noise=nz)       # without r2 both positions coincide
+    assert torch.equal(y2.cpu(), (z * m).cpu())
+
+
+@pytest.mark.parametrize("grad_shape", [False, True])
+@pytest.mark.parametrize("shape", [(1, 10, 20), (5, 64, 96)])
+def test_dense_block_one_launch_forms_with_noise(shape, grad_shape):
+    """The dense block's one-launch forms (tnr_conv_sweep in TNR_MMA_BF16X3, tnr_conv_chain otherwise) with the noise multiplier on
+    the last stage against five per-layer launches, bit for bit; and against the same block without noise times the field."""
+    ops = _ops()
+    from tools.probes.sweep_check import block
+    nz = ops.Noise(0.1, ops.noise_key(5, 0, 17), pix0=77)
+    run = block(*shape, seed=33, grad_shape=grad_shape, with_r2=False, noise=nz)
+    rb, ro, _ = run("layers")
+    for rep in range(2):
+        gb, go, _ = run("sweep")
+        assert torch.equal(gb, rb) and torch.equal(go, ro), rep
+    _, plain, _ = block(*shape, seed=33, grad_shape=grad_shape, with_r2=False)("sweep")
+    N, H, W = shape
+    assert torch.equal(ro.cpu(), (plain * _device_field(ops, N, H, W, 64, nz)).cpu())
+    assert ops.chain_error_flag() == 0
+
+
 @pytest.mark.parametrize("case", [("3x3", 2, 8, 8, 256, 96), ("3x3", 16, 4, 4, 512, 512), ("s2", 2, 16, 16, 128, 64),
                                   ("s2", 4, 8, 8, 512, 160), ("dgrad3", 2, 8, 8, 96, 256)])
 def test_conv_small_im2col_splitk(case):

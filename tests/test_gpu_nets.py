@@ -88,6 +88,85 @@ def test_rrdbnet_forward_backward(mode):
         assert rel_err(p.grad, 2 * osd[k].grad) < 2e-4, k
 
 
+def _engine_noise_fields(N, h, w, seed, call, nblocks, sigma=0.1, nf=64):
+    """The multiplier fields m = 1 + sigma n the engine draws in training forward `call` (tnr_gauss_mult), as NCHW CPU tensors."""
+    from trainner_amd import ops
+    out = []
+    for i in range(nblocks):
+        buf = torch.empty((N, h, w, nf), device=DEV)
+        ops.gauss_mult(ops.View(buf), None, ops.Noise(sigma, ops.noise_key(seed, call, i)))
+        out.append(buf.permute(0, 3, 1, 2).contiguous().cpu())
+    return out
+
+
+def test_rrdbnet_gaussian_noise():
+    """gaussian_noise=True (ESRGAN+, the reference's default: defaults.py:59; ResidualDenseBlock_5C.forward RRDBNet_arch.py:160-163,
+    block.py:587-600): forward and every parameter gradient against the oracle evaluated ON THE ENGINE'S OWN DRAW (the fields are
+    read back with tnr_gauss_mult), i.e. the multiplier sits after `x5*0.2 + x`, before the RRDB residual, and the gradient flows
+    through both terms.  Then: the same (seed, forward count) reproduces the step bit for bit, the next forward draws a different
+    field, eval() and sigma = 0 are bit-identical to a network built with gaussian_noise=False, and a no-grad training-mode
+    forward (buffer ring) draws the same field as the graph-building one."""
+    from trainner_amd.models.modules.architectures.RRDBNet_arch import RRDBNet
+    nb = 2
+    net = RRDBNet(3, 3, 64, nb, gaussian_noise=True)
+    plain = RRDBNet(3, 3, 64, nb, gaussian_noise=False)
+    sd = seeded(net, 5)
+    plain.load_state_dict(sd)
+    net, plain = net.to(DEV), plain.to(DEV)
+    assert net.noise_sigma == 0.1 and plain.noise_sigma == 0.0 and net.training
+    net.noise_seed = 777
+    lr = detrand.uniform((2, 3, 24, 20), 3, 0.0, 1.0)
+    gout = detrand.uniform((2, 3, 96, 80), 4, -1.0, 1.0)
+    taken = []
+    inner = net.engine_forward
+
+    def tapped(x, save):
+        o, saved = inner(x, save)
+        taken.append(saved)
+        return o, saved
+
+    net.engine_forward = tapped
+    out = net(lr.to(DEV))
+    out.backward(gout.to(DEV))
+    net.engine_forward = inner
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    ms = _engine_noise_fields(2, 24, 20, 777, 0, 3 * nb)
+    # fp64 with the engine's own LeakyReLU branches AND the engine's own draw: smooth, so every gradient element is held to round-off
+    gates = gated.gates_of_rrdbnet(taken[0])
+    gates["noise"] = [m.double() for m in ms]
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in sd.items()}
+    ref = gated.rrdbnet_forward_gated(lr.double(), p64, nb, gates)
+    ref.backward(gout.double())
+    assert rel_err(out, ref) < 2e-5
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad, p64[k].grad) < 2e-4, k
+    # and the free-running fp32 oracle on the same draw (forward only: its LeakyReLU inputs within round-off of zero gate either way)
+    assert rel_err(out, O.rrdbnet_forward(lr, sd, nb, 4, "upconv", noise=ms)) < 2e-5
+    # the noise matters at this tolerance: without it the oracle is far away
+    assert rel_err(out, O.rrdbnet_forward(lr, sd, nb, 4, "upconv")) > 1e-3
+    # same seed, same forward count: bit-identical forward and backward
+    net._noise_calls = 0
+    net.flat_params().grad.zero_()            # (every p.grad is a view of the flat gradient buffer)
+    out_b = net(lr.to(DEV))
+    out_b.backward(gout.to(DEV))
+    assert torch.equal(out_b, out)
+    for k, p in net.named_parameters():
+        assert torch.equal(p.grad, grads[k]), k
+    # a no-grad training-mode forward of the same count draws the same field; the next count a different one
+    net._noise_calls = 0
+    with torch.no_grad():
+        assert torch.equal(net(lr.to(DEV)), out)
+        assert net._noise_calls == 1 and not torch.equal(net(lr.to(DEV)), out)
+    # eval() is the identity (block.py:595: `if self.training and self.sigma != 0`), and so is sigma = 0: bit-identical to gaussian_noise=False
+    base = plain(lr.to(DEV))
+    net.eval()
+    with torch.no_grad():
+        assert torch.equal(net(lr.to(DEV)), base)
+    net.train()
+    net.noise_sigma = 0.0
+    assert torch.equal(net(lr.to(DEV)), base)
+
+
 def test_srresnet_forward_backward():
     from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
     net = SRResNet(3, 3, 64, 3)

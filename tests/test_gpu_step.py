@@ -66,7 +66,9 @@ def check_logs(log, ref_log, tol=2e-4, d_tol=None):
                                   "esrgan_nb2_crop64_k10",       # K = 10 consecutive G+D steps
                                   "esrgan_nb23_crop512_b2",      # BASELINE configs[1] resolution, batch 2: BN over > 1 image
                                   "esrgan_nb23_crop512_b4",      # the same at batch 4: BN + relativistic means over 4 images
-                                  "esrgan_nb1_unet"])            # network_D: unet (Real-ESRGAN's U-Net discriminator)
+                                  "esrgan_nb1_unet",             # network_D: unet (Real-ESRGAN's U-Net discriminator)
+                                  "esrgan_nb23_unet_crop128_b2",  # BASELINE configs[3]'s networks at full depth: RRDBNet-23 + UNetDiscriminator
+                                  "esrgan_nb2_crop64_gauss"])    # gaussian: true (ESRGAN+ noise, the reference's default), 3 steps
 def test_step_matches_reference_golden(case, tmp_path):
     fx = FX.load(case)
     T = CASE_TOL.get(case, DEFAULT_TOL)
@@ -76,6 +78,11 @@ def test_step_matches_reference_golden(case, tmp_path):
         assert dict(opt["network_D"]) == fx["network_D"]
     g, d, f = FX.initial_states(fx)
     load_initial(model, g, d, f)
+    if fx["spec"].get("noise_seed") is not None:
+        # the golden ran the reference's GaussianNoise on the engine's own field (oracle/ref_harness._substitute_gaussian_draw):
+        # same seed, same count of training forwards => the same draw
+        assert model.netG.noise_sigma == 0.1 and fx["network_G"]["gaussian_noise"] is True
+        model.netG.noise_seed = fx["spec"]["noise_seed"]
     for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
         model.feed_data({"LR": LR, "HR": HR})
         model.optimize_parameters(s)
@@ -112,8 +119,86 @@ def test_step_matches_reference_golden_bf16x3(case, tmp_path, monkeypatch):
     assert ops.MMA == hip.MMA_BF16X3
 
 
-def test_step_gate_pinned_fp64_trajectory(tmp_path):
-    """Three consecutive G+D steps, each arbitrated by float64 with the engine's own gates (oracle/gated.gated_step64): before every
+VGG19_FEATURE_IDX = [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28, 30, 32, 34]      # conv layers of torchvision's vgg19().features
+
+
+def shipped_recipe(tmp_path, monkeypatch):
+    """The reference's own options/sr/train_sr.yml (tests/golden/train_sr_reference.yml: its text with only the filesystem locations
+    re-rooted, oracle/make_golden_options.py) plus the two files it expects on disk: the pretrained generator
+    `experiments/pretrained_models/RRDB_PSNR_x4.pth` (here a seeded RRDBNet-23 state_dict in the reference's legacy checkpoint format,
+    base_model.py:364-375) and torchvision's cached ImageNet VGG19 (here seeded weights under torchvision's file name in $TORCH_HOME)."""
+    root = str(tmp_path)
+    txt = open(os.path.join(FX.GOLDEN_DIR, "train_sr_reference.yml")).read().replace("@ROOT@", root)
+    yml = os.path.join(root, "train_sr.yml")
+    with open(yml, "w") as fh:
+        fh.write(txt)
+    g = FX.initial_state(FX.load("esrgan_nb23_crop128")["g_keys"], 101)
+    os.makedirs(os.path.join(root, "experiments", "pretrained_models"))
+    torch.save(g, os.path.join(root, "experiments", "pretrained_models", "RRDB_PSNR_x4.pth"), _use_new_zipfile_serialization=False)
+    f = FX.vgg_state(77)
+    convs = [k[len("feature_net."):-len(".weight")] for k in f if k.endswith(".weight")]
+    tv = {}
+    for name, i in zip(convs, VGG19_FEATURE_IDX):
+        tv["features.%d.weight" % i], tv["features.%d.bias" % i] = f["feature_net.%s.weight" % name], f["feature_net.%s.bias" % name]
+    hub = os.path.join(root, "torch_home")
+    os.makedirs(os.path.join(hub, "hub", "checkpoints"))
+    torch.save(tv, os.path.join(hub, "hub", "checkpoints", "vgg19-dcbb9e9d.pth"))
+    monkeypatch.setenv("TORCH_HOME", hub)
+    return yml, g
+
+
+def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
+    """Drop-in boundary: `options.parse` + `create_model` on the reference's shipped ESRGAN recipe, then three
+    G+D steps.  The recipe says network_G: esrgan (=> gaussian_noise True, defaults.py:59), use_amp: true, network_D:
+    discriminator_vgg (size = crop_size 128), batch 8, pretrain_model_G, lr_steps_rel, metrics 'psnr,ssim,lpips' (read at validation
+    only).  The run is repeated from scratch: same manual_seed => the same noise draw => bit-identical logs and generator."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    yml, g = shipped_recipe(tmp_path, monkeypatch)
+
+    def run():
+        opt = options.parse(yml, is_train=True)
+        torch.manual_seed(opt["train"]["manual_seed"])          # train.py:107 (util.set_random_seed)
+        model = create_model(opt, verbose=False)
+        logs = []
+        for s in (1, 2, 3):
+            LR, HR = detrand.synthetic_pair(opt["datasets"]["train"]["batch_size"], opt["datasets"]["train"]["crop_size"], 500 + s)
+            model.feed_data({"LR": LR, "HR": HR})
+            model.optimize_parameters(s)
+            logs.append(model.get_current_log())
+        return opt, model, logs
+
+    opt, model, logs = run()
+    assert opt["network_G"]["type"] == "rrdb_net" and opt["network_G"]["gaussian_noise"] is True and opt["network_G"]["nb"] == 23
+    assert opt["network_D"]["type"] == "discriminator_vgg" and opt["network_D"]["size"] == 128 and opt["use_amp"] is True
+    assert opt["train"]["lr_steps"] == [50000, 100000, 200000, 300000] and opt["datasets"]["train"]["batch_size"] == 8
+    assert model.netG.noise_sigma == 0.1 and model.netG._noise_calls == 3 and model.netG.training
+    netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
+    assert netF.weights_source.endswith("vgg19-dcbb9e9d.pth")
+    for log in logs:
+        assert set(log) >= {"pix-l1", "fea-vgg19-l1", "l_g_gan", "l_d_real", "l_d_fake", "D_real", "D_fake"}
+        assert all(v == v and abs(v) < 1e4 for v in log.values()), log
+    # the pretrained generator was loaded (not the kaiming init) and has been trained for three steps since
+    w0 = g["model.1.sub.0.RDB1.conv1.0.weight"]
+    w = model.netG.state_dict()["model.1.sub.0.RDB1.conv1.0.weight"].detach().cpu()
+    assert 0 < (w - w0).abs().max().item() <= 3.05e-4
+    _, model2, logs2 = run()
+    assert logs2 == logs
+    for k, v in model.netG.state_dict().items():
+        assert torch.equal(v, model2.netG.state_dict()[k]), k
+    # validation forward: eval() => no noise (block.py:595), deterministic
+    LR, HR = detrand.synthetic_pair(1, 128, 7)
+    model.feed_data({"LR": LR, "HR": HR})
+    model.test()
+    a = model.fake_H.clone()
+    model.test()
+    assert torch.equal(a, model.fake_H) and model.netG._noise_calls == 3
+
+
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian):
+    """(gaussian: the ESRGAN+ noise on -- the float64 side is fed the engine's own draw, read back with tnr_gauss_mult.)
+    Three consecutive G+D steps, each arbitrated by float64 with the engine's own gates (oracle/gated.gated_step64): before every
     step the float64 side takes the engine's state (parameters, Adam moments and step counts, BatchNorm running statistics) and
     re-computes the WHOLE step independently -- forward, the three losses, both backward passes, clip, Adam(G), Adam(D), the
     BatchNorm statistics -- with every LeakyReLU / ReLU / max-pool branch pinned to the one the engine took.  The function is then
@@ -121,12 +206,13 @@ def test_step_gate_pinned_fp64_trajectory(tmp_path):
     step 1: logs 2e-5 relative, the generated image 2e-5, moments 1e-4 of their scale, running statistics 1e-5 -- not the 3e-3 /
     0.15 lr trajectory bounds of the K = 10 golden.  A systematic optimiser or BatchNorm error after the first step cannot hide."""
     from oracle import gated
-    kw = dict(nb=2, batch=2, crop=64, d_nf=16)
+    kw = dict(nb=2, batch=2, crop=64, d_nf=16, gaussian=gaussian)
     opt, model = build_engine_model(kw, tmp_path)
     g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
     d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
     f = FX.vgg_state(77)
     load_initial(model, g, d, f)
+    assert model.netG.noise_sigma == (0.1 if gaussian else 0.0)
     netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
     calls = []
 
@@ -175,6 +261,15 @@ def test_step_gate_pinned_fp64_trajectory(tmp_path):
                 by.setdefault((tag, "fake" if ptr == fake_ptr else ("real" if ptr == real_ptr else "in")), saved)
         gates = {"G": gated.gates_of_rrdbnet(by[("G", "in")]), "D_fake": gated.gates_of_discriminator(by[("D", "fake")]),
                  "D_real": gated.gates_of_discriminator(by[("D", "real")]), "F_fake": gated.gates_of_vgg(by[("F", "fake")])}
+        if gaussian:
+            from trainner_amd import ops
+            fields = []
+            for nz in by[("G", "in")]["noise"]:
+                buf = torch.empty((2, 16, 16, 64), device=model.fake_H.device)
+                ops.gauss_mult(ops.View(buf), None, nz)
+                fields.append(buf.permute(0, 3, 1, 2).contiguous().cpu().double())
+            assert len(fields) == 6
+            gates["G"]["noise"] = fields
         ref = gated.gated_step64(LR, HR, gsd, dsd, f, gates, state, nb=2, d_size=64, d_nf=16)
         for k, v in ref["log"].items():
             assert abs(log[k] - v) <= 2e-5 * max(1.0, abs(v)) + 1e-6, (s, k, log[k], v)

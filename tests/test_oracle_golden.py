@@ -13,7 +13,9 @@ from oracle import fixtures as FX
 CASES = ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
          "esrgan_nb2_crop64_k10",        # K = 10 consecutive steps
          "esrgan_nb23_crop512_b2",       # BASELINE configs[1] resolution, batch 2 through Discriminator_VGG(512)
-         "esrgan_nb1_unet"]              # network_D: unet (UNetDiscriminator)
+         "esrgan_nb1_unet",              # network_D: unet (UNetDiscriminator)
+         "esrgan_nb23_unet_crop128_b2",  # RRDBNet-23 + UNetDiscriminator (BASELINE configs[3]'s networks)
+         "esrgan_nb2_crop64_gauss"]      # gaussian: true -- the reference's GaussianNoise on the engine's field
 LOG_RTOL = 2e-5
 STATE_MEAN = 0.01     # mean |dp| in units of lr*steps (the largest possible Adam displacement)
 STATE_WORST = 0.6     # a noise-gradient element may flip sign once: bounded, not tight
@@ -25,6 +27,10 @@ def test_oracle_matches_reference(case):
     fx = FX.load(case)
     orc = FX.oracle_for(fx)
     for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
+        if fx["spec"].get("noise_seed") is not None:       # ESRGAN+ noise: the multiplier fields of this step's forward
+            from oracle import gauss_noise
+            N, _, h, w = LR.shape
+            orc.noise = [1.0 + 0.1 * gauss_noise.normals_nchw(N, 64, h, w, fx["spec"]["noise_seed"], s - 1, i) for i in range(3 * orc.nb)]
         log = orc.step(LR, HR)
         # beyond the second step two fp32 implementations of the SAME math drift apart measurably: Adam's first steps
         # are sign-like, so weight elements whose gradient is rounding noise move +-lr either way (measured drift

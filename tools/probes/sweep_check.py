@@ -15,7 +15,9 @@ dev = torch.device("cuda")
 nf, gc = 64, 32
 
 
-def block(N, H, W, seed, grad_shape, with_r2=True):
+def block(N, H, W, seed, grad_shape, with_r2=True, noise=None):
+    """noise: an ops.Noise for the last stage (ESRGAN+ multiplier: after the r1 step in the forward shape, after the r2 step in the gradient shape)."""
+    nk = dict(noise=noise.at(2 if grad_shape else 1)) if noise is not None else {}
     g = torch.Generator().manual_seed(seed)
     shapes = [(nf + k * gc, gc) for k in range(4)] + [(nf + 4 * gc, nf)]
     p = ops.WeightPacker(dev)
@@ -38,10 +40,10 @@ def block(N, H, W, seed, grad_shape, with_r2=True):
                                fresh_from=(cin - gc if k else None)))
         if grad_shape:
             st.append(dict(x=ops.View(buf), wp=p.get(idx[4]), y=ops.View(out), fresh_from=nf + 3 * gc, r1=ops.View(buf, 0, nf), beta1=0.2,
-                           **(dict(r2=ops.View(skip), alpha2=1.0) if with_r2 else {})))
+                           **(dict(r2=ops.View(skip), alpha2=1.0) if with_r2 else {}), **nk))
         else:
             st.append(dict(x=ops.View(buf), wp=p.get(idx[4]), y=ops.View(out), bias=bs[4], alpha=0.2, r1=ops.View(buf, 0, nf),
-                           fresh_from=nf + 3 * gc, **(dict(r2=ops.View(skip), alpha2=0.2) if with_r2 else {})))
+                           fresh_from=nf + 3 * gc, **(dict(r2=ops.View(skip), alpha2=0.2) if with_r2 else {}), **nk))
         return st
 
     def run(how):
@@ -89,13 +91,14 @@ def main():
     N, H, W = 16, 128, 128
     fl = sum(2.0 * N * H * W * 9 * ci * co for ci, co in [(nf + k * gc, gc) for k in range(4)] + [(nf + 4 * gc, nf)])
     for grad_shape in (False, True):
-        run = block(N, H, W, seed=5, grad_shape=grad_shape)
-        _, _, st = run("layers")
-        for how in (("sweep",) if TIME_ONLY else ("chain", "sweep")):
-            ops.CONV_SWEEP = how == "sweep"
-            us = timeit(lambda: ops.conv_chain(st))
-            print("%-5s %-6s %8.1f us  %6.1f TFLOP/s fp32-equivalent" % ("grad" if grad_shape else "fwd", how, us, fl / us / 1e6), flush=True)
-        ops.CONV_SWEEP = True
+        for nz in (None, ops.Noise(0.1, ops.noise_key(1, 2, 3))):       # the ESRGAN+ multiplier in the last stage's epilogue: its cost
+            run = block(N, H, W, seed=5, grad_shape=grad_shape, noise=nz)
+            _, _, st = run("layers")
+            for how in (("sweep",) if TIME_ONLY else ("chain", "sweep")):
+                ops.CONV_SWEEP = how == "sweep"
+                us = timeit(lambda: ops.conv_chain(st))
+                print("%-5s %-6s %-6s %8.1f us  %6.1f TFLOP/s fp32-equivalent" % ("grad" if grad_shape else "fwd", how, "noise" if nz else "", us, fl / us / 1e6), flush=True)
+            ops.CONV_SWEEP = True
     print("chain error flag:", ops.chain_error_flag())
 
     lib = hip.load()

@@ -32,6 +32,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*, include/trainner_hip.h) -- stamped into the PMC records under profiles/ so that
+    bench.py can tell whether a recorded counter value belongs to THIS tree's kernels."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "include", "trainner_hip.h")]:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB

@@ -2,6 +2,7 @@
 // (conv_tile.hip) and the multi-layer chain kernel (conv_chain.hip).  See conv_tile.hip for the design.
 #pragma once
 #include "common.h"
+#include "gauss_noise.h"
 
 namespace {
 
@@ -103,6 +104,8 @@ struct ConvK {
     size_t split_stride;
     int bf;                  // operands rounded to bf16 in front of the matrix core (tnr_conv_desc.mma)
     int reflect;             // TNR_CONV_3x3: rows / columns -1 and H / W are read as 1 and H - 2 / W - 2 (ReflectionPad2d(1))
+    // ESRGAN+ GaussianNoise multiplier (gauss_noise.h; tnr_conv_desc.noise_*): 0 none, 1 after the r1 step, 2 after the r2 step
+    int noise_pos; float noise_sigma; unsigned noise_k0, noise_k1, noise_pix0;
 };
 
 #ifdef TNR_TIMELINE   /* tools/probes/conv_timeline.hip: per-workgroup s_memtime stamps, 8 per body call */
@@ -770,6 +773,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // residual / mask / partial-store branches) spent ~1000 cycles per float4 unit on control flow -- 17k cycles
     // per tile, as much as one input chunk's MFMA phase.  Uniform switches are hoisted, lane conditions are selects.
     const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.m != nullptr;     // wave-uniform
+    const bool has_noise = a.noise_pos != 0;                                                  // wave-uniform
     const bool all_full = (a.Cout & 3) == 0;                                                  // wave-uniform
     const bool use_r1 = has_r1 && co < a.r1_ch;                                               // per lane
     const bool use_m = has_m && co >= a.m_lo && co < a.m_hi;
@@ -817,7 +821,15 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ns, __builtin_fminf(v[e], 0.f), __builtin_fmaxf(v[e], 0.f)) * a.alpha;
             if (has_r1) v += b1 * q1[set][k];
-            if (has_r2) v = v * a.alpha2 + q2[set][k];
+            if (has_noise) {           // (its own branch: the paths without noise keep their instruction stream)
+                const f32x4 nm = tnr_gauss_mult4(((unsigned)pixi[set][k] + a.noise_pix0) * (unsigned)(a.Cout >> 2) + (unsigned)(co >> 2),
+                                                 a.noise_k0, a.noise_k1, a.noise_sigma);
+                if (a.noise_pos == 1) v *= nm;
+                if (has_r2) v = v * a.alpha2 + q2[set][k];
+                if (a.noise_pos != 1) v *= nm;
+            } else if (has_r2) {
+                v = v * a.alpha2 + q2[set][k];
+            }
             if (has_m) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= (qm[set][k][e] > 0.f ? 1.f : ms);
@@ -881,6 +893,7 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     // Everything below is written branch-light (uniform switches hoisted, lane conditions as selects): a per-element
     // activation switch and per-unit residual / mask / partial-store branches once cost ~1000 cycles per float4 unit.
     const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.m != nullptr;     // wave-uniform
+    const bool has_noise = a.noise_pos != 0;                                                  // wave-uniform
     const bool all_full = (a.Cout & 3) == 0;                                                  // wave-uniform
     const float ns = a.act == TNR_ACT_LRELU ? a.slope : (a.act == TNR_ACT_RELU ? 0.f : 1.f);  // act(v) = max(v,0) + ns*min(v,0)
     int co_n[NT];
@@ -953,7 +966,15 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ns, __builtin_fminf(v[e], 0.f), __builtin_fmaxf(v[e], 0.f)) * a.alpha;
             if (has_r1) v += b1f[nn] * q1[set][nn];
-            if (has_r2) v = v * a.alpha2 + q2[set][nn];
+            if (has_noise) {           // (its own branch: the paths without noise keep their instruction stream)
+                const f32x4 nm = tnr_gauss_mult4(((unsigned)pixi[set] + a.noise_pix0) * (unsigned)(a.Cout >> 2) + (unsigned)(co_n[nn] >> 2),
+                                                 a.noise_k0, a.noise_k1, a.noise_sigma);
+                if (a.noise_pos == 1) v *= nm;
+                if (has_r2) v = v * a.alpha2 + q2[set][nn];
+                if (a.noise_pos != 1) v *= nm;
+            } else if (has_r2) {
+                v = v * a.alpha2 + q2[set][nn];
+            }
             if (has_m) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= (qm[set][nn][e] > 0.f ? 1.f : msf[nn]);

@@ -7,7 +7,7 @@ namespace {
 
 // Epilogue of a tile (the quad-transpose epilogue of conv_body.h as a function: same arithmetic, same order): `acc` holds the MFMA
 // results of wave `wave` (M-tile mi = pixels (wave * MT + mi) * 32 .. + 31 of the TW-wide tile at (ty0, tx0), channel block cb).
-template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1>
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true>
 __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
                                                   const int tx0, const int par, const int wave, const int li, const int half,
                                                   const __amdgpu_buffer_rsrc_t y_rs) {
@@ -50,6 +50,7 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
     // Everything below is written branch-light (uniform switches hoisted, lane conditions as selects): a per-element
     // activation switch and per-unit residual / mask / partial-store branches once cost ~1000 cycles per float4 unit.
     const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.m != nullptr;     // wave-uniform
+    const bool has_noise = NOISE && a.noise_pos != 0;     // wave-uniform (NOISE = false: an instance for stages that never carry the ESRGAN+ noise)
     const bool all_full = (a.Cout & 3) == 0;                                                  // wave-uniform
     const float ns = a.act == TNR_ACT_LRELU ? a.slope : (a.act == TNR_ACT_RELU ? 0.f : 1.f);  // act(v) = max(v,0) + ns*min(v,0)
     int co_n[NT];
@@ -125,7 +126,15 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ns, __builtin_fminf(v[e], 0.f), __builtin_fmaxf(v[e], 0.f)) * a.alpha;
             if (has_r1) v += b1f[nn] * q1[set][nn];
-            if (has_r2) v = v * a.alpha2 + q2[set][nn];
+            if (has_noise) {           // (its own branch: the paths without noise keep their instruction stream)
+                const f32x4 nm = tnr_gauss_mult4(((unsigned)pixi[set] + a.noise_pix0) * (unsigned)(a.Cout >> 2) + (unsigned)(co_n[nn] >> 2),
+                                                 a.noise_k0, a.noise_k1, a.noise_sigma);
+                if (a.noise_pos == 1) v *= nm;
+                if (has_r2) v = v * a.alpha2 + q2[set][nn];
+                if (a.noise_pos != 1) v *= nm;
+            } else if (has_r2) {
+                v = v * a.alpha2 + q2[set][nn];
+            }
             if (has_m) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= (qm[set][nn][e] > 0.f ? 1.f : msf[nn]);

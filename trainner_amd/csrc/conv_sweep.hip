@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(512, 1) conv_sweep_kernel(const SweepK c) {
                     case 2: t[0][0] = acc[2]; break;
                     default: t[0][0] = acc[3]; break;
                     }
-                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 1, true>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
+                    conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 1, true, 1, false>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
                 } else {
                     f32x16 t[1][2];
                     t[0][0] = acc[4];
@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                 f32x16 t[2][1];
                 t[0][0] = acc[0][S];
                 t[1][0] = acc[1][S];
-                conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 2, true, 8>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
+                conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 1, 2, true, 8, false>(a, t, 0, n, ty0, tx0, 0, wave, li, half, y_rs);
             } else {
                 f32x16 t[2][2];
 #pragma unroll
@@ -849,6 +849,7 @@ bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
         if (d.r1.ptr && ((d.r1.ctot % 4) || (d.r1.coff % 4) || (d.r1_ch % 4))) return no("r1 view");
         if (d.r2.ptr && ((d.r2.ctot % 4) || (d.r2.coff % 4))) return no("r2 view");
         if (d.m.ptr && ((d.m.ctot % 4) || (d.m.coff % 4) || (d.m_lo % 4) || (d.m_hi % 4))) return no("mask view");
+        if (d.noise_pos < 0 || d.noise_pos > 2 || (i < 4 && d.noise_pos != 0)) return no("the noise multiplier belongs to the last stage");
         if ((int64_t)d.N * d.H * d.W * d.x.ctot >= (1LL << 30) || (int64_t)d.N * d.H * d.W * d.y.ctot >= (1LL << 30)) return no("buffer above 4 GiB");
         if (!d.x.ptr || !d.y.ptr || !d.wp) return no("null pointer");
     }
@@ -952,6 +953,7 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
         k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
         k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
         k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+        k.noise_pos = d->noise_pos; k.noise_sigma = d->noise_sigma; k.noise_k0 = d->noise_key0; k.noise_k1 = d->noise_key1; k.noise_pix0 = d->noise_pix0;
         k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = d->KoutP / 32;
         k.th_space = d->Ho; k.tw_space = d->Wo;
         k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = 0;

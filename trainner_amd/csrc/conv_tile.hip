@@ -139,7 +139,7 @@ int conv_pick_tw(int sw, int sh) {
 // launch, and only launches that leave most of the 512 workgroup slots empty while looping over >= 32 input
 // chunks are worth a second launch: the 512-channel discriminator layers at 16x16 and below.
 int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
-    if (d->r1.ptr || d->r2.ptr || d->m.ptr || (d->Cout % 4) != 0 || d->mode == TNR_DGRAD_4x4_S2) return 1;
+    if (d->r1.ptr || d->r2.ptr || d->m.ptr || d->noise_pos || (d->Cout % 4) != 0 || d->mode == TNR_DGRAD_4x4_S2) return 1;
     const int nchunks = (d->KinP / TNR_CK) * (d->mode == TNR_CONV_4x4_S2 ? 4 : 1);
     if (tiles >= 192 || nchunks < 32) return 1;
     int want = (int)((512 + tiles - 1) / tiles);
@@ -168,8 +168,9 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d->r2.ptr == nullptr || ((d->r2.ctot % 4) == 0 && (d->r2.coff % 4) == 0), "conv: r2 view must be 4-channel aligned");
     TNR_REQUIRE(d->m.ptr == nullptr || ((d->m.ctot % 4) == 0 && (d->m.coff % 4) == 0 && (d->m_lo % 4) == 0 && (d->m_hi % 4) == 0),
                 "conv: mask view / range must be 4-channel aligned");
-    TNR_REQUIRE(d->Cout % 4 == 0 || (d->r1.ptr == nullptr && d->r2.ptr == nullptr && d->m.ptr == nullptr),
-                "conv: residual / mask epilogues need Cout %% 4 == 0");
+    TNR_REQUIRE(d->Cout % 4 == 0 || (d->r1.ptr == nullptr && d->r2.ptr == nullptr && d->m.ptr == nullptr && d->noise_pos == 0),
+                "conv: residual / mask / noise epilogues need Cout %% 4 == 0");
+    TNR_REQUIRE(d->noise_pos >= 0 && d->noise_pos <= 2, "conv: bad noise_pos %d", d->noise_pos);
     ConvK k;
     k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
     k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
@@ -179,6 +180,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
     k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
     k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+    k.noise_pos = d->noise_pos; k.noise_sigma = d->noise_sigma; k.noise_k0 = d->noise_key0; k.noise_k1 = d->noise_key1; k.noise_pix0 = d->noise_pix0;
 
     int sh, sw;  // tile space
     switch (d->mode) {

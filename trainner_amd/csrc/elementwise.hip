@@ -2,6 +2,7 @@
 // backward, PixelShuffle (depth_to_space, PyTorch order) forward/backward, 2x2 max-pool,
 // masked scaling and fills.  All kernels are grid-stride over float4 (16 B/lane) where the layout allows.
 #include "common.h"
+#include "gauss_noise.h"
 
 namespace {
 
@@ -228,6 +229,21 @@ __global__ void axpby_kernel(float *dst, int d_ct, int d_co, const float *src, i
     }
 }
 
+// dst = (src or 1) * ESRGAN+ noise multiplier (gauss_noise.h): same counter as the convolution epilogues
+__global__ void gauss_mult_kernel(float *dst, int d_ct, int d_co, const float *src, int s_ct, int s_co, int64_t pixels, int C, float sigma,
+                                  unsigned k0, unsigned k1, unsigned pix0) {
+    const int c4n = C / 4;
+    const int64_t total = pixels * c4n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const int64_t pix = e / c4n;
+        f32x4 v = {1.f, 1.f, 1.f, 1.f};
+        if (src != nullptr) v = *reinterpret_cast<const f32x4 *>(src + pix * s_ct + s_co + c4 * 4);
+        v *= tnr_gauss_mult4(((unsigned)pix + pix0) * (unsigned)c4n + (unsigned)c4, k0, k1, sigma);
+        *reinterpret_cast<f32x4 *>(dst + pix * d_ct + d_co + c4 * 4) = v;
+    }
+}
+
 __global__ void mask_mul_kernel(float *g, int g_ct, int g_co, const float *y, int y_ct, int y_co, int64_t pixels, int C,
                                 float mslope) {
     const int c4n = C / 4;
@@ -449,6 +465,15 @@ extern "C" int tnr_axpby(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, 
     hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(pixels * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)stream, dst.ptr, dst.ctot,
                        dst.coff, src.ptr, src.ctot, src.coff, pixels, C, a, b);
     return tnr_check_launch("axpby");
+}
+
+extern "C" int tnr_gauss_mult(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, float sigma, uint32_t key0, uint32_t key1,
+                              uint32_t pix0, void *stream) {
+    TNR_REQUIRE(view_ok(dst) && (src.ptr == nullptr || view_ok(src)) && (C % 4) == 0 && pixels >= 0, "gauss_mult: bad arguments");
+    if (pixels == 0) return TNR_OK;
+    hipLaunchKernelGGL(gauss_mult_kernel, dim3(ew_grid(pixels * (C / 4))), dim3(EW_BLOCK), 0, (hipStream_t)stream, dst.ptr, dst.ctot,
+                       dst.coff, src.ptr, src.ctot, src.coff, pixels, C, sigma, key0, key1, pix0);
+    return tnr_check_launch("gauss_mult");
 }
 
 extern "C" int tnr_mask_mul(tnr_view g, tnr_view y, int64_t pixels, int32_t C, float mslope, void *stream) {

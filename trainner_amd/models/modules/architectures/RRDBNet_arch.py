@@ -54,9 +54,6 @@ class RRDBNet(HipNet):
         super().__init__()
         if nr != 3 or norm_type is not None or mode != "CNA" or convtype != "Conv2D" or finalact or plus:
             raise NotImplementedError("RRDBNet option outside the ESRGAN recipe is not implemented by the HIP engine")
-        if gaussian_noise:
-            raise NotImplementedError("gaussian_noise (ESRGAN+) is stochastic and off the measured path; "
-                                      "set network_G.gaussian: false")
         if upscale not in (2, 4, 8) or upsample_mode not in ("upconv", "pixelshuffle"):
             raise NotImplementedError("upscale %s / upsample mode [%s] is not found" % (upscale, upsample_mode))
         if nf % 32 or in_nc > 4 or out_nc > 4:
@@ -64,6 +61,13 @@ class RRDBNet(HipNet):
         self.in_nc, self.out_nc, self.nf, self.nb, self.gc = in_nc, out_nc, nf, nb, 32  # reference ignores gc (:24)
         self.upsample_mode, self.n_up = upsample_mode, int(math.log(upscale, 2))
         self.act, self.slope = B.act_code(act_type)
+        # ESRGAN+ GaussianNoise at the end of every dense block (ResidualDenseBlock_5C.forward :160-163, block.py:587-600: sigma 0.1,
+        # training mode only, gradient through both terms; on by default, options/defaults.py:59).  The draw is a counter-based
+        # function of (noise_seed, training-forward count, block, element) evaluated inside the convolution epilogues
+        # (csrc/gauss_noise.h): nothing is stored, backward regenerates it.  noise_seed None: torch.initial_seed() at the forward
+        # (what util.set_random_seed pins); noise_sample0: index of this rank's first sample in the global batch.
+        self.noise_sigma = 0.1 if gaussian_noise else 0.0
+        self.noise_seed, self.noise_sample0, self._noise_calls = None, 0, 0
 
         fea_conv = B.conv_block(in_nc, nf, 3, act_type=None)
         trunk = [RRDB(nf, 32, act_type) for _ in range(nb)] + [B.conv_block(nf, nf, 3, act_type=None)]
@@ -113,6 +117,7 @@ class RRDBNet(HipNet):
         lr = new_act(N, h, w, 4, dev)
         ops.nchw_to_nhwc(x, View(lr), Cpad=4)
         nrdb = 3 * self.nb
+        nz = self._draw_noise(nrdb, h * w)         # per dense block: ops.Noise, or None (eval mode / sigma 0)
         nbuf = nrdb if save else min(nrdb, 4)
         bufs = [new_act(N, h, w, cb, dev) for _ in range(nbuf)]
         trunk = new_act(N, h, w, nf, dev)
@@ -134,11 +139,12 @@ class RRDBNet(HipNet):
                 st.append(convs[k].fwd_stage(View(buf, 0, cin), View(buf, cin, gc), fresh_from=(cin - gc if k else None),
                                              act=act, slope=sl))
             dst = View(bufs[(i + 1) % nbuf], 0, nf) if i + 1 < nrdb else View(trunk)
-            if i % 3 == 2:   # RDB3 also closes the RRDB: (x5*0.2 + x)*0.2 + x_rrdb
+            nk = dict(noise=nz[i]) if nz else {}     # noise(x5*0.2 + x): the multiplier sits between the r1 and the r2 step
+            if i % 3 == 2:   # RDB3 also closes the RRDB: noise(x5*0.2 + x)*0.2 + x_rrdb
                 st.append(convs[4].fwd_stage(View(buf), dst, fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf),
-                                             r2=View(bufs[(i - 2) % nbuf], 0, nf), alpha2=0.2))
+                                             r2=View(bufs[(i - 2) % nbuf], 0, nf), alpha2=0.2, **nk))
             else:
-                st.append(convs[4].fwd_stage(View(buf), dst, fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf)))
+                st.append(convs[4].fwd_stage(View(buf), dst, fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf), **nk))
             ops.conv_chain(st)
         y0 = new_act(N, h, w, nf, dev)
         o["lr"].fwd(View(trunk), View(y0), r1=fea_keep)          # ShortcutBlock: fea + trunk(fea)
@@ -164,15 +170,24 @@ class RRDBNet(HipNet):
         ops.nhwc_to_nchw(View(o4, 0, self.out_nc), out)
         saved = None
         if save:
-            saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w))
+            saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w), noise=nz)
         return out, saved
 
-    def _rdb_backward(self, convs, dense, buf, GP, s, gnext, extra, want_w, pend):
+    def _draw_noise(self, nrdb, hw):
+        if not (self.training and self.noise_sigma != 0.0):
+            return None
+        seed = torch.initial_seed() if self.noise_seed is None else int(self.noise_seed)
+        call, self._noise_calls = self._noise_calls, self._noise_calls + 1
+        pix0 = self.noise_sample0 * hw
+        return [ops.Noise(self.noise_sigma, ops.noise_key(seed, call, i), 1, pix0) for i in range(nrdb)]
+
+    def _rdb_backward(self, convs, dense, buf, GP, s, gnext, extra, want_w, pend, nz_out=None):
         """Backward of one dense block as a 'gradient dense block' (mirror of the forward).
         GP: 192-ch gradient buffer whose [0:nf) holds the incoming gradient g (unscaled; the block's
         residual scale s and conv5's 0.2 are folded into the packed weights).  Fills GP[nf:] with the
         pre-activation gradients [g4 | g3 | g2 | g1] and writes the gradient w.r.t. the block input,
-        + s*g (+ extra, the RRDB skip), into `gnext` (64-ch view)."""
+        + s*g (+ extra, the RRDB skip), into `gnext` (64-ch view).  nz_out: the noise multiplier of the tensor `gnext` is the
+        gradient of (the previous dense block's noised output): what leaves is the gradient of its pre-noise value, m * (...)."""
         nf, gc, sl = self.nf, self.gc, self.slope
         dp = self._dense_packer
         st = []
@@ -183,6 +198,8 @@ class RRDBNet(HipNet):
                            mask=xk, m_lo=0, m_hi=gc, m_slope=sl))
         g = View(GP, 0, nf)
         kw = dict(r2=extra, alpha2=1.0) if extra is not None else {}
+        if nz_out is not None:
+            kw["noise"] = nz_out.at(2)
         st.append(dict(x=View(GP), wp=dp.get(dense[4]), y=gnext, fresh_from=nf + 3 * gc, r1=g, beta1=s, **kw))
         ops.conv_chain(st)                       # one launch for the block's data-gradient (conv_chain.hip)
         if want_w:
@@ -265,20 +282,37 @@ class RRDBNet(HipNet):
         if W:
             o["lr"].wgrad(View(sv["trunk"]), gy0)
             done(o["lr"])
-        o["lr"].dgrad(gy0, View(G[0], 0, nf))
+        # ESRGAN+ noise (sv["noise"]): a dense block's incoming gradient is m * (gradient of its noised output).  Inside an RRDB the
+        # producing launch applies m in its last epilogue (nz_out).  The gradient of an RRDB's output is needed twice -- times RDB3's m
+        # as RDB3's input and plain for the RRDB skip (:96) -- so it is written plain to one of two 64-channel buffers P and the
+        # multiplied copy is one elementwise launch (tnr_gauss_mult) per RRDB.
+        nz = sv.get("noise")
+        P = [View(new_act(N, h, w, nf, dev)) for _ in range(2)] if (nz and nrdb) else None
+        pc = 0
+        o["lr"].dgrad(gy0, P[0] if P else View(G[0], 0, nf))
+        if P:
+            ops.gauss_mult(View(G[0], 0, nf), P[0], nz[nrdb - 1])
         pin = 0                                        # buffer whose [0:nf) holds the incoming gradient
         pend = {}
         for b in range(self.nb - 1, -1, -1):
             q, r, t = (pin + 1) % 4, (pin + 2) % 4, (pin + 3) % 4
             bufs, convs, dense = sv["bufs"], o["rdb"], o["rdb_dense"]
-            self._rdb_backward(convs[3 * b + 2], dense[3 * b + 2], bufs[3 * b + 2], G[pin], 0.2, View(G[q], 0, nf), None, W, pend)
-            self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W, pend)
-            self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, View(G[t], 0, nf), View(G[pin], 0, nf), W, pend)
+            skip = P[pc] if P else View(G[pin], 0, nf)                    # plain gradient of the RRDB's output
+            leave = P[pc ^ 1] if P else View(G[t], 0, nf)                 # plain gradient of the RRDB's input
+            self._rdb_backward(convs[3 * b + 2], dense[3 * b + 2], bufs[3 * b + 2], G[pin], 0.2, View(G[q], 0, nf), None, W, pend,
+                               nz[3 * b + 1] if nz else None)
+            self._rdb_backward(convs[3 * b + 1], dense[3 * b + 1], bufs[3 * b + 1], G[q], 1.0, View(G[r], 0, nf), None, W, pend,
+                               nz[3 * b] if nz else None)
+            self._rdb_backward(convs[3 * b], dense[3 * b], bufs[3 * b], G[r], 1.0, leave, skip, W, pend)
             pin = t
+            if P:
+                pc ^= 1
+                if b > 0:
+                    ops.gauss_mult(View(G[t], 0, nf), leave, nz[3 * b - 1])
             if W:
                 self._flush_wgrads(pend)
                 done(convs[3 * b][0])                  # everything from this RRDB's first conv onwards is final
-        gfea = View(G[pin], 0, nf)
+        gfea = P[pc] if P else View(G[pin], 0, nf)
         ops.axpby(gfea, gy0, 1.0, 1.0)                 # ShortcutBlock: both branches reach fea
         if W:
             o["fea"].wgrad(View(sv["lr"], 0, self.in_nc), gfea)

@@ -44,6 +44,10 @@ def vgg_layer_names(net):
     return names
 
 
+# file names of torchvision's ImageNet checkpoints (torchvision/models/vgg.py model_urls), as cached under <torch hub dir>/checkpoints
+TORCHVISION_FILES = {"vgg11": "vgg11-8a719046.pth", "vgg13": "vgg13-19584684.pth", "vgg16": "vgg16-397923af.pth", "vgg19": "vgg19-dcbb9e9d.pth"}
+
+
 class FeatureExtractor(HipNet):
     def __init__(self, listen_list=None, net="vgg19", use_input_norm=True, z_norm=False, requires_grad=False,
                  remove_pooling=False, pooling_stride=2, change_padding=False, load_path=None, allow_random_init=False):
@@ -92,6 +96,13 @@ class FeatureExtractor(HipNet):
             return "torchvision:%s" % net
         except Exception as e:                                    # no torchvision / no network / no cached weights
             why += "; torchvision pretrained weights unavailable (%s: %s)" % (type(e).__name__, e)
+        # the file torchvision's `pretrained=True` would have cached (torch.hub checkpoints dir, $TORCH_HOME): usable without
+        # torchvision itself -- an offline box that carries the cached weights runs the reference's recipe unmodified
+        cached = os.path.join(torch.hub.get_dir(), "checkpoints", TORCHVISION_FILES.get(net, ""))
+        if os.path.isfile(cached):
+            self.load_torchvision_state(torch.load(cached, map_location="cpu", weights_only=False))
+            return cached
+        why += "; no cached %s" % cached
         if not allow_random_init:
             from ....hip import HipEngineError
             raise HipEngineError("FeatureExtractor(%s): %s. A perceptual loss on randomly initialised features is refused; "

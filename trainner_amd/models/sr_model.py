@@ -65,6 +65,9 @@ class SRModel(BaseModel):
 
     def feed_data(self, data, need_HR=True):
         self.var_L = self._shard(data["LR"]).to(self.device, non_blocking=True)
+        if self.dp.world_size > 1 and hasattr(self.netG, "noise_sample0"):
+            # ESRGAN+ noise: every rank draws the field of ITS samples of the global batch (what one process would draw)
+            self.netG.noise_sample0 = self.dp.rank * self.var_L.shape[0]
         if need_HR:
             self.real_H = self._shard(data["HR"]).to(self.device, non_blocking=True)
             self.var_ref = self._shard(data.get("ref", data["HR"])).to(self.device, non_blocking=True)

@@ -247,7 +247,7 @@ MMA = FP32_MMA
 
 
 def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-               beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False):
+               beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False, noise=None):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.wp, d.KinP, d.KoutP = wp.t.data_ptr(), wp.KinP, wp.KoutP
@@ -267,6 +267,44 @@ def _conv_desc(d, x, wp, y, mode=CONV_3x3, bias=None, act=ACT_NONE, slope=0.2, a
     d.m_slope = m_slope
     d.mma = MMA
     d.pad_mode = 1 if reflect else 0          # TNR_CONV_3x3 only: ReflectionPad2d(1) borders instead of zeros
+    if noise is not None:                      # Noise: the ESRGAN+ multiplier of tnr_conv_desc.noise_* (None: the fields stay zero)
+        d.noise_sigma, d.noise_pos, d.noise_key0, d.noise_key1, d.noise_pix0 = noise.sigma, noise.pos, noise.key0, noise.key1, noise.pix0
+
+
+class Noise:
+    """ESRGAN+ GaussianNoise multiplier of one dense block (block.py:587-600): m = 1 + sigma * n(key, element).  pos: where a
+    convolution epilogue applies it (1 after the r1 step = forward, 2 after the r2 step = backward); pix0: first pixel of this
+    rank's shard in the global batch."""
+    __slots__ = ("sigma", "pos", "key0", "key1", "pix0")
+
+    def __init__(self, sigma, key, pos=1, pix0=0):
+        self.sigma, self.pos, self.pix0 = float(sigma), pos, pix0 & 0xFFFFFFFF
+        self.key0, self.key1 = key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF
+
+    def at(self, pos):
+        n = Noise(self.sigma, 0, pos, self.pix0)
+        n.key0, n.key1 = self.key0, self.key1
+        return n
+
+
+def noise_key(seed, call, block):
+    """64-bit key of (seed, training forward `call`, dense block): splitmix64 over the three words, so that neighbouring calls /
+    blocks share no structure the device-side counter hash (csrc/gauss_noise.h) would have to undo."""
+    M = 0xFFFFFFFFFFFFFFFF
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    return mix(mix(mix(seed & M) ^ (call & M)) ^ (block & M))
+
+
+def gauss_mult(dst, src, noise):
+    """dst = (src or 1) * the noise multiplier field (tnr_gauss_mult); dst / src: views of `dst.C` channels."""
+    hip.check(hip.load().tnr_gauss_mult(dst.c(), cv(src), dst.pixels, dst.C, noise.sigma, noise.key0, noise.key1, noise.pix0,
+                                        hip.stream()), "gauss_mult")
 
 
 IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel for <= 4-channel image layers (A/B switch)
