@@ -103,6 +103,23 @@ def test_device_feeder_double_buffering():
                 assert torch.equal(got[i].cpu(), torch.from_numpy(want)), (k, key, i, f)
         assert paths == b["LR_path"]
     assert feeder.bytes_uploaded == sum(b["LR"].nbytes + b["HR"].nbytes for b in batches)
+    # a consumer that leaves the loop early: the slot it still reads and the pre-uploaded ones get a fresh `free` event,
+    # so the next epoch's uploads queue up behind the work that reads them -- the batch taken in the aborted epoch stays intact
+    # while that work runs, and the new epoch delivers the right data again
+    gen = iter(feeder)
+    d0 = next(gen)
+    lr0 = d0["LR"]
+    for _ in range(6):
+        busy = busy @ busy * 1e-4                                   # long compute-stream work that "reads" lr0 afterwards
+    keep = lr0.clone()                                              # enqueued behind it on the compute stream
+    gen.close()                                                     # GeneratorExit at the yield
+    for k, d in enumerate(feeder):
+        if k == 0:
+            first = d["LR"].clone()
+    torch.cuda.synchronize()
+    want0 = torch.stack([torch.from_numpy(FO.np2tensor(np.ascontiguousarray(FO.flip_rot(batches[0]["LR"][i], int(batches[0]["flags"][i]) & 1,
+                         int(batches[0]["flags"][i]) & 2, int(batches[0]["flags"][i]) & 4)))) for i in range(4)])
+    assert torch.equal(keep.cpu(), want0) and torch.equal(first.cpu(), want0) and k == len(batches) - 1
 
 
 @pytest.mark.gpu

@@ -54,7 +54,9 @@ for s in range(1, steps + 1):
     model.feed_data({{"LR": LR, "HR": HR}})
     model.optimize_parameters(s)
     logs.append(dict(model.get_current_log()))
+from trainner_amd import ops
 torch.save(dict(logs=logs, fake=model.fake_H.detach().cpu(), observed=observed, backend=os.environ.get("TNR_DP_BACKEND", "torch"),
+                counters=dict(ops.COUNTERS), overlap_g=bool(ops.dense_blocks_overlap_collectives()),
                 g={{k: v.detach().cpu() for k, v in model.netG.state_dict().items()}},
                 d={{k: v.detach().cpu() for k, v in model.netD.state_dict().items()}}), os.path.join(out_dir, "rank%d.pt" % rank))
 model.dp.finalize()
@@ -63,8 +65,8 @@ if torch.distributed.is_initialized():
 '''
 
 
-def _launch(tmp_path, world, backend, mma):
-    out = tmp_path / ("w%d_%s" % (world, backend))
+def _launch(tmp_path, world, backend, mma, overlap="auto"):
+    out = tmp_path / ("w%d_%s_%s" % (world, backend, overlap))
     out.mkdir()
     script = out / "worker.py"
     script.write_text(WORKER.format(root=ROOT, kw=json.dumps(KW), steps=STEPS, out=str(out)))
@@ -74,6 +76,9 @@ def _launch(tmp_path, world, backend, mma):
     env["TNR_MMA"] = mma or "bf16x3"                  # the workers compute in the arithmetic this test instance runs in
     if world == 1:
         env["TNR_DP_SELFTEST"] = "1"
+    env["TNR_DP_OVERLAP_G"] = {"auto": "auto", "forced": "1", "off": "0"}[overlap]
+    if overlap == "forced":
+        env["TNR_CHAIN_WITH_COLLECTIVES"] = "1"       # fp32 matrix core: tnr_conv_chain stays one launch next to the collectives
     port = 29500 + (os.getpid() + world * 7 + (13 if backend == "abi" else 0)) % 1000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
@@ -102,16 +107,32 @@ def _single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("overlap", ["auto", "forced", "off"])
 @pytest.mark.parametrize("backend", ["torch", "abi"])
 @pytest.mark.parametrize("world", [1, 2])
-def test_rccl_ranks_equal_single_process(world, backend, tmp_path, mma_mode):
+def test_rccl_ranks_equal_single_process(world, backend, overlap, tmp_path, mma_mode):
+    """overlap: how the GENERATOR's gradient buckets travel.  auto = the default policy (sr_model.backward_G): from inside its backward
+    when the dense blocks stay one launch each next to the collectives (the dispensed sweep of TNR_MMA_BF16X3), at the optimizer step
+    otherwise; forced = TNR_DP_OVERLAP_G=1 TNR_CHAIN_WITH_COLLECTIVES=1 (one-launch dense blocks next to RCCL in either arithmetic);
+    off = at the optimizer step.  The discriminator's buckets always leave from inside its backward."""
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d visible GPUs (this box has %d)" % (world, torch.cuda.device_count()))
+    if overlap != "auto" and backend == "abi":
+        pytest.skip("the overlap policy is independent of the communicator backend: covered with the torch group")
     one = _single_process(tmp_path)
-    res = _launch(tmp_path, world, backend, mma_mode)
+    res = _launch(tmp_path, world, backend, mma_mode, overlap)
     per, lr_steps = KW["batch"] // world, 1e-4 * STEPS
     for r, out in enumerate(res):
         assert out["observed"] == world and out["backend"] == backend          # the communicator's own rank count
+        sweep_mode = (mma_mode or "bf16x3") == "bf16x3"
+        if overlap == "off":
+            assert out["counters"]["one_launch_next_to_collectives"] == 0 and out["counters"]["per_layer_next_to_collectives"] == 0, out["counters"]
+        elif overlap == "forced" or sweep_mode:
+            # G's backward ran with buckets on the wire and its dense blocks (3 forward-shaped gradient blocks per step) stayed one launch
+            assert out["overlap_g"] and out["counters"]["one_launch_next_to_collectives"] >= 2 * STEPS, out["counters"]
+            assert out["counters"]["per_layer_next_to_collectives"] == 0, out["counters"]
+        else:
+            assert not out["overlap_g"] and out["counters"]["one_launch_next_to_collectives"] == 0, out["counters"]
         for s in range(STEPS):
             for k, v in one["logs"][s].items():
                 # every log entry is a global-batch quantity on every rank (G losses are all-reduced means)

@@ -13,7 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from trainner_amd import ops  # noqa: E402
 from tools.probes.sweep_check import block  # noqa: E402
 
-hog = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcu_hog.so"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+if not os.path.exists(os.path.join(HERE, "libcu_hog.so")):       # (probe binaries are not tracked: built where they run)
+    import subprocess
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(HERE, "cu_hog.hip"), "-o",
+                    os.path.join(HERE, "libcu_hog.so")], check=True)
+hog = C.CDLL(os.path.join(HERE, "libcu_hog.so"))
 hog.cu_hog.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int]
 dev = torch.device("cuda")
 out = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -38,5 +43,13 @@ def timed(blocks, reps=20):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-print("TNR_SWEEP_WAVES=%s: %.1f us per launch alone; %.1f us with 1 CU held; %.1f us with 4 CUs held; error flag %d"
-      % (os.environ.get("TNR_SWEEP_WAVES", "4"), timed(0), timed(1), timed(4), ops.chain_error_flag()))
+print("TNR_SWEEP_WAVES=%s TNR_SWEEP_FORM=%s: per launch alone %.1f us; with 1 / 4 / 8 / 16 CUs held (what RCCL's ring kernels do to a launch next to them) "
+      "%.1f / %.1f / %.1f / %.1f us; error flag %d" % (os.environ.get("TNR_SWEEP_WAVES", "4"), os.environ.get("TNR_SWEEP_FORM", "direct"), timed(0), timed(1), timed(4),
+                                                      timed(8), timed(16), ops.chain_error_flag()))
+# and the results do not depend on who else is on the chip: bit-identical with 16 CUs held
+ref_buf, ref_out, _ = run("sweep")
+hog.cu_hog(C.c_void_p(side.cuda_stream), 60.0, C.c_void_p(out.data_ptr()), 16)
+torch.cuda._sleep(2_000_000)
+got_buf, got_out, _ = run("sweep")
+torch.cuda.synchronize()
+print("results with 16 CUs held bit-identical:", bool(torch.equal(ref_buf, got_buf) and torch.equal(ref_out, got_out)), "; error flag", ops.chain_error_flag())

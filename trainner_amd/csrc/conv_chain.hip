@@ -304,7 +304,6 @@ __global__ void __launch_bounds__(512, 1) conv_chain_x3w8_kernel(const ChainK c)
 }
 
 constexpr int CH_TH = 16, CH_TW = 32;
-constexpr int CH_CU_KEYS = 16 * 128;   // (xcc, se, sh, cu) keys of chain_kernel's per-CU arrival counters
 constexpr size_t chain_lds(int bf = 0) {
     // (the split-operand form keeps the input tile as three bf16 planes: 96-byte rows, conv_body.h)
     const size_t lds_main = (size_t)((CH_TH + 2) * (CH_TW + 2) * ((bf == 2 && TNR_X3_REFILL != 0) ? TNR_X3_ROW : TNR_PST) + 9 * 32 * TNR_PST) * sizeof(float);
@@ -358,9 +357,10 @@ int chain_capacity(int *out) {
 extern "C" int64_t tnr_conv_chain_workspace_bytes(const tnr_conv_desc *d) {
     if (d == nullptr) return 0;
     // progress counters (sized for the 8 x 32 tiles of tnr_conv_sweep, which shares the buffer: twice the 16 x 32 tiles of this
-    // kernel), per-CU arrival counters, 2 x 2 tile dispensers, the error word (ALWAYS the last word of the buffer)
+    // kernel), the sweep's tile dispensers (words of their own: conv_handoff.h), per-CU arrival counters, 2 x 2 tile dispensers, the
+    // error word (ALWAYS the last word of the buffer)
     const int64_t tiles = (int64_t)tnr_cdiv(d->Wo, CH_TW) * tnr_cdiv(d->Ho, 8) * d->N;
-    return (tiles + CH_CU_KEYS + 4 + 1) * (int64_t)sizeof(uint32_t);
+    return (tiles + CH_SWEEP_WORDS + CH_CU_KEYS + 4 + 1) * (int64_t)sizeof(uint32_t);
 }
 
 extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32_t n, uint32_t *ws, int64_t ws_bytes,

@@ -8,6 +8,11 @@
 
 namespace {
 
+// Tail of the shared workspace (tnr_conv_chain_workspace_bytes), counted from its end: [sweep dispensers: CH_SWEEP_WORDS]
+// [chain per-CU arrival counters: CH_CU_KEYS] [chain tile dispensers: 4] [error word: 1].
+constexpr int CH_CU_KEYS = 16 * 128;   // (xcc, se, sh, cu) keys of chain_kernel's per-CU arrival counters
+constexpr int CH_SWEEP_WORDS = 16;     // tnr_conv_sweep: 8 tile dispensers + the finished-workgroup count (zero between launches)
+
 struct ChainWait {
     unsigned *progress;
     unsigned need;

@@ -113,6 +113,7 @@ __host__ __device__ inline int sw_total_units(int nck0) {
 // plane at slot h ^ ((r >> TNR_X3_SWZ) & 1) -- byte for byte the LDS image the MFMA loop reads.
 struct SweepPackK {
     int nck0, units;
+    int direct;                        // 1: the register image of the direct form (conv_sweep4_kernel<true>), 0: the LDS image
     const float *wp[SW_NSTAGE];
     int KinP[SW_NSTAGE], KoutP[SW_NSTAGE];
     float *out;
@@ -138,6 +139,14 @@ __global__ void __launch_bounds__(256) sweep_pack_kernel(const SweepPackK a) {
     const f32x4 q0 = *reinterpret_cast<const f32x4 *>(src), q1 = *reinterpret_cast<const f32x4 *>(src + 4);
     tnr_bf16x8 pl[3];
     tnr_split_bf16x3(q0, q1, pl);
+    if (a.direct) {
+        // direct form: plane k of a unit is ONE 1 KB block in the order the lanes hold it -- lane (half = channel octet h, li = row r)
+        // owns 16 bytes -- so a fragment load is a fully coalesced 1 KB read straight into the MFMA operand registers
+        float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + (h * 32 + r) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + k * 256) = pl[k];
+        return;
+    }
     float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + r * SW_ROW + 4 * sp;
 #pragma unroll
     for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + 8 * k) = pl[k];
@@ -498,9 +507,17 @@ __device__ __forceinline__ void sw_static_for(F &&f) {
 //     MFMA 4 .. 8   one step of an input-chunk item (hi plane, mid plane, lo plane + store, store, store: see the kernel)
 // (profiles/r03t_sweep4_timeline.txt: issued in blocks between the units these cost 50 .. 100 cycles per plain unit, 150 per DMA
 // unit and 520 per item against the unit's 384 cycles of matrix core.)
-template <int J0, int NJ, class Sync, class Item, class Dma, class Tick>
+// DIRECT (the default since round 4): the weight fragments do not pass through LDS at all.  The stream is consumed strictly in
+// order, one 3 KB unit per 12 MFMAs, and in the direct layout (sweep_pack_kernel) a plane of a unit is one coalesced 1 KB read in
+// register order: every wave fetches the fragments of unit g + 2 straight from L2 / L1 into a three-deep register ring behind the first
+// three MFMAs of unit g (`b_fetch`; the four waves of a CU ask for the same lines within a few hundred cycles: one L2 read, three L1
+// hits).  No weight ring in LDS, no LDS-DMA pieces (60 cycles of issue each: +230 cycles on 2 units of every slot), no slot
+// synchronisations (two per chunk at ~550 cycles) -- profiles/r03ap_sweep4_units.txt priced those at 14 % of the kernel.
+template <int J0, int NJ, bool DIRECT, class Sync, class Item, class Dma, class Tick, class BFetch>
 __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const float *sa, const float *s_b_lane, const int (&apix0)[2],
-                                             const int half, Sync &&sync, Item &&item_step, Dma &&dma_step, Tick &&tick) {
+                                             const int half, Sync &&sync, Item &&item_step, Dma &&dma_step, Tick &&tick,
+                                             tnr_bf16x8 (&fbr)[3][3], BFetch &&b_fetch) {
+    static_assert((9 * NJ) % 3 == 0, "a chunk starts at ring position 0");
     constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // the six kept partial products, smallest first
     constexpr int NU = 9 * NJ, SU = 3 * NJ;
     tnr_bf16x8 fa[2][2][3], fb[2][3];
@@ -524,21 +541,23 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
     addr_a(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int k = 0; k < 6; ++k) read_a(std::integral_constant<int, 0>{}, k / 3, k % 3);
+    if constexpr (!DIRECT) {
 #pragma unroll
-    for (int sp = 0; sp < 3; ++sp) read_b(std::integral_constant<int, 0>{}, sp);
+        for (int sp = 0; sp < 3; ++sp) read_b(std::integral_constant<int, 0>{}, sp);
+    }
     sw_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value, t = u / NJ, jj = u % NJ, sl = u / SU;
 #ifdef SW_TIMELINE
         const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
 #endif
-        constexpr bool SYNC_UNIT = (u % SU == SU - 1 && sl < 2);
+        constexpr bool SYNC_UNIT = !DIRECT && (u % SU == SU - 1 && sl < 2);
 #ifndef S4_DMA_UNITS
 #define S4_DMA_UNITS 2      /* units behind a synchronisation that carry DMA pieces (with the synchronisation unit itself) */
 #endif
 #ifndef S4_DMA_EVERY
 #define S4_DMA_EVERY 3      /* one piece behind every n-th MFMA of such a unit */
 #endif
-        constexpr bool DMA_UNIT = (u % SU) < S4_DMA_UNITS || SYNC_UNIT;
+        constexpr bool DMA_UNIT = !DIRECT && ((u % SU) < S4_DMA_UNITS || SYNC_UNIT);
         constexpr bool NEXT_TAP = u + 1 < NU && (u + 1) % NJ == 0;
         // input-chunk item i: behind the last units of slots 1 and 2 (NJ = 1: one per unit from unit 3)
         constexpr int ITEM = NJ == 1 ? u - 3 : (u >= 2 * SU - 4 && u <= 2 * SU - 2 ? u - (2 * SU - 4) : (u >= 3 * SU - 3 ? u - (3 * SU - 3) + 3 : -1));
@@ -547,8 +566,13 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
         __builtin_amdgcn_sched_barrier(0);
         sw_static_for<0, 12>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value, p = i / 2, m = i % 2;
-            acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
-            if constexpr (u + 1 < NU && i < 3) read_b(std::integral_constant<int, (u + 1 < NU ? u + 1 : u)>{}, i);
+            if constexpr (DIRECT) {
+                acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fbr[u % 3][TB[p]], acc[m][J0 + jj], 0, 0, 0);
+                if constexpr (i < 3) b_fetch(std::integral_constant<int, (u + 2) % 3>{}, i);       // unit g + 2 into the slot unit g - 1 left
+            } else {
+                acc[m][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fb[u & 1][TB[p]], acc[m][J0 + jj], 0, 0, 0);
+                if constexpr (u + 1 < NU && i < 3) read_b(std::integral_constant<int, (u + 1 < NU ? u + 1 : u)>{}, i);
+            }
             if constexpr (NEXT_TAP && i >= 3 && i < 9) read_a(std::integral_constant<int, (t + 1 < 9 ? t + 1 : 8)>{}, (i - 3) / 3, (i - 3) % 3);
             if constexpr (DMA_UNIT && i % S4_DMA_EVERY == S4_DMA_EVERY - 1) dma_step();
             if constexpr (ITEM >= 0 && ITEM < S4_A_IT && i >= 4 && i < 9) item_step(std::integral_constant<int, (ITEM >= 0 && ITEM < S4_A_IT ? ITEM : 0)>{}, std::integral_constant<int, (i >= 4 && i < 9 ? i - 4 : 0)>{});
@@ -564,6 +588,13 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
     });
 }
 
+#ifndef S4D_EPI_AFTER
+#define S4D_EPI_AFTER 1       /* direct form: a stage's epilogue behind its pass's chunk loop (0: under `ck == 0` at the top of the next pass) */
+#endif
+#ifndef S4D_ALOAD_ALWAYS
+#define S4D_ALOAD_ALWAYS 1    /* direct form: the next chunk's input loads on every path (0: only when there is a next chunk) */
+#endif
+template <bool DIRECT>
 __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_a = smem, *s_b = smem + 2 * SW_A_FLOATS;
@@ -623,10 +654,10 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         }
         static_assert(S4_A_IT * 256 <= SW_A_ALLOC_ROWS * 4, "a row per staging item");
         f32x4 rin[S4_A_IT];
-        auto a_load = [&](int ch) __attribute__((always_inline)) {          // system-coherent: the channels may have been written by another CU in this launch
+        auto a_load = [&](int ch, bool valid = true) __attribute__((always_inline)) {          // system-coherent: the channels may have been written by another CU in this launch
 #pragma unroll
             for (int it = 0; it < S4_A_IT; ++it) {
-                const unsigned bo = in_off[it] >= 0 ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;      // (past the end: the range check returns 0)
+                const unsigned bo = (valid && in_off[it] >= 0) ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;      // (past the end: the range check returns 0)
                 rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, TNR_COH_LOAD_AUX));
             }
         };
@@ -686,8 +717,23 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         SweepCur ld{0, 0, 0, 0};         // the next slot to fetch
         a_load(0);
         __syncthreads();                 // the previous tile's last fragments are consumed
-        b_issue(ld, 0);
-        cur_advance(ld);
+        // direct form: register ring of weight fragments, unit `bq` is the next to fetch (wave-uniform); units 0 and 1 go out now
+        tnr_bf16x8 fbr[3][3];
+        int bq = 0;
+        auto b_fetch = [&](auto rc, int sp) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            fbr[r][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (bq * 3 + sp) * 1024, 0));      // (past the end of the stream: zeros)
+            if (sp == 2) ++bq;
+        };
+        if constexpr (DIRECT) {
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 0>{}, sp);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 1>{}, sp);
+        } else {
+            b_issue(ld, 0);
+            cur_advance(ld);
+        }
         sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_store_item(ic, 0); });
         { SW_T(t_pro); SW_ADD(0, t_pro - t_tile0); }
         int e = 0;                       // input chunks consumed so far in this tile
@@ -714,6 +760,23 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         // 2/3 of a slot ago; vector-memory operations complete in order, so waiting for all of them also covers the input-chunk loads
         // issued a slot ago); the ring slot `fill` is free and its DMA is set up -- the pieces are issued from inside the next two units
         auto slot_sync = [&](int fill) __attribute__((always_inline)) {
+            if constexpr (DIRECT) {
+                // chunk top of the direct form: only the input tile's double buffer is synchronised (LDS stores of every wave done,
+                // the other buffer consumed) -- the weight prefetch stays in flight across the barrier.  A pending stage output is
+                // published at the second chunk top after its epilogue (a whole chunk later: its stores have drained, vmcnt(0) costs the
+                // two prefetched units).
+                const bool pub = pend_tile >= 0 && ++pend_age >= (S4D_EPI_AFTER ? 2 : 1);
+                SW_T(t_s0);
+                if (pub) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                SW_T(t_s2);
+                SW_ADD(4, t_s2 - t_s0);
+                if (pub) {
+                    if (tid == 0) __hip_atomic_store(c.progress + pend_tile, pend_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pend_tile = -1;
+                }
+                return;
+            }
             const bool pub = pend_tile >= 0 && ++pend_age >= 3;
             SW_T(t_s0);
             while (dq < dpieces) dma_step();         // (never taken: every slot has room for its pieces)
@@ -781,11 +844,12 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
             for (int ck = 0; ck < nchunks; ++ck) {
                 // ---- chunk top: slot 0 of this chunk has landed, the chunk's input tile is in LDS
                 slot_sync(1);
-                if constexpr (!sw_apass(p)) {        // the stage completed by pass a of this phase (this pass never touches its accumulators)
+                if constexpr (!sw_apass(p) && !(DIRECT && S4D_EPI_AFTER)) {        // the stage completed by pass a of this phase (this pass never touches its accumulators)
                     if (ck == 0) epilogue_of(std::integral_constant<int, sw_phase(p)>{});
                 }
                 const bool last_ck = ck + 1 == nchunks;
                 has_next = !(last_ck && p == SW_NPASS - 1);
+                int ch_keep = 0;
                 if (has_next) {
                     int ch_next = ch_lo + 16 * (ck + 1);
                     if (last_ck) {
@@ -800,15 +864,33 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                             { SW_T(t_w1); SW_ADD(1, t_w1 - t_w0); }
                         }
                     }
+                    if constexpr (!(DIRECT && S4D_ALOAD_ALWAYS)) {
+                        SW_T(t_al0);
+                        a_load(ch_next);
+                        { SW_T(t_al1); SW_ADD(2, t_al1 - t_al0); }
+                    } else {
+                        ch_keep = ch_next;
+                    }
+                }
+                if constexpr (DIRECT && S4D_ALOAD_ALWAYS) {
+                    // the loads are issued on EVERY path (past-the-end addresses when there is no next chunk): with a branch around
+                    // them the compiler has to assume the shorter queue in front of the first fragment use and waits for these loads too
                     SW_T(t_al0);
-                    a_load(ch_next);
+                    a_load(ch_keep, has_next);
                     { SW_T(t_al1); SW_ADD(2, t_al1 - t_al0); }
                 }
                 const float *sa = s_a + (e & 1) * SW_A_FLOATS;
                 SW_T(t_c0);
-                sweep4_chunk<sw_j0(p), sw_nj(p)>(acc, sa, s_b_lane, apix0, half, sync, item_step, dma_step, tick);
+                sweep4_chunk<sw_j0(p), sw_nj(p), DIRECT>(acc, sa, s_b_lane, apix0, half, sync, item_step, dma_step, tick, fbr, b_fetch);
                 { SW_T(t_c1); SW_ADD(6, t_c1 - t_c0); SW_ADD(15, 1ull); SW_ADD(9 + (sw_nj(p) == 3 ? 0 : (sw_nj(p) == 2 ? 1 : 2)), t_c1 - t_c0); }
                 ++e;
+            }
+            if constexpr (DIRECT && S4D_EPI_AFTER && sw_apass(p) && p + 1 < SW_NPASS) {
+                // direct form: the epilogue of the stage this pass completed stands BEHIND the pass's chunk loop, on every path -- under
+                // `if (ck == 0)` at the top of the next pass the compiler must assume, at the join, that the fragment ring is the
+                // youngest thing in the memory queue and makes the first unit wait for the epilogue's stores.  Published two chunk tops
+                // later (slot_sync), as before: a whole chunk after the stores were issued.
+                epilogue_of(std::integral_constant<int, sw_phase(p)>{});
             }
         });
         epilogue_of(std::integral_constant<int, 4>{});      // the last stage (pass 8 is a pass a)
@@ -858,6 +940,18 @@ bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
     return true;
 }
 
+// which form runs (one per process: the weight image is laid out for it).  TNR_SWEEP_WAVES=8: the eight-wave form; TNR_SWEEP_FORM=dma:
+// the four-wave form with the LDS weight ring (round 3's default); otherwise the four-wave direct form.
+int sweep_form() {
+    static const int form = [] {
+        const char *w = getenv("TNR_SWEEP_WAVES"), *f = getenv("TNR_SWEEP_FORM");
+        if (w && atoi(w) == 8) return 8;
+        return (f && f[0] == 'd' && f[1] == 'm') ? 4 : 5;
+    }();
+    return form;
+}
+constexpr size_t S4D_LDS_BYTES = (size_t)(2 * SW_A_FLOATS) * sizeof(float);      // direct form: the input tile's double buffer only
+
 int sweep_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -865,8 +959,10 @@ int sweep_cus() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SW_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)SW_LDS_BYTES) != hipSuccess || cus < 1)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)SW_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)S4D_LDS_BYTES) != hipSuccess || cus < 1)
             cus = -1;
     }
     return cus;
@@ -907,6 +1003,7 @@ extern "C" int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void 
     SweepPackK a;
     a.nck0 = stages[0].Cin / 16;
     a.units = sw_total_units(a.nck0);
+    a.direct = sweep_form() == 5;
     TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_sweep_pack: image buffer too small");
     for (int i = 0; i < SW_NSTAGE; ++i) {
         a.wp[i] = stages[i].wp;
@@ -938,7 +1035,7 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     c.err = ws + ws_bytes / 4 - 1;
     static const int nxcd = [] { const char *e = getenv("TNR_SWEEP_DISPENSERS"); return e ? atoi(e) : 1; }();
     c.nxcd = nxcd == 1 ? 1 : 8;
-    c.disp = ws + (ws_bytes / 4 - 1 - 4 - 16);      // (inside conv_chain's per-CU counter area, which no sweep launch touches; zero-initialised)
+    c.disp = ws + (ws_bytes / 4 - 1 - 4 - CH_CU_KEYS - CH_SWEEP_WORDS);      // (words of their own, zero-initialised; every launch leaves them at zero)
     c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
     c.wq = static_cast<const float *>(image);
     c.wq_bytes = sw_total_units(c.nck0) * SW_UNIT_FLOATS * (int)sizeof(float);
@@ -961,8 +1058,9 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     // whole images per round of the grid, one tile per workgroup and round
     const int per_round = (cus / c.tpi) * c.tpi;
     const int grid = c.tiles < per_round ? c.tiles : per_round;
-    static const int waves = [] { const char *e = getenv("TNR_SWEEP_WAVES"); return e ? atoi(e) : 4; }();      // 8: the eight-wave form
-    if (waves == 8) hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
-    else hipLaunchKernelGGL(conv_sweep4_kernel, dim3((unsigned)grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, c);
+    const int form = sweep_form();
+    if (form == 8) hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
+    else if (form == 4) hipLaunchKernelGGL(conv_sweep4_kernel<false>, dim3((unsigned)grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, c);
+    else hipLaunchKernelGGL(conv_sweep4_kernel<true>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     return tnr_check_launch("conv_sweep");
 }

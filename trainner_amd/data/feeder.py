@@ -50,7 +50,7 @@ class DeviceFeeder:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.znorm, self.data_range, self.bgr2rgb = bool(znorm), float(data_range), bool(bgr2rgb)
         self.depth = max(2, int(depth))
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.copy_stream = torch.cuda.Stream(device=self.device, priority=-1)     # ahead of the step's kernels: its launches are few and small
         self.bytes_uploaded = 0
         # the slots (device buffers, pinned staging, `free` events) live as long as the feeder: a new epoch's first uploads wait
         # for the step that consumed the slot last, and no buffer goes back to the copy stream's allocator pool while the
@@ -98,11 +98,19 @@ class DeviceFeeder:
                 if flags is None:
                     return None, 0
                 f = _as_host_tensor(flags).to(torch.int32).contiguous()
-                d = slot.dev_flags.get(name)
-                if d is None or d.numel() != f.numel():
-                    d = torch.empty(f.numel(), dtype=torch.int32, device=self.device)
-                    slot.dev_flags[name] = d
-                d.copy_(f, non_blocking=False)               # a few bytes
+                ent = slot.dev_flags.get(name)
+                if ent is None or ent[0].numel() != f.numel():
+                    ent = slot.dev_flags[name] = (torch.empty(f.numel(), dtype=torch.int32, device=self.device),
+                                                  torch.empty(f.numel(), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+                    ent[2].record(self.copy_stream)
+                d, pin, ev = ent
+                # through page-locked memory and asynchronous: a pageable (blocking) copy here made the HOST wait for the copy stream,
+                # which itself waits for the step that consumed this slot (slot.free) -- the launch queue ran dry once per step
+                # (bench.py --feed paired: 253.3 vs 244.1 ms, profiles/r03ag_bench_variants.txt)
+                ev.synchronize()                             # the slot's previous flag upload (two steps ago) has executed
+                pin.copy_(f)
+                d.copy_(pin, non_blocking=True)
+                ev.record(self.copy_stream)
                 return d, int(bool((f & 2).any()))
 
             shared = device_flags("flags")
@@ -148,23 +156,62 @@ class DeviceFeeder:
 
     # ------------------------------------------------------------------ iteration
     def __iter__(self):
-        it = iter(self.loader)
-        pending = collections.deque()
-        for s in self._slots:
-            b = next(it, None)
-            if b is None:
-                break
-            self._upload(s, b)
-            pending.append(s)
-        while pending:
-            s = pending.popleft()
-            torch.cuda.current_stream(self.device).wait_event(s.ready)
-            yield s.batch
-            # the consumer came back for the next batch: everything that reads this slot is enqueued by now
-            if s.free is None:
-                s.free = torch.cuda.Event()
-            s.free.record(torch.cuda.current_stream(self.device))
-            b = next(it, None)
-            if b is not None:
-                self._upload(s, b)
-                pending.append(s)
+        """Batches in loader order.  The loader iteration, the uploads and the on-device preparation (crop / flip / degradations) run in a
+        worker thread on the copy stream: whatever blocks the HOST there -- pageable copies of per-sample parameters, the wait for the
+        step that last read a slot -- blocks that thread (the GIL is released inside the runtime calls), never the thread that
+        launches the training step.  The consumer hands a slot back (with a fresh `free` event) when it returns for the next batch."""
+        import queue
+        import threading
+        todo, done = queue.Queue(), queue.Queue()
+        STOP = object()
+
+        def work():
+            torch.cuda.set_device(self.device)
+            it = iter(self.loader)
+            try:
+                while True:
+                    slot = todo.get()
+                    if slot is STOP:
+                        return
+                    b = next(it, None)
+                    if b is None:
+                        done.put(STOP)
+                        return
+                    self._upload(slot, b)
+                    done.put(slot)
+            except BaseException as e:      # surfaces in the consumer's thread
+                done.put(e)
+
+        worker = threading.Thread(target=work, name="tnr-feeder", daemon=True)
+        worker.start()
+        for slot in self._slots:
+            todo.put(slot)
+        out = set(self._slots)              # slots whose tensors may still be read (handed to the worker or the consumer)
+        s = None
+        try:
+            while True:
+                s = done.get()
+                if s is STOP:
+                    s = None
+                    break
+                if isinstance(s, BaseException):
+                    e, s = s, None
+                    raise e
+                torch.cuda.current_stream(self.device).wait_event(s.ready)
+                yield s.batch
+                # the consumer came back for the next batch: everything that reads this slot is enqueued by now
+                self._mark_free(s)
+                todo.put(s)
+                s = None
+        finally:
+            # also when the consumer leaves early (break / exception: GeneratorExit lands at the yield): stop the worker, then give
+            # every slot a fresh `free` event so that the next epoch's uploads wait for whatever still reads them
+            todo.put(STOP)
+            worker.join()
+            for q in out:
+                self._mark_free(q)
+
+    def _mark_free(self, s):
+        if s.free is None:
+            s.free = torch.cuda.Event()
+        s.free.record(torch.cuda.current_stream(self.device))

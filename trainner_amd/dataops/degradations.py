@@ -202,7 +202,36 @@ RESRGAN = {
     "final_compression": dict(enabled=True, quality=(30, 95)),
     "shuffle": False,
 }
+# What the reference merges every preset OVER (options/presets/base_{blur,resize,noise}.yaml): every degradation stage is off -- only
+# the plain down-scaling to the LR size (`lr_downscale: true`, linear / bicubic) is on -- and the per-type values are the base files'.
+BASE = {
+    "blur": dict(enabled=False, types={}, prob=1.0,
+                 iso=dict(ks=(7, 21), sigmaX=(0.1, 2.8)), aniso=dict(ks=(7, 21), sigmaX=(0.1, 2.8), sigmaY=(0.1, 2.8), angle=(0, 180)),
+                 sinc=dict(ks=(7, 21))),
+    "blur2": dict(enabled=False, types={}, prob=1.0,
+                  iso=dict(ks=(7, 21), sigmaX=(0.1, 2.8)), aniso=dict(ks=(7, 21), sigmaX=(0.1, 2.8), sigmaY=(0.1, 2.8), angle=(0, 180)),
+                  sinc=dict(ks=(7, 21))),
+    "final_blur": dict(enabled=False, prob=1.0, sinc=dict(ks=(7, 21))),
+    # (base_resize.yaml's `lr_downscale: true` with no random range active = the plain HR -> LR down-scaling by `scale`: in this
+    #  pipeline's terms the final scale; the random-factor resizes are what the resrgan resize preset switches on)
+    "resize": dict(enabled=False, prob={"down": 1.0}, up=(1.0, 1.5), down=(0.15, 1.0), algos=("linear", "cubic")),
+    "resize2": dict(enabled=False, prob={"down": 1.0}, up=(1.0, 1.2), down=(0.3, 1.0), algos=("linear", "cubic")),
+    "final_scale": dict(enabled=True, algos=("linear", "cubic")),
+    "noise": dict(enabled=False, types=(), gaussian=dict(var=(1, 25), prob_color=0.5, multi=True), poisson=dict(scale=(0.5, 1.0), prob_color=0.5)),
+    "noise2": dict(enabled=False, types=(), gaussian=dict(var=(1, 25), prob_color=0.5, multi=True), poisson=dict(scale=(0.5, 1.0), prob_color=0.5)),
+    "compression": dict(enabled=False, quality=(30, 95)),
+    "final_compression": dict(enabled=False, quality=(30, 95)),
+    "shuffle": False,
+}
+_KIND_KEYS = {"blur": ("blur", "blur2", "final_blur"), "resize": ("resize", "resize2", "final_scale"),
+              "noise": ("noise", "noise2", "compression", "final_compression")}
 _ALGO = {"area": "area", "linear": "linear", "bilinear": "linear", "cubic": "cubic", "bicubic": "cubic"}
+
+
+def _algo(t):
+    if str(t) not in _ALGO:
+        raise NotImplementedError("resize type %r is not implemented by the device pipeline (area / linear / cubic)" % (t,))
+    return _ALGO[str(t)]
 
 
 def _load_preset(path, kind):
@@ -214,28 +243,55 @@ def _load_preset(path, kind):
     return doc.get("config") or {}
 
 
+def find_preset_file(presets_root, name, options_dir=None):
+    """options/options.py:166-181: `options/<presets_root>/<name>.yaml` relative to the working directory, or the bare file name;
+    additionally `<presets_root>` itself (absolute or relative) and the same two places next to the options file."""
+    if not name:
+        return None
+    import os
+    full = name if name.endswith(".yaml") else name + ".yaml"
+    root = presets_root or "presets"
+    cands = [os.path.join("options", root, full), os.path.join(root, full), full]
+    if options_dir:
+        cands += [os.path.join(options_dir, root, full), os.path.join(options_dir, full), os.path.join(options_dir, "..", root, full)]
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    return None
+
+
 def degradation_config(dataset_opt=None, presets_root=None):
     """The pipeline configuration of a train dataset with `augs_strategy: <name>` / `add_{blur,resize,noise}_preset` (reference:
-    options/options.py presets_names :148-165 and the merge :366-463): the built-in resrgan values, overlaid by the preset files
-    `<name>_{blur,resize,noise}.yaml` found under `presets_root` (default: `presets` next to the options file, as in the reference)
-    when they exist, overlaid by keys given directly in the dataset options (pipeline switches such as `lr_blur_types`, `blur_prob`,
-    `shuffle_degradations`, and per-type dictionaries under `aug_configs`).  Types the device pipeline does not implement raise."""
+    options/options.py presets_names :148-165, find_preset_file :166-181 and the merge :366-463).  Like there, everything starts
+    from the base presets -- every degradation stage OFF, plain down-scaling on (BASE) -- and only what a named preset or a key in
+    the dataset options switches on runs: `add_blur_preset: resrgan_blur` alone gives the Real-ESRGAN blurs and nothing else.
+    Per kind: the preset file `<name>.yaml` (find_preset_file) when it exists; else, for the `resrgan_*` names, the built-in copy of
+    the reference's resrgan_{blur,resize,noise}.yaml (logged); any other missing preset is skipped like in the reference
+    (`realsr` ships no blur preset).  Then the keys given directly in the dataset options (pipeline switches such as
+    `lr_blur_types`, `blur_prob`, `shuffle_degradations`, per-type dictionaries under `aug_configs`).  Types the device pipeline
+    does not implement raise NotImplementedError.  No arguments: the full Real-ESRGAN configuration (`augs_strategy: resrgan`)."""
     import copy
-    import os
-    ds = dict(dataset_opt or {})
-    cfg = copy.deepcopy(RESRGAN)
+    import logging
+    log = logging.getLogger("base")
+    if dataset_opt is None:
+        dataset_opt = {"augs_strategy": "resrgan"}
+    ds = dict(dataset_opt)
+    cfg = copy.deepcopy(BASE)
     strat = ds.get("augs_strategy")
     names = {k: ds.get("add_%s_preset" % k) or (("%s_%s" % (strat, k)) if strat else None) for k in ("blur", "resize", "noise")}
     root = presets_root or ds.get("presets_root") or "presets"
     raw = {}
     for k, kind in (("blur", "Blur"), ("resize", "Resize"), ("noise", "Noise")):
-        path = os.path.join(root, "%s.yaml" % names[k]) if names[k] else None
-        if path and os.path.isfile(path):
+        raw[k] = {}
+        path = find_preset_file(root, names[k], ds.get("_options_dir"))
+        if path:
             raw[k] = _load_preset(path, kind)
-        elif names[k] and not str(names[k]).startswith("resrgan"):
-            raise NotImplementedError("preset %r not found under %r (only the resrgan values are built in)" % (names[k], root))
-        else:
-            raw[k] = {}
+        elif names[k] and str(names[k]) == "resrgan_%s" % k:
+            log.info("preset %s not found under %r: using the built-in copy of the reference's file", names[k], root)
+            for key in _KIND_KEYS[k]:
+                cfg[key] = copy.deepcopy(RESRGAN[key])
+        elif names[k]:
+            log.warning("preset %s not found under %r: skipped (as the reference does)", names[k], root)
     pipe = {}
     for k in ("blur", "resize", "noise"):
         pipe.update(raw[k].get("pipeline") or {})
@@ -285,7 +341,7 @@ def degradation_config(dataset_opt=None, presets_root=None):
         if sw in pipe:
             c["enabled"] = bool(pipe[sw])
         if tk in pipe and pipe[tk]:
-            c["algos"] = tuple(_ALGO[str(t)] for t in pipe[tk])
+            c["algos"] = tuple(_algo(t) for t in pipe[tk])
         a = aug.get(key) or {}
         if a.get("resize_prob"):
             c["prob"] = dict(a["resize_prob"])
@@ -293,7 +349,7 @@ def degradation_config(dataset_opt=None, presets_root=None):
     if "final_scale" in pipe:
         cfg["final_scale"]["enabled"] = bool(pipe["final_scale"])
     if pipe.get("final_scale_types"):
-        cfg["final_scale"]["algos"] = tuple(_ALGO[str(t)] for t in pipe["final_scale_types"])
+        cfg["final_scale"]["algos"] = tuple(_algo(t) for t in pipe["final_scale_types"])
     for key, sw, tk, sfx in (("noise", "lr_noise", "lr_noise_types", ""), ("noise2", "lr_noise2", "lr_noise_types2", "2")):
         c = cfg[key]
         if sw in pipe:

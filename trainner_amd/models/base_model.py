@@ -407,6 +407,10 @@ class BaseModel:
         """Data-parallel exchange of the gradients the backward pass just produced."""
         if not self.dp.active:
             return
+        timed = getattr(self, "comm_events", None) is not None and self.device.type == "cuda"
+        if timed:                                   # bench.py: the EXPOSED part of the exchange = how long the compute stream sits
+            e0 = torch.cuda.Event(enable_timing=True)      # between the last backward kernel and the first optimiser kernel
+            e0.record(torch.cuda.current_stream(self.device))
         for net in self._opt_nets[opt_flag]:
             holder = net.flat_params()
             sched = getattr(net, "_bucket_schedule", None)
@@ -416,6 +420,10 @@ class BaseModel:
             else:
                 self.dp.reduce_flat(holder.grad)
         self.dp.wait(self.device)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream(self.device))
+            self.comm_events.append((opt_flag, e0, e1))
 
     def optimizer_step(self, step, optimizer, opt_flag):
         """base_model.py:815-850: step only when the virtual batch is complete; G gets the clip."""

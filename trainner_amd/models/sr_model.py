@@ -86,13 +86,14 @@ class SRModel(BaseModel):
             l_g_gan = self.adversarial(self.fake_H, self.var_ref, netD=self.netD, stage="generator", fsfilter=self.f_high)
             self.log_dict["l_g_gan"] = l_g_gan.detach()
             l_g_total = l_g_total + (l_g_gan if self.accumulations == 1 else l_g_gan / self.accumulations)
-        # G's gradients (67 MB: ~1 ms of xGMI time) are NOT all-reduced while its backward runs: with RCCL kernels on the CUs the
-        # dense-block chain kernel has to fall back to one launch per layer (it needs its whole grid co-resident), which costs the
-        # trunk's backward more (~8 ms) than the overlap could hide.  They go out in one sweep at the optimizer step (_sync_gradients);
-        # D, which has no chain launches and the larger buffer (110 MB), keeps the overlapped schedule (backward_D).
-        # TNR_DP_OVERLAP_G=1 arms the bucket schedule for G as well (north star: overlapped with backward on a side stream); together
-        # with TNR_CHAIN_WITH_COLLECTIVES=1 the dense blocks stay one launch each next to the collectives (ops.CHAIN_WITH_COLLECTIVES).
-        if os.environ.get("TNR_DP_OVERLAP_G", "0") == "1":
+        # G's gradient buckets (67 MB) leave for RCCL from inside its backward, on the side stream (north star; SURVEY.md 8(e) collective 1),
+        # whenever the dense blocks can stay one launch each next to the collectives -- the dispensed four-wave sweep of the default
+        # arithmetic does (ops.dense_blocks_overlap_collectives).  Where they cannot (tnr_conv_chain: fp32 matrix core, use_amp), the
+        # per-layer fallback would cost the trunk's backward more (~8 ms) than the overlap hides (~1 ms of xGMI time): there the buckets
+        # go out in one sweep at the optimizer step (_sync_gradients).  TNR_DP_OVERLAP_G=1 / 0 forces either.
+        from .. import ops
+        want = os.environ.get("TNR_DP_OVERLAP_G", "auto")
+        if want == "1" or (want == "auto" and ops.dense_blocks_overlap_collectives()):
             self._arm_bucket_schedule([self.netG], passes=1)
         self.calc_gradients(l_g_total)
 

@@ -343,6 +343,14 @@ COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket ha
 # +0.10 ms per dense-block launch (sweep 0.61 -> 0.71 ms, chain 1.01 -> 1.14 ms).  Off by default: with N > 1 ranks an RCCL kernel waits
 # for its peers while it holds CUs the launch wants all of -- never exercised on hardware here.
 CHAIN_WITH_COLLECTIVES = os.environ.get("TNR_CHAIN_WITH_COLLECTIVES", "0") == "1"
+SWEEP_DISPENSED = os.environ.get("TNR_SWEEP_WAVES", "4") != "8"      # the four-wave forms take their tiles from an atomic counter (conv_sweep.hip)
+COUNTERS = {"one_launch_next_to_collectives": 0, "per_layer_next_to_collectives": 0}      # dense blocks launched while gradient buckets were in flight
+
+
+def dense_blocks_overlap_collectives():
+    """True when the dense blocks stay one launch each next to in-flight gradient buckets in the CURRENT arithmetic (the dispensed
+    sweep of TNR_MMA_BF16X3, or TNR_CHAIN_WITH_COLLECTIVES=1): the generator's all-reduce can then overlap its backward for free."""
+    return CHAIN_WITH_COLLECTIVES or (CONV_CHAIN and CONV_SWEEP and SWEEP_DISPENSED and CHAIN_X3 and MMA == hip.MMA_BF16X3)
 _chain_epoch = {}
 _sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
 
@@ -379,7 +387,14 @@ def conv_chain(stages):
     n = len(stages)
     assert 1 <= n <= CHAIN_MAX
     eligible = all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages)
-    if not CONV_CHAIN or (COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES) or not eligible:
+    # gradient buckets on the wire: tnr_conv_chain (and the eight-wave sweep) need their whole grid co-resident, which RCCL's
+    # kernels on the same CUs could delay -> one launch per layer meanwhile.  The four-wave sweep DISPENSES its tiles (a waited-for
+    # tile always belongs to a running workgroup; tiles_x + 2 resident workgroups are enough): it stays one launch.
+    crowded = COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES
+    sweep_ok = CONV_SWEEP and n == 5 and MMA == hip.MMA_BF16X3 and CHAIN_X3
+    if not CONV_CHAIN or not eligible or (crowded and not (sweep_ok and SWEEP_DISPENSED)):
+        if crowded and CONV_CHAIN and eligible:
+            COUNTERS["per_layer_next_to_collectives"] += 1
         for st in stages:
             conv(**{k: v for k, v in st.items() if k != "fresh_from"})
         return
@@ -410,6 +425,13 @@ def conv_chain(stages):
     image = None
     if CONV_SWEEP and n == 5 and descs[0].mma == hip.MMA_BF16X3:
         image = _sweep_image(lib, descs, n, stages, dev)
+    if crowded and image is None:                      # (a 5-stage block the sweep does not cover: shapes, tiles per image)
+        COUNTERS["per_layer_next_to_collectives"] += 1
+        for st in stages:
+            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+        return
+    if COLLECTIVES_IN_FLIGHT:
+        COUNTERS["one_launch_next_to_collectives"] += 1
     t0 = PROFILE.begin() if PROFILE is not None else None
     if image is not None:
         hip.check(lib.tnr_conv_sweep(descs, n, image.data_ptr(), ws.data_ptr(), ws.numel() * 4, _chain_epoch[key], hip.stream()), "conv_sweep")

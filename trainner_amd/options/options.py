@@ -97,11 +97,13 @@ def parse_datasets(opt, scale=1):
             ds["subset_file"] = os.path.normpath(os.path.expanduser(ds["subset_file"]))
         if phase == "train" and scale != 1 and not ds.get("pre_crop", None) and not ds.get("preprocess"):
             ds["preprocess"] = "crop"
-        if phase == "train" and (ds.get("augs_strategy") or any(ds.get("add_%s_preset" % k) for k in ("blur", "resize", "noise"))):
+        if phase == "train" and not ds.get("dataroot_LR") and (ds.get("augs_strategy") or any(ds.get("add_%s_preset" % k) for k in ("blur", "resize", "noise"))):
             # presets overlay (options.py:148-165,366-463): the merged degradation configuration of the device pipeline
             # (dataops/degradations.degradation_config reads <presets_root>/<name>_{blur,resize,noise}.yaml and the dataset's overrides)
             from ..dataops.degradations import degradation_config
+            # (only when the LR side is generated on the fly: with dataroot_LR the device pipeline is not used and nothing is merged)
             ds["presets_root"] = opt.get("presets_root", None) or ds.get("presets_root", None) or "presets"
+            ds["_options_dir"] = opt.get("_options_dir")
             ds["degradation"] = degradation_config(ds, ds["presets_root"])
         ds.setdefault("resize_strat", "pre")
         if ds.get("tensor_shape", None):
@@ -125,6 +127,7 @@ def parse(opt_path, is_train=True):
 
     opt["is_train"] = is_train
     scale = opt.get("scale", 1)
+    opt["_options_dir"] = os.path.dirname(os.path.abspath(opt_path))      # presets are also looked up next to the options file
     opt = parse_datasets(opt, scale)
 
     for key, path in opt["path"].items():
