@@ -44,6 +44,13 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_bf16, dense: 256 CU x 4
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 FLOP_PER_IMG = 3.0327e12           # full optimize_parameters, fp32, 128->512 (the reference's schedule)
 D_FWD_FLOP_PER_IMG = 7.34e10       # one Discriminator_VGG(512) forward (the D rows / 4 calls)
+# --netd unet (BASELINE configs[3]'s discriminator, discriminators.py:686-779, nf 64 at 512 x 512): forward MACs per image, layer by layer
+# conv0 3->64 3x3 @512: 0.453 G; conv1..3 4x4 s2 (64->128 @256, 128->256 @128, 256->512 @64): 3 x 8.59 G; conv4..6 3x3 after bilinear x2
+# (512->256 @128, 256->128 @256, 128->64 @512): 3 x 19.33 G; conv7, conv8 64->64 @512: 2 x 9.66 G; conv9 64->1 @512: 0.151 G  = 103.7 GMAC
+UNET_D_FWD_FLOP_PER_IMG = 2.074e11
+# the step with it: everything but the discriminator (3.0327e12 - 9 x 7.34e10: four forwards, the G stage's data-gradient, two full backward
+# passes of the VGG-style D) + the same nine forward-equivalents of the U-Net D
+FLOP_PER_IMG_UNET_D = FLOP_PER_IMG - 9 * D_FWD_FLOP_PER_IMG + 9 * UNET_D_FWD_FLOP_PER_IMG
 BATCH_PER_GPU = 16
 CROP = 512
 MMA_TEXT = {
@@ -346,8 +353,13 @@ def main():
                               device=device, degrade=degrade)
         batches = iter(feeder)
 
+    last_batch = [None]
+
     def next_batch():
-        return data if feeder is None else next(batches)
+        if feeder is None:
+            return data
+        last_batch[0] = next(batches)
+        return last_batch[0]
 
     for _ in range(args.warmup):
         step += 1
@@ -384,8 +396,11 @@ def main():
         raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
 
     roof = None
-    if not args.no_roofline and feeder is None:
+    if not args.no_roofline:
         # separate instrumented pass: HIP events around every implicit-GEMM launch, on the launch stream
+        # (with the input pipeline in the loop: on the last batch it delivered -- the kernels and shapes are the same)
+        if feeder is not None:
+            data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in last_batch[0].items()}
         prof = ops.ConvProfile()
         ops.PROFILE = prof
         nprof = min(2, args.steps)
@@ -465,7 +480,8 @@ def main():
 
     if rank == 0:
         imgs = args.batch * world * args.steps
-        memo = bool(getattr(getattr(model, "netD", None), "memoize", False)) and args.netd == "discriminator_vgg"
+        memo_any = bool(getattr(getattr(model, "netD", None), "memoize", False))
+        memo = memo_any and args.netd == "discriminator_vgg"
         out = {
             "metric": "HR images/sec (G+D step), ESRGAN x4 128->512",
             "value": round(imgs / dt, 3), "unit": "HR img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -483,8 +499,9 @@ def main():
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of
             # the reference schedule's four D forwards are not recomputed and are NOT counted
-            "step_tflops": round((FLOP_PER_IMG - (2 * D_FWD_FLOP_PER_IMG if memo else 0.0)) * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
-            "d_forward_memoized": memo,
+            "step_tflops": round(((FLOP_PER_IMG - (2 * D_FWD_FLOP_PER_IMG if memo else 0.0)) if args.netd == "discriminator_vgg" else
+                                  (FLOP_PER_IMG_UNET_D - (2 * UNET_D_FWD_FLOP_PER_IMG if memo_any else 0.0))) * (args.crop / 512.0) ** 2 * imgs / dt / 1e12, 2),
+            "d_forward_memoized": memo_any,
             "roofline": roof,
             (variant_key or "variant_f32_mfma"): variant,
             "losses": {k: round(v, 6) for k, v in log.items()},

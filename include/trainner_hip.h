@@ -123,6 +123,12 @@ typedef struct tnr_conv_desc {
      * noise_pix0: first pixel of this rank's shard in the global batch (data-parallel ranks draw what one process would draw on the
      * concatenated batch).  Cout % 4 == 0; never combined with split-K; tnr_conv_sweep accepts it on the last stage only.          */
     float noise_sigma; int32_t noise_pos; uint32_t noise_key0, noise_key1, noise_pix0;
+    /* optional: the layer's weights as a PRE-SPLIT stream (tnr_conv_wq_pack from the packed fp32 weights `wp`; valid until those
+     * change) for TNR_MMA_BF16X3 / TNR_CONV_3x3 launches with Cout % 64 == 0 and Cin % 16 == 0: the kernel then takes its weight
+     * fragments straight from L2 into registers (three bf16 planes in MFMA operand order, one coalesced 1 KB read per plane) instead
+     * of splitting and staging the slab through LDS per workgroup and chunk.  NULL: the launch stages `wp` itself.  Same results
+     * bit for bit either way.                                                                                                    */
+    const void *wq; int64_t wq_bytes;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -183,6 +189,9 @@ int tnr_conv_forward(const tnr_conv_desc *d, void *stream);
 int tnr_gauss_mult(tnr_view dst, tnr_view src, int64_t pixels, int32_t C, float sigma, uint32_t key0, uint32_t key1, uint32_t pix0,
                    void *stream);
 int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d);   /* 0 when the launch would not be split */
+/* size of / build the pre-split weight stream of a launch (tnr_conv_desc.wq); 0: the launch cannot use one */
+int64_t tnr_conv_wq_bytes(const tnr_conv_desc *d);
+int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t image_bytes, void *stream);
 /* out[(n*Ho + oy)*Wo + ox][(ky*kw + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside):
  * the patch matrix of a k x k convolution as an NHWC "image" of Ho*Wo*N pixels with kh*kw*C channels, for
  * TNR_CONV_1x1 with TNR_PACK_COL_* weights.  C % 4 == 0.                                                */

@@ -302,6 +302,33 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
     assert ops.chain_error_flag() == 0
 
 
+@pytest.mark.parametrize("case", [(2, 40, 72, 64, 64, "lrelu", False), (1, 8, 32, 32, 64, "plain", False), (3, 17, 33, 128, 128, "res", False),
+                                  (2, 64, 64, 256, 256, "mask", True), (1, 32, 32, 512, 512, "plain", False), (2, 96, 160, 64, 128, "lrelu", True),
+                                  (1, 9, 45, 96, 192, "res", False), (2, 24, 40, 64, 64, "noise", False)])
+def test_conv3x3_weight_stream_kernel_equals_staged_weights(case):
+    """TNR_MMA_BF16X3, 3x3 layers with Cout % 64 == 0: conv3x3_d4_kernel (tnr_conv_desc.wq: weights as a pre-split stream read straight
+    into registers; csrc/conv_sweep.hip) against the kernels that split and stage the slab per workgroup (ops.X3_D4 = False), bit for bit:
+    ragged tiles, a single tile, several 64-cout blocks, channel windows of wider buffers, forward and data-gradient packings, bias /
+    LeakyReLU / residual / mask / noise epilogues; and the staged kernels themselves against fp32 F.conv2d (test_conv3x3_forward...)."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the weight stream is the split arithmetic's (three bf16 planes)")
+    from tools.probes.d4_check import layer
+    N, H, W, Cin, Cout, epi, dg = case
+    run, packer, _ = layer(N, H, W, Cin, Cout, 77, epi, dg)
+    ref = run(False)
+    for rep in range(2):
+        assert torch.equal(run(True), ref), rep
+    assert len(packer.__dict__.get("_wq_images", {})) <= 1 and float(ref[..., :64].min()) == 3.0 and float(ref[..., 64 + Cout:].min()) == 3.0
+    assert len(packer.__dict__.get("_wq_images", {})) == 1 or N * H * W <= 16384         # (small-spatial 512-channel layers run split-K instead)
+    # the stream follows the weights: after the packer runs again (optimiser step) the image is rebuilt
+    packer.jobs[0][0].mul_(0.5)
+    packer.run()
+    half = run(True)
+    assert torch.equal(half, run(False)) and not torch.equal(half, ref)
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # ESRGAN+ GaussianNoise (block.py:587-600): the counter-based multiplier field of csrc/gauss_noise.h
 # ------------------------------------------------------------------------------------------------------------------------

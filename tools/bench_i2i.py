@@ -160,13 +160,18 @@ def main():
     print(json.dumps({
         "metric": "images/sec (G+D step), %s %dx%d" % (args.model, args.size, args.size), "value": round(imgs / dt, 2), "unit": "img/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-        "higher_is_better": True, "dtype": "bf16" if args.amp else "f32", "data": "synthetic", "variant": True,
+        "higher_is_better": True, "dtype": "bf16" if args.amp else ("f32 (bf16x3)" if ops.MMA == hip.MMA_BF16X3 else "f32"), "data": "synthetic", "variant": True,
         "config": {"workload": "%s: %s + PatchGAN (ndf 64), batch %d, %dx%d, vanilla GAN (standard form) + L1%s (BASELINE configs[4])"
                                % (args.model, "ResnetGenerator-9 (ngf 64, InstanceNorm)" if args.netg == "resnet" else "UnetGenerator (8 downs, ngf 64, BatchNorm)",
                                   args.batch, args.size, args.size, ", identity 0.5, pool 50" if args.model == "cyclegan" else ""),
                    "mma": os.environ.get("TNR_MMA", "bf16x3")},
         "conv_gflop_per_img": round(fl / 1e9, 1) if args.netg == "resnet" else None,
         "step_tflops": round(fl * imgs / dt / 1e12, 2) if args.netg == "resnet" else None,
+        # the same convention as bench.py's roofline: fp32-equivalent ceiling of the split arithmetic = bf16 dense peak / 6
+        "roofline": ({"bound": "mfma", "achieved": round(fl * imgs / dt / 1e12, 2), "unit": "TFLOP/s",
+                      "peak": round((2516.6 if args.amp else (2516.6 / 6.0 if ops.MMA == hip.MMA_BF16X3 else 157.3)), 1),
+                      "frac": round(fl * imgs / dt / 1e12 / (2516.6 if args.amp else (2516.6 / 6.0 if ops.MMA == hip.MMA_BF16X3 else 157.3)), 4),
+                      "scope": "whole step (every convolution of G and D, forward and both gradients; wall clock)"} if args.netg == "resnet" else None),
         "losses": {k: round(v, 5) for k, v in log.items()}}))
 
 

@@ -3,6 +3,7 @@
 #   suite <tag> [pytest args]        the -m gpu suite (both arithmetic modes, tests/conftest.py) + smoke
 #   prof  <tag> <bf16x3|f32> [bench args]   rocprofv3 kernel stats of 3 bench steps + separate PMC passes (HBM traffic, MFMA busy) of 1
 #   final <tag>                      suite + default bench line (with cpu_baseline) + prof bf16x3: the validation of a tree
+#   power <tag> <name> <cmd...>      the command with rocm-smi sampled every 0.5 s next to it (clock, socket power, temperature)
 #   run   <tag> <name> <cmd...>      any command, output to gpurun_out/<tag>_<name>.txt (tail printed)
 #   ab    <tag> <name> <v1,v2,..> <cmd...>  the command once per kernel-build variant (tools/build_variant.py; "" = the shipped library)
 set -u
@@ -47,6 +48,14 @@ case $CMD in
     tail -1 $O/${TAG}_bench_default.json.log | cut -c1-1500
     prof bf16x3 > $O/${TAG}_prof_summary.txt 2>&1
     tail -4 $O/${TAG}_prof_summary.txt | cut -c1-600 ;;
+  power)
+    NAME=${1:?name}; shift
+    ( while true; do rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|Socket Graphics Package Power|junction" | tr '\n' ' '; echo; sleep 0.5; done ) > $O/${TAG}_${NAME}_smi.txt &
+    SMI=$!
+    ( time "$@" ) > $O/${TAG}_${NAME}.txt 2>&1
+    kill $SMI
+    grep -v amdgpu.ids $O/${TAG}_${NAME}.txt | tail -3 | cut -c1-300
+    awk 'NR%4==0' $O/${TAG}_${NAME}_smi.txt | cut -c1-260 | tail -${TAIL:-25} ;;
   run)
     NAME=${1:?name}; shift
     ( time "$@" ) > $O/${TAG}_${NAME}.txt 2>&1

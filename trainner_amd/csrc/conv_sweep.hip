@@ -912,6 +912,160 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
 #endif
 }
 
+// =====================================================================================================================================
+// A plain 3x3 convolution / data-gradient on the machinery of the direct sweep ("d4"; TNR_MMA_BF16X3, Cout % 64 == 0, Cin % 16 == 0).
+// The 8-wave kernel of conv_x3w8.h splits and stages the 9 x 64 x 16 weight slab through LDS in every workgroup at every chunk, in a
+// phase of its own between two barriers (the matrix core idles meanwhile: MFMA busy 0.62).  Here the weights come as a pre-split stream
+// (tnr_conv_wq_pack: units of one tap x one 32-cout N-tile x 16 channels, 3 KB, plane by plane in register order) straight from L2 into a
+// register ring, the input tile is double-buffered in LDS and its split + store is handed out behind the MFMAs -- sweep4_chunk<0, 2, true>,
+// the chunk body of the dense-block sweep with two N-tiles: one barrier per chunk, nothing but MFMAs and side work between them.
+// Tile 8 x 32 pixels x 64 output channels, four waves (wave w: tile rows 2 w, 2 w + 1), OCC workgroups per CU (73.7 KB of LDS each):
+// with two, one workgroup's epilogue / prologue / barrier runs under the other's MFMAs.  Arithmetic (split, kept products and their
+// order, chunk and tap order, epilogue) is that of conv_tile_body<.., BF = 2> / conv3x3_x3w8_kernel: bit-identical results.
+struct D4K {
+    ConvK a;
+    const float *wq;                   // [cb][chunk][tap][N-tile] units (sweep direct layout)
+    int wq_bytes;
+    int nck;                           // input chunks (Cin / 16)
+    int tiles_x, tiles_y, ncb, tiles;
+};
+
+struct D4PackK {
+    const float *wp;
+    int KinP, KoutP, nck, ncb, units;
+    float *out;
+};
+
+__global__ void __launch_bounds__(256) d4_pack_kernel(const D4PackK a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int unit = g >> 6, r = (g >> 1) & 31, h = g & 1;
+    if (unit >= a.units) return;
+    const int per_cb = a.nck * 18;
+    const int cb = unit / per_cb, rem = unit - cb * per_cb;
+    const int ck = rem / 18, tj = rem - ck * 18, tap = tj >> 1, j = tj & 1;
+    const float *src = a.wp + ((size_t)tap * a.KoutP + cb * 64 + j * 32 + r) * a.KinP + 16 * ck + 8 * h;
+    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(src), q1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    tnr_bf16x8 pl[3];
+    tnr_split_bf16x3(q0, q1, pl);
+    float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + (h * 32 + r) * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + k * 256) = pl[k];
+}
+
+template <int OCC>
+__global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_a = smem;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    const ConvK &a = c.a;
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.wq), 0, c.wq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+    const int apix0[2] = {(2 * wave) * SW_WT + li, (2 * wave + 1) * SW_WT + li};
+
+    for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+        // (cb innermost: the ncb workgroups of a pixel tile run side by side and share its input in L2)
+        const int cb = tile % c.ncb;
+        int rest = tile / c.ncb;
+        const int tx = rest % c.tiles_x;
+        rest /= c.tiles_x;
+        const int ty = rest % c.tiles_y, n = rest / c.tiles_y;
+        const int ty0 = ty * SW_TH, tx0 = tx * SW_TW;
+        int in_off[S4_A_IT], a_dst[S4_A_IT];
+#pragma unroll
+        for (int it = 0; it < S4_A_IT; ++it) {
+            const int i = tid + it * 256, row = i >> 2, q = i & 3;
+            const int hr = row / SW_WT, hc = row - hr * SW_WT;
+            const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            const bool in = (row < SW_A_ROWS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            in_off[it] = in ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+            a_dst[it] = row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
+        }
+        f32x4 rin[S4_A_IT];
+        auto a_load = [&](int ch, bool valid) __attribute__((always_inline)) {     // on every path (past-the-end addresses read zeros)
+#pragma unroll
+            for (int it = 0; it < S4_A_IT; ++it) {
+                const unsigned bo = (valid && in_off[it] >= 0) ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;
+                rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
+            }
+        };
+        tnr_bf16x4 ih, im, il;
+        f32x4 ir;
+        auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {      // (conv_sweep4_kernel: five steps per item)
+            constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
+            if constexpr (k == 0) {
+                ih = __builtin_convertvector(rin[it], tnr_bf16x4);
+                ir = rin[it] - __builtin_convertvector(ih, f32x4);
+            } else if constexpr (k == 1) {
+                im = __builtin_convertvector(ir, tnr_bf16x4);
+                ir = ir - __builtin_convertvector(im, f32x4);
+            } else {
+                if constexpr (k == 2) il = __builtin_convertvector(ir, tnr_bf16x4);
+                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
+                *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
+            }
+        };
+        f32x16 acc[2][SW_NTILE];         // (only N-tiles 0 and 1 are ever touched: the rest is never materialised)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+        a_load(0, true);
+        __syncthreads();                 // the previous tile's last fragments are consumed
+        tnr_bf16x8 fbr[3][3];
+        int bq = cb * c.nck * 18;        // this channel block's part of the stream
+        auto b_fetch = [&](auto rc, int sp) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            fbr[r][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (bq * 3 + sp) * 1024, 0));
+            if (sp == 2) ++bq;
+        };
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 0>{}, sp);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 1>{}, sp);
+        sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) {
+            sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, 0); });
+        });
+        bool has_next = false;
+        int e = 0;
+        auto item_step = [&](auto ic, auto kc) __attribute__((always_inline)) {
+            if (has_next) item_step_buf(ic, kc, (e + 1) & 1);
+        };
+        auto nop1 = [&](auto) __attribute__((always_inline)) {};
+        auto nop0 = [&]() __attribute__((always_inline)) {};
+        auto tick = [&](int, unsigned long long) __attribute__((always_inline)) {};
+#pragma unroll 1
+        for (int ck = 0; ck < c.nck; ++ck) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the chunk's input tile is in LDS; the other buffer is consumed
+            has_next = ck + 1 < c.nck;
+            a_load(16 * (ck + 1), has_next);
+            sweep4_chunk<0, 2, true>(acc, s_a + (e & 1) * SW_A_FLOATS, nullptr, apix0, half, nop1, item_step, nop0, tick, fbr, b_fetch);
+            ++e;
+        }
+        f32x16 t[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            t[m][0] = acc[m][0];
+            t[m][1] = acc[m][1];
+        }
+        // (two workgroups per CU: the other one's MFMAs cover this epilogue's load latency -- one unit of look-ahead keeps it in 256 registers)
+        conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 2, false, (OCC == 1 ? 8 : 1)>(a, t, cb, n, ty0, tx0, 0, wave, li, half, y_rs);
+    }
+}
+
+bool d4_ok(const tnr_conv_desc *d) {
+    return d->mode == TNR_CONV_3x3 && d->mma == TNR_MMA_BF16X3 && d->pad_mode == 0 && (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
+           d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && d->Ho == d->H && d->Wo == d->W && d->W >= 32 && d->H >= 8 &&
+           (int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->H * d->W * d->y.ctot < (1LL << 30) &&
+           (int64_t)(d->Cout / 64) * (d->Cin / 16) * 18 * SW_UNIT_FLOATS * (int64_t)sizeof(float) < (1LL << 31);
+}
+
 // Do the stages form a dense block the sweep kernel covers?  (5 stages over ONE input buffer, stage k reading channels [0, nf + 32 k)
 // and -- except the last -- writing the next 32 channels of that buffer; 32, 32, 32, 32, 64 output channels)
 bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
@@ -1063,4 +1217,65 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     else if (form == 4) hipLaunchKernelGGL(conv_sweep4_kernel<false>, dim3((unsigned)grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, c);
     else hipLaunchKernelGGL(conv_sweep4_kernel<true>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     return tnr_check_launch("conv_sweep");
+}
+
+extern "C" int64_t tnr_conv_wq_bytes(const tnr_conv_desc *d) {
+    if (d == nullptr || !d4_ok(d)) return 0;
+    return (int64_t)(d->Cout / 64) * (d->Cin / 16) * 18 * SW_UNIT_FLOATS * (int64_t)sizeof(float);
+}
+
+extern "C" int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t image_bytes, void *stream) {
+    TNR_REQUIRE(d != nullptr && image != nullptr && d->wp != nullptr && d4_ok(d), "conv_wq_pack: the launch cannot use a pre-split weight stream");
+    D4PackK a;
+    a.wp = d->wp; a.KinP = d->KinP; a.KoutP = d->KoutP; a.nck = d->Cin / 16; a.ncb = d->Cout / 64;
+    a.units = a.ncb * a.nck * 18;
+    TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_wq_pack: image buffer too small");
+    a.out = static_cast<float *>(image);
+    hipLaunchKernelGGL(d4_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return tnr_check_launch("conv_wq_pack");
+}
+
+// called by tnr_conv_forward (conv_tile.hip) for a launch that carries a pre-split weight stream; 1: not for this kernel
+int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
+    if (!d4_ok(d) || d->wq == nullptr || d->wq_bytes < tnr_conv_wq_bytes(d) || d->noise_pos < 0 || d->noise_pos > 2) return 1;
+    static int occ = [] { const char *e = getenv("TNR_D4_OCC"); return e ? atoi(e) : 2; }();
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
+            cus = 0;
+            tnr_set_error("conv3x3_d4: cannot set up the kernel");
+            return TNR_ELAUNCH;
+        }
+    }
+    D4K c;
+    ConvK &k = c.a;
+    k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+    k.wp = d->wp; k.KinP = d->KinP; k.KoutP = d->KoutP;
+    k.y = d->y.ptr; k.y_ct = d->y.ctot; k.y_co = d->y.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.bias = d->bias; k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+    k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
+    k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
+    k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+    k.noise_pos = d->noise_pos; k.noise_sigma = d->noise_sigma; k.noise_k0 = d->noise_key0; k.noise_k1 = d->noise_key1; k.noise_pix0 = d->noise_pix0;
+    k.th_space = d->Ho; k.tw_space = d->Wo;
+    k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = 0;
+    c.wq = static_cast<const float *>(d->wq);
+    c.wq_bytes = (int)tnr_conv_wq_bytes(d);
+    c.nck = d->Cin / 16;
+    c.tiles_x = tnr_cdiv(d->Wo, SW_TW);
+    c.tiles_y = tnr_cdiv(d->Ho, SW_TH);
+    c.ncb = d->Cout / 64;
+    const int64_t tiles = (int64_t)c.tiles_x * c.tiles_y * c.ncb * d->N;
+    if (tiles >= (1LL << 31)) return 1;
+    c.tiles = (int)tiles;
+    k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = c.ncb;
+    const int slots = cus * (occ == 1 ? 1 : 2);
+    const int grid = c.tiles < slots ? c.tiles : slots;
+    if (occ == 1) hipLaunchKernelGGL(conv3x3_d4_kernel<1>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    else hipLaunchKernelGGL(conv3x3_d4_kernel<2>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    return tnr_check_launch("conv3x3_d4");
 }

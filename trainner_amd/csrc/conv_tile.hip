@@ -152,6 +152,8 @@ int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
 
 }  // namespace
 
+int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream);      // conv_sweep.hip (1: not for that kernel)
+
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
     TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_3x3_C4, "conv: bad mode %d", d->mode);
@@ -238,6 +240,13 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
         tiles *= ksplit;
     }
     int rc;
+    if (d->wq != nullptr && k.ksplit == 1) {       // pre-split weight stream: the direct four-wave kernel (conv_sweep.hip), when the launch qualifies
+        static const bool d4 = [] { const char *e = std::getenv("TNR_X3_D4"); return e == nullptr || e[0] != '0'; }();
+        if (d4) {
+            rc = tnr_launch_conv3x3_d4(d, (void *)s);
+            if (rc <= 0) return rc;
+        }
+    }
     {   // TNR_MMA_BF16X3, 64-cout 3x3 layers: the 8-wave kernel with both operands pre-split in LDS (conv_x3w8.h; TNR_X3_W8=0: off)
         static const bool w8 = [] { const char *e = std::getenv("TNR_X3_W8"); return e == nullptr || e[0] != '0'; }();
         if (w8 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_x3w8_ok(k)) return launch_conv3x3_x3w8(k, s);

@@ -116,6 +116,7 @@ class WeightPacker:
 
     def _finalize(self):
         self.__dict__.pop("_sweep_images", None)       # derived layouts of the old slabs
+        self.__dict__.pop("_wq_images", None)
         total = sum(round_up(j[4], 64) for j in self.jobs)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
         items = (PackItem * len(self.jobs))()
@@ -311,6 +312,28 @@ IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel f
 SMALL_GEMM = os.environ.get("TNR_SMALL_GEMM", "1") != "0"   # im2col + split-K GEMM for <= 4096-pixel layers (A/B switch)
 
 
+X3_D4 = os.environ.get("TNR_X3_D4", "1") != "0"      # TNR_MMA=bf16x3: 64-cout 3x3 layers take their weights as a pre-split stream (A/B switch)
+_wq_oneoff = {}
+
+
+def _wq_image(lib, d, wp, dev):
+    """The pre-split weight stream of a launch (tnr_conv_desc.wq; None: the launch cannot use one).  Kept on the packer that owns the
+    packed weights and rebuilt (one small launch) when that packer has run since -- once per optimiser step, once ever for the VGG."""
+    need = lib.tnr_conv_wq_bytes(C.byref(d))
+    if need <= 0:
+        return None
+    owner = wp.owner
+    cache, gen = (_wq_oneoff, None) if owner is None else (owner.__dict__.setdefault("_wq_images", {}), owner.gen)
+    key = wp.t.data_ptr()
+    ent = cache.get(key)
+    if ent is None or ent[0].numel() * 4 < need:
+        ent = cache[key] = [torch.empty(need // 4, dtype=torch.float32, device=dev), None]
+    if gen is None or ent[1] != gen:
+        hip.check(lib.tnr_conv_wq_pack(C.byref(d), ent[0].data_ptr(), need, hip.stream()), "conv_wq_pack")
+        ent[1] = gen
+    return ent[0]
+
+
 def conv(x, wp, y, mode=CONV_3x3, **epi):
     d = ConvDesc()
     _conv_desc(d, x, wp, y, mode, **epi)
@@ -319,6 +342,10 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
         if need > 0:
             ws = WS.get("splitk@%x" % hip.stream(), need, x.buf.device)
             d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
+    if X3_D4 and mode == CONV_3x3 and d.mma == hip.MMA_BF16X3 and not d.ws and y.C % 64 == 0:
+        img = _wq_image(hip.load(), d, wp, x.buf.device)
+        if img is not None:
+            d.wq, d.wq_bytes = img.data_ptr(), img.numel() * 4
     if PROFILE is None:
         hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
         return
