@@ -409,9 +409,11 @@ int tnr_l1_mean_fwd(const float *a, const float *b, int64_t n, float scale, floa
 int tnr_l1_mean_bwd(const float *a, const float *b, int64_t n, float scale, const float *gscale,
                     float *ga, int32_t accumulate, void *stream);
 /* relativistic BCE, three phases so that the two 2-scalar sums can be all-reduced between them
- * (SURVEY.md 8(e)); sums = 8 floats on device.  stage 0 = generator, 1 = discriminator.           */
-int tnr_ragan_phase_a(const float *pf, const float *pr, int32_t n, float *sums, void *stream);
-int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, int32_t stage, float *sums, void *stream);
+ * (SURVEY.md 8(e)); sums = 8 floats on device.  stage 0 = generator, 1 = discriminator.
+ * ws: tnr_reduce_workspace_bytes() of scratch for the two-stage (fixed-order) reductions over per-pixel logit maps (n >= 4096:
+ * UNetDiscriminator); NULL or smaller n: one block reduces everything.                                                      */
+int tnr_ragan_phase_a(const float *pf, const float *pr, int32_t n, float *sums, void *ws, void *stream);
+int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, int32_t stage, float *sums, void *ws, void *stream);
 int tnr_ragan_phase_c(const float *pf, const float *pr, int32_t n, int32_t stage, float weight,
                       const float *sums, float *loss_out, float *gf, float *gr, void *stream);
 int tnr_scale_by(float *dst, const float *src, int64_t n, const float *gscale, void *stream);

@@ -709,9 +709,10 @@ def test_linear_and_losses_and_optim():
     # relativistic BCE, both stages
     from oracle import sr_oracle as O
     lib = hip.load()
-    for stage in (0, 1):
-        pf = rnd(6, 1, seed=48).requires_grad_(True)
-        pr = rnd(6, 1, seed=49).requires_grad_(True)
+    # (6 logits: the one-block kernels; 3 x 64 x 70 per-pixel logits of a U-Net discriminator: the two-stage fixed-order reductions)
+    for stage, nlog in ((0, 6), (1, 6), (0, 13440), (1, 13440)):
+        pf = rnd(nlog, 1, seed=48).requires_grad_(True)
+        pr = rnd(nlog, 1, seed=49).requires_grad_(True)
         if stage == 0:
             loss = 5e-3 * O.ragan_g_loss(pf, pr)
             gf_r, = torch.autograd.grad(loss, pf)
@@ -723,15 +724,21 @@ def test_linear_and_losses_and_optim():
         wgt = 5e-3 if stage == 0 else 1.0
         pfd, prd = pf.detach().to(DEV).view(-1), pr.detach().to(DEV).view(-1)
         sums, o5 = torch.zeros(8, device=DEV), torch.zeros(5, device=DEV)
-        gf, gr = torch.zeros(6, device=DEV), torch.zeros(6, device=DEV)
+        gf, gr = torch.zeros(nlog, device=DEV), torch.zeros(nlog, device=DEV)
         s = hip.stream()
-        hip.check(lib.tnr_ragan_phase_a(pfd.data_ptr(), prd.data_ptr(), 6, sums.data_ptr(), s))
-        hip.check(lib.tnr_ragan_phase_b(pfd.data_ptr(), prd.data_ptr(), 6, stage, sums.data_ptr(), s))
-        hip.check(lib.tnr_ragan_phase_c(pfd.data_ptr(), prd.data_ptr(), 6, stage, wgt, sums.data_ptr(), o5.data_ptr(),
+        ws = torch.zeros(lib.tnr_reduce_workspace_bytes() // 8, dtype=torch.float64, device=DEV)
+        hip.check(lib.tnr_ragan_phase_a(pfd.data_ptr(), prd.data_ptr(), nlog, sums.data_ptr(), ws.data_ptr(), s))
+        hip.check(lib.tnr_ragan_phase_b(pfd.data_ptr(), prd.data_ptr(), nlog, stage, sums.data_ptr(), ws.data_ptr(), s))
+        hip.check(lib.tnr_ragan_phase_c(pfd.data_ptr(), prd.data_ptr(), nlog, stage, wgt, sums.data_ptr(), o5.data_ptr(),
                                         gf.data_ptr(), gr.data_ptr(), s))
         assert abs(float(o5[0]) - float(loss)) < 1e-6, (stage, float(o5[0]), float(loss))
-        close(gf.cpu().view(6, 1), gf_r, tol=1e-6, what="ragan gf")
-        close(gr.cpu().view(6, 1), gr_r, tol=1e-6, what="ragan gr")
+        close(gf.cpu().view(nlog, 1), gf_r, tol=1e-6, what="ragan gf")
+        close(gr.cpu().view(nlog, 1), gr_r, tol=1e-6, what="ragan gr")
+        if nlog > 4096:       # without scratch: the one-block kernels, the same numbers
+            sums1, o51 = torch.zeros(8, device=DEV), torch.zeros(5, device=DEV)
+            hip.check(lib.tnr_ragan_phase_a(pfd.data_ptr(), prd.data_ptr(), nlog, sums1.data_ptr(), None, s))
+            hip.check(lib.tnr_ragan_phase_b(pfd.data_ptr(), prd.data_ptr(), nlog, stage, sums1.data_ptr(), None, s))
+            assert (sums1 - sums).abs().max().item() <= 1e-6 * sums.abs().max().item()
     # clip + Adam against torch
     n = 10000
     p0, g0 = rnd(n, seed=50), rnd(n, seed=51) * 0.01

@@ -392,6 +392,106 @@ __global__ void ragan_b_kernel(const float *pf, const float *pr, int n, int stag
     }
 }
 
+// Per-pixel logit maps (UNetDiscriminator, discriminators.py:686-779: n = N x H x W = 4.2 M at batch 16, 512 x 512): the same three
+// phases as a two-stage reduction in a FIXED order -- up to 256 blocks write their double partial sums to ws, one block adds them in
+// index order -- and an elementwise gradient pass over the whole grid.  (The single-block forms above took 6.8 + 12.6 + 8.1 ms per call
+// there: 19 % of the Real-ESRGAN step, profiles/r04k_*.)
+constexpr int RAGAN_MULTI_MIN = 4096;       // below: the single-block kernels (bit-for-bit what they always computed)
+
+__global__ void ragan_a_partial_kernel(const float *pf, const float *pr, int n, double *ws) {
+    __shared__ double sh[256];
+    double sf = 0, sr = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        sf += pf[i];
+        sr += pr[i];
+    }
+    sf = block_reduce_sum(sf, sh);
+    sr = block_reduce_sum(sr, sh);
+    if (threadIdx.x == 0) {
+        ws[2 * blockIdx.x] = sf;
+        ws[2 * blockIdx.x + 1] = sr;
+    }
+}
+
+__global__ void ragan_a_final_kernel(const double *ws, int nb, int n, float *sums) {
+    if (threadIdx.x == 0) {
+        double sf = 0, sr = 0;
+        for (int b = 0; b < nb; ++b) {
+            sf += ws[2 * b];
+            sr += ws[2 * b + 1];
+        }
+        sums[0] = (float)sf;
+        sums[1] = (float)sr;
+        sums[2] = (float)n;
+        sums[3] = sums[4] = sums[5] = sums[6] = sums[7] = 0.f;
+    }
+}
+
+__global__ void ragan_b_partial_kernel(const float *pf, const float *pr, int n, int stage, const float *sums, double *ws) {
+    __shared__ double sh[256];
+    const float mf = sums[0] / sums[2], mr = sums[1] / sums[2];
+    double t1 = 0, t2 = 0, sa = 0, sb = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float dr = pr[i] - mf, df = pf[i] - mr;
+        if (stage == 0) {
+            t1 += softplusf(dr);
+            t2 += softplusf(-df);
+            sa += sigmoidf(dr);
+        } else {
+            t1 += softplusf(-dr);
+            t2 += softplusf(df);
+            sa += sigmoidf(-dr);
+            sb += sigmoidf(df);
+        }
+    }
+    t1 = block_reduce_sum(t1, sh);
+    t2 = block_reduce_sum(t2, sh);
+    sa = block_reduce_sum(sa, sh);
+    sb = block_reduce_sum(sb, sh);
+    if (threadIdx.x == 0) {
+        double *w = ws + 4 * blockIdx.x;
+        w[0] = t1; w[1] = t2; w[2] = sa; w[3] = sb;
+    }
+}
+
+__global__ void ragan_b_final_kernel(const double *ws, int nb, float *sums) {
+    if (threadIdx.x == 0) {
+        double t[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < 4; ++k) t[k] += ws[4 * b + k];
+        sums[3] = (float)t[0];
+        sums[4] = (float)t[1];
+        sums[5] = (float)t[2];
+        sums[6] = (float)t[3];
+    }
+}
+
+__global__ void ragan_c_grid_kernel(const float *pf, const float *pr, int n, int stage, float weight, const float *sums,
+                                    float *loss_out, float *gf, float *gr) {
+    const float NN = sums[2];
+    const float mf = sums[0] / NN, mr = sums[1] / NN;
+    const float l1 = sums[3] / NN, l2 = sums[4] / NN;
+    const float sa = sums[5], sb = sums[6];
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        loss_out[0] = weight * ((l1 + l2) * 0.5f);
+        loss_out[1] = l1;
+        loss_out[2] = l2;
+        loss_out[3] = mr;
+        loss_out[4] = mf;
+    }
+    const float k = weight * 0.5f / NN;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float dr = pr[i] - mf, df = pf[i] - mr;
+        if (stage == 0) {
+            if (gf) gf[i] = k * (-(sa / NN) - sigmoidf(-df));
+            if (gr) gr[i] = 0.f;
+        } else {
+            if (gf) gf[i] = k * (sigmoidf(df) + sa / NN);
+            if (gr) gr[i] = k * (-sigmoidf(-dr) - sb / NN);
+        }
+    }
+}
+
 // loss_out: [0] weight * (l1 + l2)/2, [1] l1 (real-side term), [2] l2 (fake-side term), [3] mean r, [4] mean f
 __global__ void ragan_c_kernel(const float *pf, const float *pr, int n, int stage, float weight, const float *sums,
                                float *loss_out, float *gf, float *gr) {
@@ -640,14 +740,26 @@ extern "C" int tnr_l1_mean_bwd(const float *a, const float *b, int64_t n, float 
     return tnr_check_launch("l1_mean_bwd");
 }
 
-extern "C" int tnr_ragan_phase_a(const float *pf, const float *pr, int32_t n, float *sums, void *stream) {
+extern "C" int tnr_ragan_phase_a(const float *pf, const float *pr, int32_t n, float *sums, void *ws, void *stream) {
     TNR_REQUIRE(pf && pr && sums && n > 0, "ragan_a: bad arguments");
+    if (n >= RAGAN_MULTI_MIN && ws != nullptr) {
+        const int nb = n / 4096 > 256 ? 256 : (n / 4096 < 1 ? 1 : n / 4096);
+        hipLaunchKernelGGL(ragan_a_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pf, pr, n, (double *)ws);
+        hipLaunchKernelGGL(ragan_a_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)ws, nb, n, sums);
+        return tnr_check_launch("ragan_a");
+    }
     hipLaunchKernelGGL(ragan_a_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pf, pr, n, sums);
     return tnr_check_launch("ragan_a");
 }
 
-extern "C" int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, int32_t stage, float *sums, void *stream) {
+extern "C" int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, int32_t stage, float *sums, void *ws, void *stream) {
     TNR_REQUIRE(pf && pr && sums && n > 0, "ragan_b: bad arguments");
+    if (n >= RAGAN_MULTI_MIN && ws != nullptr) {
+        const int nb = n / 4096 > 256 ? 256 : (n / 4096 < 1 ? 1 : n / 4096);
+        hipLaunchKernelGGL(ragan_b_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pf, pr, n, stage, (const float *)sums, (double *)ws);
+        hipLaunchKernelGGL(ragan_b_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)ws, nb, sums);
+        return tnr_check_launch("ragan_b");
+    }
     hipLaunchKernelGGL(ragan_b_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pf, pr, n, stage, sums);
     return tnr_check_launch("ragan_b");
 }
@@ -655,6 +767,10 @@ extern "C" int tnr_ragan_phase_b(const float *pf, const float *pr, int32_t n, in
 extern "C" int tnr_ragan_phase_c(const float *pf, const float *pr, int32_t n, int32_t stage, float weight, const float *sums,
                                  float *loss_out, float *gf, float *gr, void *stream) {
     TNR_REQUIRE(pf && pr && sums && loss_out && n > 0, "ragan_c: bad arguments");
+    if (n >= RAGAN_MULTI_MIN) {
+        hipLaunchKernelGGL(ragan_c_grid_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pf, pr, n, stage, weight, sums, loss_out, gf, gr);
+        return tnr_check_launch("ragan_c");
+    }
     hipLaunchKernelGGL(ragan_c_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pf, pr, n, stage, weight, sums, loss_out, gf,
                        gr);
     return tnr_check_launch("ragan_c");

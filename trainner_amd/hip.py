@@ -144,8 +144,8 @@ _SIGS = {
     "tnr_reduce_workspace_bytes": (c_l, []),
     "tnr_l1_mean_fwd": (c_i, [c_p, c_p, c_l, c_f, c_p, c_p, c_p]),
     "tnr_l1_mean_bwd": (c_i, [c_p, c_p, c_l, c_f, c_p, c_p, c_i, c_p]),
-    "tnr_ragan_phase_a": (c_i, [c_p, c_p, c_i, c_p, c_p]),
-    "tnr_ragan_phase_b": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p]),
+    "tnr_ragan_phase_a": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p]),
+    "tnr_ragan_phase_b": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "tnr_ragan_phase_c": (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     "tnr_scale_by": (c_i, [c_p, c_p, c_l, c_p, c_p]),
     "tnr_sumsq": (c_i, [c_p, c_l, c_p, c_p, c_p]),

@@ -801,12 +801,16 @@ def l1_mean_bwd(a, b, scale, gscale, ga, accumulate=False):
                                          int(accumulate), hip.stream()), "l1_mean_bwd")
 
 
+def _reduce_ws(dev):
+    return WS.get("reduce@%x" % hip.stream(), hip.load().tnr_reduce_workspace_bytes(), dev)
+
+
 def ragan_phase_a(pf, pr, sums):
-    hip.check(hip.load().tnr_ragan_phase_a(pf.data_ptr(), pr.data_ptr(), pf.numel(), sums.data_ptr(), hip.stream()), "ragan_a")
+    hip.check(hip.load().tnr_ragan_phase_a(pf.data_ptr(), pr.data_ptr(), pf.numel(), sums.data_ptr(), _reduce_ws(pf.device).data_ptr(), hip.stream()), "ragan_a")
 
 
 def ragan_phase_b(pf, pr, stage, sums):
-    hip.check(hip.load().tnr_ragan_phase_b(pf.data_ptr(), pr.data_ptr(), pf.numel(), stage, sums.data_ptr(), hip.stream()),
+    hip.check(hip.load().tnr_ragan_phase_b(pf.data_ptr(), pr.data_ptr(), pf.numel(), stage, sums.data_ptr(), _reduce_ws(pf.device).data_ptr(), hip.stream()),
               "ragan_b")
 
 
