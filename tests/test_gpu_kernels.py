@@ -329,6 +329,44 @@ def test_conv3x3_weight_stream_kernel_equals_staged_weights(case):
     assert torch.equal(half, run(False)) and not torch.equal(half, ref)
 
 
+@pytest.mark.parametrize("grad_shape", [False, True])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 40, 72), (5, 64, 96)])
+def test_amp_dense_block_sweep_agrees_with_per_layer(shape, grad_shape, monkeypatch):
+    """`use_amp` (TNR_MMA_BF16: operands rounded to bf16, fp32 accumulate): the dense block through the sweep's bf16-operand form
+    (conv_sweep4_kernel<true, true>: plane 0 of the weight stream and of the input tile, units of 2 MFMAs, nine-deep fragment ring)
+    against five per-layer launches.  Same rounded operands; the 16 products of an MFMA are summed in another order, so the first
+    stage agrees to 2e-6 of the scale and the later ones to bf16 resolution (an activation within 5e-7 of a rounding boundary rounds
+    the other way: one bf16 ulp of ONE input, a 3 x 3 patch of ~2e-4).  Deterministic: two runs are bit-identical."""
+    ops = _ops()
+    from trainner_amd import hip
+    from tools.probes.sweep_check import block
+    monkeypatch.setattr(ops, "MMA", hip.MMA_BF16)
+    run = block(*shape, seed=35, grad_shape=grad_shape, with_r2=(shape[0] % 2 == 1))
+    rb, ro, _ = run("layers")
+    gb, go, _ = run("sweep")
+    sc = max(float(rb.abs().max()), float(ro.abs().max()), 1.0)
+    assert float((gb[..., 64:96] - rb[..., 64:96]).abs().max()) <= 2e-6 * sc
+    assert float((gb - rb).abs().max()) <= 4e-3 * sc and float((go - ro).abs().max()) <= 4e-3 * sc
+    assert float((gb - rb).abs().mean()) <= 2e-5 * sc
+    g2, o2, _ = run("sweep")
+    assert torch.equal(g2, gb) and torch.equal(o2, go) and ops.chain_error_flag() == 0
+
+
+@pytest.mark.parametrize("case", [(2, 40, 72, 64, 64, "lrelu", False), (3, 17, 33, 128, 128, "res", False), (2, 64, 64, 256, 256, "mask", True),
+                                  (1, 9, 45, 96, 192, "res", False)])
+def test_amp_conv3x3_weight_stream_kernel(case, monkeypatch):
+    """TNR_MMA_BF16: conv3x3_d4_kernel<2, true> (bf16-operand form of the weight-stream kernel) against conv_tile_body<BF = 1>: one layer,
+    the same rounded operands -> agreement to fp32 summation order (2e-5 of the scale)."""
+    ops = _ops()
+    from trainner_amd import hip
+    from tools.probes.d4_check import layer
+    monkeypatch.setattr(ops, "MMA", hip.MMA_BF16)
+    N, H, W, Cin, Cout, epi, dg = case
+    run, packer, _ = layer(N, H, W, Cin, Cout, 78, epi, dg)
+    ref, got = run(False), run(True)
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())) and len(packer.__dict__.get("_wq_images", {})) == 1
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # ESRGAN+ GaussianNoise (block.py:587-600): the counter-based multiplier field of csrc/gauss_noise.h
 # ------------------------------------------------------------------------------------------------------------------------

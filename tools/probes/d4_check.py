@@ -38,7 +38,10 @@ def layer(N, H, W, Cin, Cout, seed, epi="plain", dgrad=False):
 
 
 def main():
-    assert ops.MMA == hip.MMA_BF16X3
+    amp = "--amp" in sys.argv           # TNR_MMA_BF16 (use_amp): the kernel's bf16-operand form against conv_tile_body<BF = 1> -- agreement, not equality
+    if amp:
+        ops.MMA = hip.MMA_BF16
+    assert ops.MMA == (hip.MMA_BF16 if amp else hip.MMA_BF16X3)
     ok = True
     if "--time-only" not in sys.argv:
         cases = [(2, 40, 72, 64, 64, "lrelu", False), (1, 8, 32, 32, 64, "plain", False), (3, 17, 33, 128, 128, "res", False), (2, 64, 64, 256, 256, "mask", True),
@@ -48,7 +51,7 @@ def main():
             ref = run(False)
             for rep in range(2):
                 got = run(True)
-                same = bool(torch.equal(got, ref))
+                same = bool(torch.equal(got, ref)) if not amp else float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
                 ok &= same
                 if not same:
                     d = (got - ref).abs()

@@ -64,7 +64,42 @@ def block(N, H, W, seed, grad_shape, with_r2=True, noise=None):
     return run
 
 
+def main_amp():
+    """--amp: TNR_MMA_BF16 (operands rounded to bf16).  The sweep's bf16-operand form against tnr_conv_chain and per-layer launches: the
+    same rounded operands and fp32 accumulation, another order of the 16 products inside an MFMA.  The first stage therefore agrees to
+    ~5e-7; downstream, an activation within that distance of a bf16 rounding boundary rounds the other way (one bf16 ulp = 2^-8 of its
+    value, seen as a 3 x 3 patch of ~2e-4 in the next stage: tools/probes/amp_dbg.py) -- every form is a valid bf16-operand evaluation,
+    they agree to bf16 resolution (4e-3 of the scale), and each is deterministic."""
+    ops.MMA = hip.MMA_BF16
+    ok = True
+    for shape in [(4, 16, 16), (1, 16, 32), (2, 40, 72), (1, 8, 32), (1, 10, 20), (3, 128, 128), (20, 128, 128), (5, 64, 96)]:
+        for grad_shape in (False, True):
+            run = block(*shape, seed=11, grad_shape=grad_shape, with_r2=(shape[0] % 2 == 1), noise=(ops.Noise(0.1, ops.noise_key(1, 2, 3)) if shape[0] == 5 else None))
+            rb, ro, _ = run("layers")
+            for how in ("chain", "sweep"):
+                gb, go, _ = run(how)
+                eb, eo = float((gb - rb).abs().max()), float((go - ro).abs().max())
+                sc = max(float(rb.abs().max()), float(ro.abs().max()), 1.0)
+                first = float((gb[..., nf:nf + gc] - rb[..., nf:nf + gc]).abs().max())
+                good = eb <= 4e-3 * sc and eo <= 4e-3 * sc and first <= 2e-6 * sc
+                ok &= good
+                print(shape, "grad" if grad_shape else "fwd", how, "max|d| buf %.2e out %.2e (scale %.2f)%s" % (eb, eo, sc, "" if good else "  <-- MISMATCH"), flush=True)
+    print("AMP AGREEMENT", "OK" if ok else "FAILED", "; chain error flag", ops.chain_error_flag())
+    N, H, W = 16, 128, 128
+    fl = sum(2.0 * N * H * W * 9 * ci * co for ci, co in [(nf + k * gc, gc) for k in range(4)] + [(nf + 4 * gc, nf)])
+    for grad_shape in (False, True):
+        run = block(N, H, W, seed=5, grad_shape=grad_shape)
+        _, _, st = run("layers")
+        for how in ("chain", "sweep"):
+            ops.CONV_SWEEP = how == "sweep"
+            us = timeit(lambda: ops.conv_chain(st))
+            print("amp %-5s %-6s %8.1f us  %6.1f TFLOP/s" % ("grad" if grad_shape else "fwd", how, us, fl / us / 1e6), flush=True)
+        ops.CONV_SWEEP = True
+
+
 def main():
+    if "--amp" in sys.argv:
+        return main_amp()
     ok = True
     assert ops.MMA == hip.MMA_BF16X3
     TIME_ONLY = "--time-only" in sys.argv

@@ -588,14 +588,55 @@ __device__ __forceinline__ void sweep4_chunk(f32x16 (&acc)[2][SW_NTILE], const f
     });
 }
 
+// The same chunk in TNR_MMA_BF16 (`use_amp`: operands ROUNDED to bf16, base_model.py:736-744): one product per (tap, N-tile, M-tile), so a
+// unit is 2 MFMAs (64 cycles of matrix core) and only plane 0 of either operand is used -- the weight stream's hi plane IS the
+// round-to-nearest bf16 weight, the input tile's hi plane the rounded activation (the stager skips the other two).  With units this
+// short the fragment ring is nine deep (unit g + 8 is fetched behind the first MFMA of unit g: ~500 cycles of look-ahead, an L2 hit),
+// one whole input-chunk item (convert + one 8-byte LDS store) rides behind the second MFMA of the chunk's last units.
+template <int J0, int NJ, class Item, class BFetch>
+__device__ __forceinline__ void amp4_chunk(f32x16 (&acc)[2][SW_NTILE], const float *sa, const int (&apix0)[2], const int half,
+                                           Item &&item, tnr_bf16x8 (&fbq)[9], BFetch &&b_fetch) {
+    constexpr int NU = 9 * NJ;
+    static_assert(NU % 9 == 0, "a chunk starts at ring position 0");
+    tnr_bf16x8 fa[2][2];               // [tap parity][M-tile]
+    const float *a_src[2][2];
+    auto addr_a = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, dy = t / 3, dx = t % 3;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int pp = apix0[m] + dy * SW_WT + dx;
+            a_src[t & 1][m] = sa + pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
+        }
+    };
+    addr_a(std::integral_constant<int, 0>{});
+    fa[0][0] = *reinterpret_cast<const tnr_bf16x8 *>(a_src[0][0]);
+    fa[0][1] = *reinterpret_cast<const tnr_bf16x8 *>(a_src[0][1]);
+    sw_static_for<0, NU>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, t = u / NJ, jj = u % NJ;
+        constexpr bool NEXT_TAP = u + 1 < NU && (u + 1) % NJ == 0;
+        constexpr int ITEM = u - (NU - S4_A_IT);               // the chunk's last six units carry the next chunk's six items
+        if constexpr (NEXT_TAP) addr_a(std::integral_constant<int, (t + 1 < 9 ? t + 1 : 8)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][0], fbq[u % 9], acc[0][J0 + jj], 0, 0, 0);
+        b_fetch(std::integral_constant<int, (u + 8) % 9>{});
+        if constexpr (NEXT_TAP) fa[(t + 1) & 1][0] = *reinterpret_cast<const tnr_bf16x8 *>(a_src[(t + 1) & 1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][J0 + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][1], fbq[u % 9], acc[1][J0 + jj], 0, 0, 0);
+        if constexpr (NEXT_TAP) fa[(t + 1) & 1][1] = *reinterpret_cast<const tnr_bf16x8 *>(a_src[(t + 1) & 1][1]);
+        if constexpr (ITEM >= 0 && ITEM < S4_A_IT) item(std::integral_constant<int, (ITEM >= 0 && ITEM < S4_A_IT ? ITEM : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 #ifndef S4D_EPI_AFTER
 #define S4D_EPI_AFTER 1       /* direct form: a stage's epilogue behind its pass's chunk loop (0: under `ck == 0` at the top of the next pass) */
 #endif
 #ifndef S4D_ALOAD_ALWAYS
 #define S4D_ALOAD_ALWAYS 1    /* direct form: the next chunk's input loads on every path (0: only when there is a next chunk) */
 #endif
-template <bool DIRECT>
+template <bool DIRECT, bool AMP = false>
 __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
+    static_assert(DIRECT || !AMP, "the bf16-operand form exists as a direct form only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_a = smem, *s_b = smem + 2 * SW_A_FLOATS;
     const int tid = threadIdx.x;
@@ -725,7 +766,22 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
             fbr[r][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (bq * 3 + sp) * 1024, 0));      // (past the end of the stream: zeros)
             if (sp == 2) ++bq;
         };
-        if constexpr (DIRECT) {
+        // bf16-operand form: nine single-plane fragments (plane 0 of unit `bq`), units 0 .. 7 go out now
+        tnr_bf16x8 fbq[9];
+        auto b_fetch1 = [&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            fbq[r] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, bq * 3072, 0));
+            ++bq;
+        };
+        auto a_item1 = [&](auto ic, int buf) __attribute__((always_inline)) {      // a whole item: round to bf16, store plane 0
+            constexpr int it = decltype(ic)::value;
+            const tnr_bf16x4 h = __builtin_convertvector(rin[it], tnr_bf16x4);
+            *reinterpret_cast<tnr_f32x2 *>(s_a + buf * SW_A_FLOATS + a_dst[it]) = __builtin_bit_cast(tnr_f32x2, h);
+        };
+        if constexpr (AMP) {
+            sw_static_for<0, 8>([&](auto rc) __attribute__((always_inline)) { b_fetch1(rc); });
+            sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_item1(ic, 0); });
+        } else if constexpr (DIRECT) {
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 0>{}, sp);
 #pragma unroll
@@ -734,7 +790,7 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
             b_issue(ld, 0);
             cur_advance(ld);
         }
-        sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_store_item(ic, 0); });
+        if constexpr (!AMP) sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_store_item(ic, 0); });
         { SW_T(t_pro); SW_ADD(0, t_pro - t_tile0); }
         int e = 0;                       // input chunks consumed so far in this tile
         bool has_next = false;
@@ -881,7 +937,14 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                 }
                 const float *sa = s_a + (e & 1) * SW_A_FLOATS;
                 SW_T(t_c0);
-                sweep4_chunk<sw_j0(p), sw_nj(p), DIRECT>(acc, sa, s_b_lane, apix0, half, sync, item_step, dma_step, tick, fbr, b_fetch);
+                if constexpr (AMP) {
+                    auto item1 = [&](auto ic) __attribute__((always_inline)) {
+                        if (has_next) a_item1(ic, (e + 1) & 1);
+                    };
+                    amp4_chunk<sw_j0(p), sw_nj(p)>(acc, sa, apix0, half, item1, fbq, b_fetch1);
+                } else {
+                    sweep4_chunk<sw_j0(p), sw_nj(p), DIRECT>(acc, sa, s_b_lane, apix0, half, sync, item_step, dma_step, tick, fbr, b_fetch);
+                }
                 { SW_T(t_c1); SW_ADD(6, t_c1 - t_c0); SW_ADD(15, 1ull); SW_ADD(9 + (sw_nj(p) == 3 ? 0 : (sw_nj(p) == 2 ? 1 : 2)), t_c1 - t_c0); }
                 ++e;
             }
@@ -952,7 +1015,7 @@ __global__ void __launch_bounds__(256) d4_pack_kernel(const D4PackK a) {
     for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + k * 256) = pl[k];
 }
 
-template <int OCC>
+template <int OCC, bool AMP = false>
 __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_a = smem;
@@ -1025,13 +1088,29 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
             fbr[r][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (bq * 3 + sp) * 1024, 0));
             if (sp == 2) ++bq;
         };
+        tnr_bf16x8 fbq[9];               // bf16-operand form (TNR_MMA_BF16): nine single-plane fragments, see amp4_chunk
+        auto b_fetch1 = [&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            fbq[r] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, bq * 3072, 0));
+            ++bq;
+        };
+        auto a_item1 = [&](auto ic, int buf) __attribute__((always_inline)) {
+            constexpr int it = decltype(ic)::value;
+            const tnr_bf16x4 h = __builtin_convertvector(rin[it], tnr_bf16x4);
+            *reinterpret_cast<tnr_f32x2 *>(s_a + buf * SW_A_FLOATS + a_dst[it]) = __builtin_bit_cast(tnr_f32x2, h);
+        };
+        if constexpr (AMP) {
+            sw_static_for<0, 8>([&](auto rc) __attribute__((always_inline)) { b_fetch1(rc); });
+            sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) { a_item1(ic, 0); });
+        } else {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 0>{}, sp);
+            for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 0>{}, sp);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 1>{}, sp);
-        sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) {
-            sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, 0); });
-        });
+            for (int sp = 0; sp < 3; ++sp) b_fetch(std::integral_constant<int, 1>{}, sp);
+            sw_static_for<0, S4_A_IT>([&](auto ic) __attribute__((always_inline)) {
+                sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, 0); });
+            });
+        }
         bool has_next = false;
         int e = 0;
         auto item_step = [&](auto ic, auto kc) __attribute__((always_inline)) {
@@ -1045,7 +1124,14 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the chunk's input tile is in LDS; the other buffer is consumed
             has_next = ck + 1 < c.nck;
             a_load(16 * (ck + 1), has_next);
-            sweep4_chunk<0, 2, true>(acc, s_a + (e & 1) * SW_A_FLOATS, nullptr, apix0, half, nop1, item_step, nop0, tick, fbr, b_fetch);
+            if constexpr (AMP) {
+                auto item1 = [&](auto ic) __attribute__((always_inline)) {
+                    if (has_next) a_item1(ic, (e + 1) & 1);
+                };
+                amp4_chunk<0, 2>(acc, s_a + (e & 1) * SW_A_FLOATS, apix0, half, item1, fbq, b_fetch1);
+            } else {
+                sweep4_chunk<0, 2, true>(acc, s_a + (e & 1) * SW_A_FLOATS, nullptr, apix0, half, nop1, item_step, nop0, tick, fbr, b_fetch);
+            }
             ++e;
         }
         f32x16 t[2][2];
@@ -1060,7 +1146,7 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
 }
 
 bool d4_ok(const tnr_conv_desc *d) {
-    return d->mode == TNR_CONV_3x3 && d->mma == TNR_MMA_BF16X3 && d->pad_mode == 0 && (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
+    return d->mode == TNR_CONV_3x3 && (d->mma == TNR_MMA_BF16X3 || d->mma == TNR_MMA_BF16) && d->pad_mode == 0 && (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
            d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && d->Ho == d->H && d->Wo == d->W && d->W >= 32 && d->H >= 8 &&
            (int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->H * d->W * d->y.ctot < (1LL << 30) &&
            (int64_t)(d->Cout / 64) * (d->Cin / 16) * 18 * SW_UNIT_FLOATS * (int64_t)sizeof(float) < (1LL << 31);
@@ -1075,7 +1161,8 @@ bool sweep_pattern(const tnr_conv_desc *st, int n, const char **why) {
     if (d0.Cin < 32 || (d0.Cin % 16) != 0) return no("block input channels must be a multiple of 16, >= 32");
     for (int i = 0; i < n; ++i) {
         const tnr_conv_desc &d = st[i];
-        if (d.mode != TNR_CONV_3x3 || d.mma != TNR_MMA_BF16X3 || d.pad_mode != 0) return no("stage is not a zero-padded 3x3 in bf16x3");
+        if (d.mode != TNR_CONV_3x3 || (d.mma != TNR_MMA_BF16X3 && d.mma != TNR_MMA_BF16) || d.mma != d0.mma || d.pad_mode != 0)
+            return no("stage is not a zero-padded 3x3 in bf16x3 (or all stages with bf16 operands)");
         if (d.N != d0.N || d.H != d0.H || d.W != d0.W || d.Ho != d0.H || d.Wo != d0.W) return no("pixel grids differ");
         if (d.x.ptr != d0.x.ptr || d.x.ctot != d0.x.ctot || d.x.coff != d0.x.coff) return no("stages read different buffers");
         if (d.Cin != d0.Cin + 32 * i || d.KinP != d.Cin) return no("input channels do not grow by 32 per stage");
@@ -1116,6 +1203,8 @@ int sweep_cus() {
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)SW_LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_sweep4_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)S4D_LDS_BYTES) != hipSuccess || cus < 1)
             cus = -1;
     }
@@ -1145,6 +1234,7 @@ extern "C" int tnr_debug_sweep_timeline(unsigned long long *out16, int reset) {
 
 extern "C" int64_t tnr_conv_sweep_image_bytes(const tnr_conv_desc *stages, int32_t n) {
     if (stages == nullptr || !sweep_pattern(stages, n, nullptr)) return 0;
+    if (stages[0].mma == TNR_MMA_BF16 && sweep_form() != 5) return 0;      // bf16 operands: the direct four-wave form only
     const int cus = sweep_cus();
     const int tpi = tnr_cdiv(stages[0].W, SW_TW) * tnr_cdiv(stages[0].H, SW_TH);
     if (cus < 1 || tpi > cus) return 0;          // an image's tiles must be co-resident (one workgroup per CU)
@@ -1213,6 +1303,11 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     const int per_round = (cus / c.tpi) * c.tpi;
     const int grid = c.tiles < per_round ? c.tiles : per_round;
     const int form = sweep_form();
+    if (stages[0].mma == TNR_MMA_BF16) {
+        TNR_REQUIRE(form == 5, "conv_sweep: bf16 operands (use_amp) run in the direct four-wave form only");
+        hipLaunchKernelGGL((conv_sweep4_kernel<true, true>), dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+        return tnr_check_launch("conv_sweep");
+    }
     if (form == 8) hipLaunchKernelGGL(conv_sweep_kernel, dim3((unsigned)grid), dim3(512), SW_LDS_BYTES, (hipStream_t)stream, c);
     else if (form == 4) hipLaunchKernelGGL(conv_sweep4_kernel<false>, dim3((unsigned)grid), dim3(256), SW_LDS_BYTES, (hipStream_t)stream, c);
     else hipLaunchKernelGGL(conv_sweep4_kernel<true>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
@@ -1244,7 +1339,8 @@ int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
             cus = 0;
             tnr_set_error("conv3x3_d4: cannot set up the kernel");
             return TNR_ELAUNCH;
@@ -1275,7 +1371,8 @@ int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
     k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = c.ncb;
     const int slots = cus * (occ == 1 ? 1 : 2);
     const int grid = c.tiles < slots ? c.tiles : slots;
-    if (occ == 1) hipLaunchKernelGGL(conv3x3_d4_kernel<1>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    if (d->mma == TNR_MMA_BF16) hipLaunchKernelGGL((conv3x3_d4_kernel<2, true>), dim3((unsigned)(c.tiles < 2 * cus ? c.tiles : 2 * cus)), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    else if (occ == 1) hipLaunchKernelGGL(conv3x3_d4_kernel<1>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     else hipLaunchKernelGGL(conv3x3_d4_kernel<2>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     return tnr_check_launch("conv3x3_d4");
 }

@@ -342,7 +342,7 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
         if need > 0:
             ws = WS.get("splitk@%x" % hip.stream(), need, x.buf.device)
             d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
-    if X3_D4 and mode == CONV_3x3 and d.mma == hip.MMA_BF16X3 and not d.ws and y.C % 64 == 0:
+    if X3_D4 and mode == CONV_3x3 and d.mma in (hip.MMA_BF16X3, hip.MMA_BF16) and not d.ws and y.C % 64 == 0:
         img = _wq_image(hip.load(), d, wp, x.buf.device)
         if img is not None:
             d.wq, d.wq_bytes = img.data_ptr(), img.numel() * 4
@@ -370,6 +370,7 @@ COLLECTIVES_IN_FLIGHT = False   # True (dp.py) from the first gradient bucket ha
 # +0.10 ms per dense-block launch (sweep 0.61 -> 0.71 ms, chain 1.01 -> 1.14 ms).  Off by default: with N > 1 ranks an RCCL kernel waits
 # for its peers while it holds CUs the launch wants all of -- never exercised on hardware here.
 CHAIN_WITH_COLLECTIVES = os.environ.get("TNR_CHAIN_WITH_COLLECTIVES", "0") == "1"
+AMP_SWEEP = os.environ.get("TNR_AMP_SWEEP", "1") != "0"      # use_amp (bf16 operands): dense blocks through the sweep's bf16-operand form (0: tnr_conv_chain; A/B switch)
 SWEEP_DISPENSED = os.environ.get("TNR_SWEEP_WAVES", "4") != "8"      # the four-wave forms take their tiles from an atomic counter (conv_sweep.hip)
 COUNTERS = {"one_launch_next_to_collectives": 0, "per_layer_next_to_collectives": 0}      # dense blocks launched while gradient buckets were in flight
 
@@ -377,7 +378,8 @@ COUNTERS = {"one_launch_next_to_collectives": 0, "per_layer_next_to_collectives"
 def dense_blocks_overlap_collectives():
     """True when the dense blocks stay one launch each next to in-flight gradient buckets in the CURRENT arithmetic (the dispensed
     sweep of TNR_MMA_BF16X3, or TNR_CHAIN_WITH_COLLECTIVES=1): the generator's all-reduce can then overlap its backward for free."""
-    return CHAIN_WITH_COLLECTIVES or (CONV_CHAIN and CONV_SWEEP and SWEEP_DISPENSED and CHAIN_X3 and MMA == hip.MMA_BF16X3)
+    return CHAIN_WITH_COLLECTIVES or (CONV_CHAIN and CONV_SWEEP and SWEEP_DISPENSED and
+                                      ((CHAIN_X3 and MMA == hip.MMA_BF16X3) or (AMP_SWEEP and MMA == hip.MMA_BF16)))
 _chain_epoch = {}
 _sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
 
@@ -418,7 +420,7 @@ def conv_chain(stages):
     # kernels on the same CUs could delay -> one launch per layer meanwhile.  The four-wave sweep DISPENSES its tiles (a waited-for
     # tile always belongs to a running workgroup; tiles_x + 2 resident workgroups are enough): it stays one launch.
     crowded = COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES
-    sweep_ok = CONV_SWEEP and n == 5 and MMA == hip.MMA_BF16X3 and CHAIN_X3
+    sweep_ok = CONV_SWEEP and n == 5 and ((MMA == hip.MMA_BF16X3 and CHAIN_X3) or (MMA == hip.MMA_BF16 and AMP_SWEEP))
     if not CONV_CHAIN or not eligible or (crowded and not (sweep_ok and SWEEP_DISPENSED)):
         if crowded and CONV_CHAIN and eligible:
             COUNTERS["per_layer_next_to_collectives"] += 1
@@ -450,7 +452,7 @@ def conv_chain(stages):
         fill(ws[:-1].view(torch.float32), 0.0)         # (stream-ordered after every earlier launch on this stream)
         _chain_epoch[key] = 1
     image = None
-    if CONV_SWEEP and n == 5 and descs[0].mma == hip.MMA_BF16X3:
+    if CONV_SWEEP and n == 5 and (descs[0].mma == hip.MMA_BF16X3 or (descs[0].mma == hip.MMA_BF16 and AMP_SWEEP)):
         image = _sweep_image(lib, descs, n, stages, dev)
     if crowded and image is None:                      # (a 5-stage block the sweep does not cover: shapes, tiles per image)
         COUNTERS["per_layer_next_to_collectives"] += 1
