@@ -944,8 +944,13 @@ def test_bf16_operand_mode(monkeypatch):
         return buf.cpu(), out.cpu()
 
     rb_, ro_ = run(False)
+    monkeypatch.setattr(ops, "AMP_SWEEP", False)          # tnr_conv_chain: the same k-order inside every MFMA as the per-layer kernel
     gb_, go_ = run(True)
     assert torch.equal(gb_, rb_) and torch.equal(go_, ro_) and ops.chain_error_flag() == 0
+    monkeypatch.setattr(ops, "AMP_SWEEP", True)           # the sweep's bf16-operand form (the default): bf16 resolution downstream of stage 1
+    gs_, os_ = run(True)                                  # (test_amp_dense_block_sweep_agrees_with_per_layer)
+    sc_ = max(1.0, float(rb_.abs().max()))
+    assert float((gs_ - rb_).abs().max()) <= 4e-3 * sc_ and float((os_ - ro_).abs().max()) <= 4e-3 * sc_ and ops.chain_error_flag() == 0
     x1 = F.leaky_relu(F.conv2d(_bf(x0.cpu().permute(0, 3, 1, 2)), _bf(ws[0].cpu()), None, padding=1), 0.2)
     close(rb_[..., nf:nf + gc].permute(0, 3, 1, 2), x1, what="bf16 chain stage 0")
 
