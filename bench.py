@@ -179,6 +179,8 @@ def cpu_reference_record():
             rec = json.load(fh)
         rec["source"] = os.path.relpath(files[-1], ROOT)
         rec.pop("last_log", None)
+        rec["note"] = ("recorded on the BUILD CONTAINER's cores (the reference tree does not travel to the GPU box): a different host from "
+                       "`cpu_baseline` (the oracle port on this box's cores) -- two reported baselines, not operands of a ratio")
         return rec
     except (OSError, ValueError):
         return None

@@ -304,7 +304,8 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
 
 @pytest.mark.parametrize("case", [(2, 40, 72, 64, 64, "lrelu", False), (1, 8, 32, 32, 64, "plain", False), (3, 17, 33, 128, 128, "res", False),
                                   (2, 64, 64, 256, 256, "mask", True), (1, 32, 32, 512, 512, "plain", False), (2, 96, 160, 64, 128, "lrelu", True),
-                                  (1, 9, 45, 96, 192, "res", False), (2, 24, 40, 64, 64, "noise", False)])
+                                  (1, 9, 45, 96, 192, "res", False), (2, 24, 40, 64, 64, "noise", False),
+                                  (2, 64, 64, 256, 256, "reflect", False), (1, 20, 37, 64, 64, "reflect", False)])    # ReflectionPad2d(1): ResnetGenerator's blocks
 def test_conv3x3_weight_stream_kernel_equals_staged_weights(case):
     """TNR_MMA_BF16X3, 3x3 layers with Cout % 64 == 0: conv3x3_d4_kernel (tnr_conv_desc.wq: weights as a pre-split stream read straight
     into registers; csrc/conv_sweep.hip) against the kernels that split and stage the slab per workgroup (ops.X3_D4 = False), bit for bit:
@@ -943,10 +944,12 @@ def test_bf16_operand_mode(monkeypatch):
         torch.cuda.synchronize()
         return buf.cpu(), out.cpu()
 
+    monkeypatch.setattr(ops, "X3_D4", False)              # per-layer launches on conv_tile_body<BF = 1> (not the weight-stream kernel's bf16 form)
     rb_, ro_ = run(False)
-    monkeypatch.setattr(ops, "AMP_SWEEP", False)          # tnr_conv_chain: the same k-order inside every MFMA as the per-layer kernel
+    monkeypatch.setattr(ops, "AMP_SWEEP", False)          # tnr_conv_chain: the same k-order inside every MFMA as that per-layer kernel
     gb_, go_ = run(True)
     assert torch.equal(gb_, rb_) and torch.equal(go_, ro_) and ops.chain_error_flag() == 0
+    monkeypatch.setattr(ops, "X3_D4", True)
     monkeypatch.setattr(ops, "AMP_SWEEP", True)           # the sweep's bf16-operand form (the default): bf16 resolution downstream of stage 1
     gs_, os_ = run(True)                                  # (test_amp_dense_block_sweep_agrees_with_per_layer)
     sc_ = max(1.0, float(rb_.abs().max()))

@@ -24,7 +24,8 @@ def layer(N, H, W, Cin, Cout, seed, epi="plain", dgrad=False):
     r1, r2, m = [(torch.rand(N, H, W, Cout, generator=g) * 2 - 1).to(dev) for _ in range(3)]
     b = (torch.rand(Cout, generator=g) - 0.5).to(dev)
     kw = {"plain": dict(bias=b), "lrelu": dict(bias=b, act=ops.ACT_LRELU, slope=0.2), "res": dict(bias=b, alpha=0.2, r1=ops.View(r1), r2=ops.View(r2), alpha2=0.2),
-          "mask": dict(mask=ops.View(m), m_slope=0.2), "noise": dict(bias=b, alpha=0.2, r1=ops.View(r1), noise=ops.Noise(0.1, ops.noise_key(3, 1, 4)))}[epi]
+          "mask": dict(mask=ops.View(m), m_slope=0.2), "noise": dict(bias=b, alpha=0.2, r1=ops.View(r1), noise=ops.Noise(0.1, ops.noise_key(3, 1, 4))),
+          "reflect": dict(bias=b, act=ops.ACT_RELU, reflect=True)}[epi]
 
     def run(d4):
         y = torch.full((N, H, W, Cout + 96), 3.0, device=dev)
@@ -45,7 +46,7 @@ def main():
     ok = True
     if "--time-only" not in sys.argv:
         cases = [(2, 40, 72, 64, 64, "lrelu", False), (1, 8, 32, 32, 64, "plain", False), (3, 17, 33, 128, 128, "res", False), (2, 64, 64, 256, 256, "mask", True),
-                 (1, 32, 32, 512, 512, "plain", False), (16, 128, 128, 64, 64, "noise", False), (2, 96, 160, 64, 128, "lrelu", True), (1, 9, 45, 96, 192, "res", False)]
+                 (1, 32, 32, 512, 512, "plain", False), (16, 128, 128, 64, 64, "noise", False), (2, 96, 160, 64, 128, "lrelu", True), (1, 9, 45, 96, 192, "res", False), (2, 64, 64, 256, 256, "reflect", False), (1, 20, 37, 64, 64, "reflect", False)]
         for k, (N, H, W, Cin, Cout, epi, dg) in enumerate(cases):
             run, _, _ = layer(N, H, W, Cin, Cout, 50 + k, epi, dg)
             ref = run(False)

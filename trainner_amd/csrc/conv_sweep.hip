@@ -1042,7 +1042,11 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
         for (int it = 0; it < S4_A_IT; ++it) {
             const int i = tid + it * 256, row = i >> 2, q = i & 3;
             const int hr = row / SW_WT, hc = row - hr * SW_WT;
-            const int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            int Y = ty0 + hr - 1, X = tx0 + hc - 1;
+            if (a.reflect) {         // nn.ReflectionPad2d(1) in front of the layer: row / column -1 is 1, H / W is H - 2 / W - 2
+                Y = Y == -1 ? 1 : (Y == a.H ? a.H - 2 : Y);
+                X = X == -1 ? 1 : (X == a.W ? a.W - 2 : X);
+            }
             const bool in = (row < SW_A_ROWS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
             in_off[it] = in ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
             a_dst[it] = row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
@@ -1146,7 +1150,8 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
 }
 
 bool d4_ok(const tnr_conv_desc *d) {
-    return d->mode == TNR_CONV_3x3 && (d->mma == TNR_MMA_BF16X3 || d->mma == TNR_MMA_BF16) && d->pad_mode == 0 && (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
+    return d->mode == TNR_CONV_3x3 && (d->mma == TNR_MMA_BF16X3 || d->mma == TNR_MMA_BF16) && (d->pad_mode == 0 || (d->pad_mode == 1 && d->H >= 2 && d->W >= 2)) &&
+           (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
            d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && d->Ho == d->H && d->Wo == d->W && d->W >= 32 && d->H >= 8 &&
            (int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->H * d->W * d->y.ctot < (1LL << 30) &&
            (int64_t)(d->Cout / 64) * (d->Cin / 16) * 18 * SW_UNIT_FLOATS * (int64_t)sizeof(float) < (1LL << 31);
@@ -1358,7 +1363,7 @@ int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
     k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
     k.noise_pos = d->noise_pos; k.noise_sigma = d->noise_sigma; k.noise_k0 = d->noise_key0; k.noise_k1 = d->noise_key1; k.noise_pix0 = d->noise_pix0;
     k.th_space = d->Ho; k.tw_space = d->Wo;
-    k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = 0;
+    k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = d->pad_mode == 1;
     c.wq = static_cast<const float *>(d->wq);
     c.wq_bytes = (int)tnr_conv_wq_bytes(d);
     c.nck = d->Cin / 16;
