@@ -427,8 +427,10 @@ def main():
             per_step_ms = {k: round(v["ms"] / nprof, 3) for k, v in summ.items()}
             kname = {"conv_chain": "conv_chain_kernel (5 dense-block 3x3 convolutions per launch, forward and data-gradient)",
                      "conv_tile_3x3": "conv_tile_kernel<3x3> (forward + data-gradient launches)"}[fam]
-            traffic, traffic_src = pmc_traffic(fam, "f32" if args.amp else args.mma)
+            traffic, traffic_src = pmc_traffic(fam, "bf16x3amp" if args.amp else args.mma)      # (tools/gpu.sh prof <tag> bf16x3 --amp)
             peak = PEAK_BF16_MFMA_TFLOPS if args.amp else (PEAK_BF16X3_TFLOPS if args.mma == "bf16x3" else PEAK_F32_MFMA_TFLOPS)
+            if fam == "conv_tile_3x3" and (args.amp or args.mma == "bf16x3") and ops.X3_D4:
+                kname = "conv3x3_d4_kernel (64-cout 3x3 layers, weights as a pre-split stream; forward + data-gradient launches) + conv_tile_kernel<3x3> for the rest"
             if fam == "conv_chain" and args.mma == "bf16x3" and not args.amp and ops.CONV_SWEEP:
                 kname = "conv_sweep4_kernel (a dense block's 5 convolutions per launch, forward and data-gradient; bf16x3)"
             roof = {"bound": "mfma", "kernel": kname,
@@ -436,21 +438,28 @@ def main():
                     "frac": round(tf / peak, 4), "peak_note": (
                         "fp32-equivalent: bf16 dense peak 2516.6 / 6 MFMAs per fp32-equivalent block" if peak == PEAK_BF16X3_TFLOPS else
                         "v_mfma_f32_32x32x16_bf16 dense" if args.amp else "v_mfma_f32_32x32x2_f32 dense"),
-                    "mfma_busy": pmc_mfma_busy(fam, args.mma if not args.amp else "amp"),
+                    "mfma_busy": pmc_mfma_busy(fam, args.mma if not args.amp else "bf16x3amp"),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
                     "kernel_ms_per_step": per_step_ms}
-            if args.amp and traffic:
-                # bf16 operands leave the bytes untouched (activations and weights stay fp32 in HBM and LDS): at 16x the matrix
-                # rate the same launch is bound by its HBM traffic, not by the MFMA pipe.  Bytes per launch = the recorded PMC
-                # figure of the fp32 run of the same kernels and shapes; the MFMA view is kept alongside.
-                avg_s = 1e-3 * dom["ms"] / dom["launches"]
-                gbs = traffic / avg_s / 1e9
-                roof.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                             "mfma_view": {"achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)},
-                             "traffic_source": (traffic_src or "") + " -- fp32 run; bf16 operand mode moves the same bytes"})
+            if args.amp:
+                kname = "conv_sweep4_kernel<true, true> (a dense block's 5 convolutions per launch, bf16 operands)" if (fam == "conv_chain" and ops.CONV_SWEEP and ops.AMP_SWEEP) else kname
+                roof["kernel"] = kname
+                if traffic:
+                    # bf16 operands leave the bytes untouched (activations stay fp32 in HBM and LDS).  Both views of the same launch, from
+                    # a PMC pass of THIS mode: the one with the larger fraction names the bound (round 3's chain kernel moved 1.92 GB per
+                    # launch at 5.9 TB/s -- HBM-bound; the sweep's bf16-operand form moves a third of that and is bound by neither roof:
+                    # load latency and epilogues)
+                    avg_s = 1e-3 * dom["ms"] / dom["launches"]
+                    gbs = traffic / avg_s / 1e9
+                    hbm = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}
+                    if hbm["frac"] > roof["frac"]:
+                        roof.update({"bound": "hbm", "mfma_view": {"achieved": roof["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof["frac"]}})
+                        roof.update(hbm)
+                    else:
+                        roof["hbm_view"] = hbm
 
     # second measurement in the same process: the same step in the OTHER fp32 arithmetic (headline bf16x3 -> v_mfma_f32_32x32x2_f32 and
     # vice versa).  (1 GPU only: the N > 1 runs are the scaling measurement and carry nothing extra.)
