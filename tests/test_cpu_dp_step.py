@@ -47,12 +47,14 @@ def _run_i2i(model):
                 d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
 
 
-def _build(tmp, seed_g, seed_d):
+def _build(tmp, seed_g, seed_d, gaussian=False):
     from trainner_amd.models import create_model
     from trainner_amd.options import options
-    yml = ref_harness.esrgan_yaml(name="dp_case", out_root=tmp, gpu_ids="[0]", **KW)
+    yml = ref_harness.esrgan_yaml(name="dp_case", out_root=tmp, gpu_ids="[0]", gaussian=gaussian, **KW)
     opt = options.parse(yml, is_train=True)
     model = create_model(opt, verbose=False)
+    if gaussian:                 # ESRGAN+ noise: one seed on every rank (train.py seeds all of them alike); each rank draws the
+        model.netG.noise_seed = 99      # field of ITS samples of the global batch (SRModel.feed_data sets noise_sample0)
     if seed_g is not None:
         model.netG.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netG.state_dict().items()}, seed_g))
         model.netD.load_state_dict(detrand.fill_state_dict_({k: v.clone() for k, v in model.netD.state_dict().items()}, seed_d))
@@ -75,7 +77,7 @@ def _run(model, rank=None, world=1):
                 d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
 
 
-def _worker(rank, world, port, tmp, q, kind="sr"):
+def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     try:
         torch.set_num_threads(4)
@@ -85,7 +87,8 @@ def _worker(rank, world, port, tmp, q, kind="sr"):
         # rank 1 holds DIFFERENT weights (as after a per-rank init RNG): sync_replicas must bring it to rank 0's
         # (SRModel's constructor calls it as its last act; here the seeded load happens after construction)
         build, run = (_build, lambda m: _run(m, rank, world)) if kind == "sr" else (_build_i2i, _run_i2i)
-        model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666)
+        kw = dict(gaussian=gaussian) if kind == "sr" else {}
+        model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666, **kw)
         assert model.dp.active and model.dp.world_size == world
         model.sync_replicas()
         out = run(model)
@@ -101,11 +104,14 @@ def _worker(rank, world, port, tmp, q, kind="sr"):
             dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process(tmp_path, monkeypatch):
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, gaussian):
+    """gaussian: with the ESRGAN+ noise on (the reference's default) -- every rank must draw the field of its own samples of the
+    GLOBAL batch (`noise_pix0`), or the two halves of fake_H would not be the single process's."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    port = 31000 + (os.getpid() % 2000) + (7 if gaussian else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, "sr", gaussian)) for r in range(2)]
     for p in procs:
         p.start()
     # the single-process comparator runs meanwhile: full batch, per-half-batch BatchNorm statistics
@@ -115,7 +121,9 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch):
     monkeypatch.setattr(ops, "bn_train_fwd", f)
     monkeypatch.setattr(ops, "bn_train_bwd", b)
     torch.set_num_threads(4)
-    one = _run(_build(str(tmp_path / "one"), 101, 202))
+    single = _build(str(tmp_path / "one"), 101, 202, gaussian)
+    assert single.netG.noise_sigma == (0.1 if gaussian else 0.0)
+    one = _run(single)
     res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
@@ -130,7 +138,10 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch):
         for s in range(STEPS):
             for k, v in one["logs"][s].items():
                 # every log entry is a global-batch quantity on every rank (G losses are all-reduced means)
-                assert abs(out["logs"][s][k] - v) <= 5e-5 * abs(v) + 1e-7, (r, s, k, out["logs"][s][k], v)
+                # (after the first update the raw mean logits D_real / D_fake carry the +-lr walk of the BatchNorm-shadowed conv
+                #  biases, whose true gradient is exactly zero: tests/test_gpu_step.check_logs uses the same looser bound for them)
+                tol = 2e-3 if (s > 0 and k in ("D_real", "D_fake")) else 5e-5
+                assert abs(out["logs"][s][k] - v) <= tol * abs(v) + 1e-7, (r, s, k, out["logs"][s][k], v)
         diff = (out["fake"] - one["fake"][r * per:(r + 1) * per]).abs().max().item()
         assert diff <= 1e-5, ("fake_H", r, diff)
         for name, mine, ref in (("G", out["g"], one["g"]), ("D", out["d"], one["d"])):

@@ -242,3 +242,18 @@ def test_optimizer_options_keep_falsy_values():
     assert o.param_groups[0]["betas"] == (0, 0.999) and o.param_groups[0]["lr"] == 0.0
     o = config_optimizer(dict_to_nonedict({}), "D", [net])
     assert o.param_groups[0]["betas"] == (0.9, 0.999) and o.param_groups[0]["lr"] == 1e-4
+
+
+def test_noise_key_derivation_matches_its_restatement():
+    """ops.noise_key (splitmix64 chain over seed / training forward / block) == oracle/gauss_noise.noise_key: the reference golden
+    with the ESRGAN+ noise on (oracle/ref_harness._substitute_gaussian_draw) and the engine derive the SAME 64-bit key."""
+    from oracle import gauss_noise
+    from trainner_amd import ops
+    for seed, call, block in ((0, 0, 0), (4242, 7, 11), (2 ** 63 + 5, 123456, 68), (99, 1, 3)):
+        k = ops.noise_key(seed, call, block)
+        assert (k & 0xFFFFFFFF, k >> 32) == gauss_noise.noise_key(seed, call, block)
+    nz = ops.Noise(0.1, ops.noise_key(1, 2, 3), pos=1, pix0=2 ** 32 + 7)
+    assert nz.pix0 == 7 and nz.at(2).pos == 2 and (nz.at(2).key0, nz.at(2).key1) == (nz.key0, nz.key1)
+    # distinct blocks / forwards / seeds -> distinct keys
+    keys = {ops.noise_key(s, c, b) for s in (0, 1) for c in range(4) for b in range(69)}
+    assert len(keys) == 2 * 4 * 69
