@@ -438,6 +438,9 @@ def main():
                     "frac": round(tf / peak, 4), "peak_note": (
                         "fp32-equivalent: bf16 dense peak 2516.6 / 6 MFMAs per fp32-equivalent block" if peak == PEAK_BF16X3_TFLOPS else
                         "v_mfma_f32_32x32x16_bf16 dense" if args.amp else "v_mfma_f32_32x32x2_f32 dense"),
+                    "power_note": ("in this arithmetic the part sits at its power cap (1.33 kW, 1.98-2.03 GHz instead of 2.4: profiles/r04j_power_bench_smi.txt); the same "
+                                   "launches on all-zero operands run 16 % (dense-block sweep) to 26 % (3x3 kernel) faster (profiles/r04t_sweep_power.txt, r04w_kernel_power.txt): "
+                                   "`peak` is the nominal-clock figure") if (args.mma == "bf16x3" and not args.amp) else None,
                     "mfma_busy": pmc_mfma_busy(fam, args.mma if not args.amp else "bf16x3amp"),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
