@@ -440,7 +440,9 @@ def main():
                         "v_mfma_f32_32x32x16_bf16 dense" if args.amp else "v_mfma_f32_32x32x2_f32 dense"),
                     "power_note": ("in this arithmetic the part sits at its power cap (1.33 kW, 1.98-2.03 GHz instead of 2.4: profiles/r04j_power_bench_smi.txt); the same "
                                    "launches on all-zero operands run 16 % (dense-block sweep) to 26 % (3x3 kernel) faster (profiles/r04t_sweep_power.txt, r04w_kernel_power.txt): "
-                                   "`peak` is the nominal-clock figure") if (args.mma == "bf16x3" and not args.amp) else None,
+                                   "a register-only loop of v_mfma_f32_32x32x16_bf16 on random bf16 operands sustains 1847 TFLOP/s = 0.73 of the dense peak, i.e. 307.8 fp32-equivalent "
+                                   "(profiles/r04y_mfma_power.txt); `peak` is the nominal-clock figure") if (args.mma == "bf16x3" and not args.amp) else None,
+                    "frac_of_sustained_mfma": (round(tf / 307.8, 4) if (args.mma == "bf16x3" and not args.amp) else None),
                     "mfma_busy": pmc_mfma_busy(fam, args.mma if not args.amp else "bf16x3amp"),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": dom["launches"] // nprof,
