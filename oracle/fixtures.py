@@ -141,6 +141,7 @@ def i2i_oracle_for(fx):
                                             pool_size=y.get("pool_size", 0), **common)
     if fx["network_G"]["type"] == "unet_net":
         orc.arch, orc.num_downs = "unet_net", fx["network_G"]["num_downs"]
+    orc.form = y.get("gan_form", "standard") or "relativistic"      # (None = no gan_opt in the recipe = the reference's default)
     return orc
 
 

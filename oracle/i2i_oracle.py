@@ -61,6 +61,15 @@ class _I2IBase:
         self.log = OrderedDict()
 
     arch, num_downs = "resnet_net", None          # generator: ResnetGenerator (n_blocks) or UnetGenerator (num_downs)
+    form = "standard"                             # train.gan_opt.form; 'relativistic' when the recipe has no gan_opt (losses.py:366-369)
+
+    def g_gan_loss(self, netD, fake, real):
+        """losses.py:395-403,424-431: standard = label loss on D(fake); relativistic = the average-relativistic pair, D(real) detached."""
+        pf = self.D(netD, fake)
+        if self.form == "standard":
+            return gan_label_loss(pf, True, self.gan_type)
+        pr = self.D(netD, real).detach()
+        return (gan_label_loss(pr - pf.mean(), False, self.gan_type) + gan_label_loss(pf - pr.mean(), True, self.gan_type)) / 2
 
     def G(self, net, x):
         if self.arch == "unet_net":
@@ -71,10 +80,15 @@ class _I2IBase:
         return patchgan_forward(x, net.sd, 3)
 
     def d_step_loss(self, netD, real, fake, log):
-        """base_model.py:852-883 + losses.py:471-478,497-523 (form: standard): D(fake.detach()) first, then D(real)."""
+        """base_model.py:852-883 + losses.py:471-478,497-523: D(fake.detach()) first, then D(real); standard labels or the
+        relativistic pair (:501-506)."""
         pf = self.D(netD, fake.detach())
         pr = self.D(netD, real)
-        l_fake, l_real = gan_label_loss(pf, False, self.gan_type), gan_label_loss(pr, True, self.gan_type)
+        if self.form == "standard":
+            l_fake, l_real = gan_label_loss(pf, False, self.gan_type), gan_label_loss(pr, True, self.gan_type)
+        else:
+            l_real = gan_label_loss(pr - pf.mean(), True, self.gan_type)
+            l_fake = gan_label_loss(pf - pr.mean(), False, self.gan_type)
         log["l_d_real"], log["l_d_fake"] = l_real.item(), l_fake.item()
         log["D_real"], log["D_fake"] = pr.detach().mean().item(), pf.detach().mean().item()
         return (l_fake + l_real) * 0.5
@@ -150,10 +164,10 @@ class OracleCycleGANStep(_I2IBase):
             l = self.pw * F.l1_loss(idt_B, A)
             self.log_B["pix-l1_idt"] = l.item()
             total = total + l * self.idt
-        l = self.gw * gan_label_loss(self.D(self.da, fake_B), True, self.gan_type)
+        l = self.gw * self.g_gan_loss(self.da, fake_B, A)          # (fake_B, real_A): cyclegan_model.py:241-243
         self.log_A["l_g_gan"] = l.item()
         total = total + l
-        l = self.gw * gan_label_loss(self.D(self.db, fake_A), True, self.gan_type)
+        l = self.gw * self.g_gan_loss(self.db, fake_A, B)          # (fake_A, real_B): :248-250
         self.log_B["l_g_gan"] = l.item()
         total = total + l
         l = self.pw * F.l1_loss(rec_A, A)

@@ -36,6 +36,11 @@ CASES = {
     # CycleGAN recipe as shipped (vanilla GAN), no identity term, no pool, batch 1, Linear LR policy
     "cyclegan_rn1_noidt": dict(yaml=dict(model="cyclegan", batch=1, crop=64, n_blocks=1, ngf=16, ndf=16, pixel_weight=10.0,
                                          lr_scheme="Linear"), steps=2, seed=84),
+    # the SHIPPED CycleGAN recipe's GAN: options/i2i/train_cyclegan.yml has no `gan_opt`, so Adversarial runs its default form,
+    # 'relativistic' (losses.py:366-369): D_A compares fake_B with real_A in the generator stage (cyclegan_model.py:241-243) and
+    # the pooled fake with real_B in its own; per-pixel PatchGAN logits, image pools, Linear LR policy
+    "cyclegan_rn1_relativistic": dict(yaml=dict(model="cyclegan", batch=1, crop=64, n_blocks=1, ngf=16, ndf=16, pixel_weight=10.0,
+                                                lr_scheme="Linear", pool_size=4, gan_form=None), steps=4, seed=86),
 }
 SEEDS = {"G": 301, "D": 302, "G_A": 303, "G_B": 304, "D_A": 305, "D_B": 306}
 POOL_SEED = 4242

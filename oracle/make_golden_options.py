@@ -1,4 +1,5 @@
-"""tests/golden/train_sr_reference.yml: the reference's shipped ESRGAN recipe (codes/options/sr/train_sr.yml) as a fixture.
+"""tests/golden/train_sr_reference.yml: the reference's shipped ESRGAN recipe (codes/options/sr/train_sr.yml) as a fixture; likewise
+its train_sr.json, test_sr.yml, i2i/train_pix2pix.yml and i2i/train_cyclegan.yml (tests/golden/*_reference.*).
 
 TEST INFRASTRUCTURE ONLY (build container: reads /root/reference).  Usage:  python -m oracle.make_golden_options
 
@@ -13,7 +14,17 @@ import re
 
 from .ref_harness import REF_CODES
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "train_sr_reference.yml")
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.path.join(GOLDEN, "train_sr_reference.yml")
+# the other recipes the reference ships for the paths in scope (same treatment: text as is, locations re-rooted)
+OTHERS = (("sr/train_sr.json", "train_sr_reference.json"), ("sr/test_sr.yml", "test_sr_reference.yml"),
+          ("i2i/train_pix2pix.yml", "train_pix2pix_reference.yml"), ("i2i/train_cyclegan.yml", "train_cyclegan_reference.yml"))
+
+
+def reroot(txt):
+    """every quoted location that starts with ../ (datasets, path.root, pretrained models) -> @ROOT@/"""
+    out, n = re.subn(r"(['\"])\.\./", r"\1@ROOT@/", txt)
+    return out, n
 
 
 def main():
@@ -27,6 +38,13 @@ def main():
     with open(OUT, "w") as f:
         f.write(out)
     print(OUT, "%d lines, %d with a location replaced" % (len(out.splitlines()), changed))
+    for rel, name in OTHERS:
+        txt = open(os.path.join(REF_CODES, "options", rel)).read()
+        out, n = reroot(txt)
+        assert n >= 2, (rel, n)
+        with open(os.path.join(GOLDEN, name), "w") as f:
+            f.write(out)
+        print(name, "%d lines, %d locations replaced" % (len(out.splitlines()), n))
 
 
 if __name__ == "__main__":

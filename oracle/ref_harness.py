@@ -160,7 +160,7 @@ def reference_netF(model):
 
 def i2i_yaml(name="oracle_i2i", model="pix2pix", batch=2, crop=64, n_blocks=2, ngf=16, ndf=16, norm_G="instance",
              gan_type="vanilla", pixel_weight=100.0, lambda_identity=None, pool_size=0, out_root=None, gpu_ids="[]",
-             lr_scheme="MultiStepLR", amp=False, which_G="resnet_net"):
+             lr_scheme="MultiStepLR", amp=False, which_G="resnet_net", gan_form="standard"):
     """A train_pix2pix.yml / train_cyclegan.yml-shaped config (codes/options/i2i/train_pix2pix.yml:1-143,
     train_cyclegan.yml:1-140) with the ResNet generator + PatchGAN of BASELINE.json configs[4], for CPU."""
     out_root = out_root or tempfile.mkdtemp(prefix="tnr_oracle_")
@@ -171,8 +171,9 @@ def i2i_yaml(name="oracle_i2i", model="pix2pix", batch=2, crop=64, n_blocks=2, n
         train += ["  lr_scheme: Linear", "  fixed_niter: 25000", "  niter_decay: 25000"]
     else:
         train += ["  lr_scheme: MultiStepLR", "  lr_steps: [50000, 100000]", "  lr_gamma: 0.5"]
-    train += ["  pixel_criterion: l1", "  pixel_weight: %g" % pixel_weight, "  gan_type: %s" % gan_type, "  gan_weight: 1",
-              "  gan_opt:", "    form: standard"]
+    train += ["  pixel_criterion: l1", "  pixel_weight: %g" % pixel_weight, "  gan_type: %s" % gan_type, "  gan_weight: 1"]
+    if gan_form is not None:        # None: no `gan_opt` at all, like the shipped recipes => 'relativistic' (losses.py:366-369)
+        train += ["  gan_opt:", "    form: %s" % gan_form]
     if lambda_identity is not None:
         train += ["  lambda_identity: %g" % lambda_identity]
     train += ["  manual_seed: 0", "  niter: 50000", "  val_freq: 5000"]

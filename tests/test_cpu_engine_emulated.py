@@ -123,6 +123,27 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     TS.test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch)
 
 
+def test_reference_shipped_test_recipe(tmp_path):
+    """options/sr/test_sr.yml (inference: is_train False, pretrained RRDB_ESRGAN_x4) over the emulated C ABI."""
+    TS.test_reference_shipped_test_recipe(tmp_path)
+
+
+def test_reference_shipped_json_recipe(tmp_path, monkeypatch):
+    """options/sr/train_sr.json (the same recipe in the JSON dialect) over the emulated C ABI."""
+    TS.test_reference_shipped_json_recipe(tmp_path, monkeypatch)
+
+
+def test_reference_shipped_cyclegan_recipe(tmp_path):
+    """options/i2i/train_cyclegan.yml unmodified (relativistic form by default, pools, use_amp, two pretrained generators)."""
+    TI.test_reference_shipped_cyclegan_recipe_runs_unmodified(tmp_path)
+
+
+def test_reference_shipped_pix2pix_recipe(tmp_path):
+    """options/i2i/train_pix2pix.yml: raises where the reference raises (no gan_opt, no real image in the generator stage);
+    steps with gan_opt.form: standard (unet_256 + conditional PatchGAN, use_amp) over the emulated C ABI."""
+    TI.test_reference_shipped_pix2pix_recipe(tmp_path)
+
+
 @pytest.mark.parametrize("gaussian", [False, True])
 def test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian):
     """The gate-pinned float64 arbitration of three consecutive steps (tests/test_gpu_step.py) over the emulated C ABI."""

@@ -14,6 +14,7 @@ step (1-4 sign-like Adam updates later: measured 5.5e-3 mean on rec_A of the 5-s
 still agrees to 7e-4) mean <= 1e-2, max <= 1e-1 (tanh output range 2); post-step weights mean |dp| <= 15 % of lr*steps, worst 2 lr*steps... the K = 10 bounds of
 test_gpu_step.CASE_TOL.
 """
+import os
 import random
 
 import pytest
@@ -25,7 +26,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt",
-             "pix2pix_unet128"]        # the shipped Pix2Pix recipe's U-Net generator (which_model_G: unet_net)
+             "pix2pix_unet128",                  # the shipped Pix2Pix recipe's U-Net generator (which_model_G: unet_net)
+             "cyclegan_rn1_relativistic"]        # the shipped CycleGAN recipe's GAN form (no gan_opt => relativistic), pools
 
 
 def build_i2i_model(yaml_kw, tmp_path):
@@ -73,6 +75,93 @@ def test_i2i_step_matches_reference_golden(case, tmp_path):
         assert mean < 0.15 and worst < 2.05, (n, k, worst, mean)
         e, k = FX.buffers_error(sd, fx["states"][n])
         assert e < (2e-3 if fx["spec"]["steps"] <= 2 else 1e-2), (n, "running stats", k, e)     # (carry the trajectory drift)
+
+
+def _shipped_i2i_recipe(tmp_path, fixture, edit=None):
+    """tests/golden/train_{pix2pix,cyclegan}_reference.yml (the reference's options/i2i/*.yml with the locations re-rooted,
+    oracle/make_golden_options.py) + the pretrained generators the recipe names, here seeded state_dicts of the recipe's nets."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    root = str(tmp_path)
+    txt = open(os.path.join(FX.GOLDEN_DIR, fixture)).read().replace("@ROOT@", root)
+    yml = os.path.join(root, fixture.replace("_reference", ""))
+    with open(yml, "w") as fh:
+        fh.write(edit(txt) if edit else txt)
+    opt = options.parse(yml, is_train=True)
+    pre = {k: v for k, v in opt["path"].items() if k.startswith("pretrain_model_") and v}
+    bare = options.parse(yml, is_train=True)
+    for k in pre:
+        bare["path"][k] = None
+    torch.manual_seed(0)
+    shapes = create_model(bare, verbose=False)
+    saved = {}
+    for i, (k, path) in enumerate(sorted(pre.items())):
+        net = getattr(shapes, "net" + k[len("pretrain_model_"):])
+        sd = detrand.fill_state_dict_({kk: vv.detach().cpu().clone() for kk, vv in net.state_dict().items()}, 700 + i)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(sd, path)
+        saved[k[len("pretrain_model_"):]] = sd
+    del shapes
+    torch.manual_seed(opt["train"]["manual_seed"])
+    return opt, create_model(opt, verbose=False), saved
+
+
+def _i2i_steps(opt, model, steps, seed):
+    ds = opt["datasets"]["train"]
+    logs = []
+    for s in range(1, steps + 1):
+        A = detrand.uniform((ds["batch_size"], 3, ds["crop_size"], ds["crop_size"]), seed + s, -1.0, 1.0)
+        B = detrand.uniform((ds["batch_size"], 3, ds["crop_size"], ds["crop_size"]), seed + 5000 + s, -1.0, 1.0)
+        model.feed_data({"A": A, "B": B, "A_path": ["a"] * ds["batch_size"]})
+        model.optimize_parameters(s)
+        logs.append(dict(model.get_current_log()))
+    return logs
+
+
+@pytest.mark.timeout(600)
+def test_reference_shipped_cyclegan_recipe_runs_unmodified(tmp_path):
+    """options/i2i/train_cyclegan.yml as shipped: resnet_net (9 blocks) x 2 + PatchGAN x 2 at 256 x 256, batch 1, use_amp, pool
+    50, Linear LR policy, two pretrained generators, and NO `gan_opt` => the relativistic form (golden cyclegan_rn1_relativistic
+    pins that form against the real reference).  Constructs, loads both generators, steps; finite logs with the reference's keys."""
+    random.seed(7)
+    opt, model, saved = _shipped_i2i_recipe(tmp_path, "train_cyclegan_reference.yml")
+    assert opt["network_G"]["type"] == "resnet_net" and opt["network_D"]["type"] == "patchgan" and opt["use_amp"] is True
+    assert opt["datasets"]["train"]["batch_size"] == 1 and opt["datasets"]["train"]["crop_size"] == 256 and opt["pool_size"] == 50
+    assert model.adversarial.form == "relativistic" and list(model.model_names) == ["G_A", "G_B", "D_A", "D_B"]
+    for n, sd in saved.items():
+        k = next(kk for kk in sd if kk.endswith(".weight"))
+        assert torch.equal(getattr(model, "net" + n).state_dict()[k].detach().cpu(), sd[k]), (n, k)      # pretrained, not the init
+    logs = _i2i_steps(opt, model, 3, 900)
+    assert list(logs[0]) == ["l_g_gan_A", "pix-l1_idt_A", "pix-l1_A", "l_g_gan_B", "pix-l1_idt_B", "pix-l1_B"] or \
+        list(logs[0]) == ["l_g_gan_A", "pix-l1_A", "l_g_gan_B", "pix-l1_B"], list(logs[0])
+    assert {"l_d_real_A", "l_d_fake_A", "D_real_A", "D_fake_A", "l_d_real_B", "l_d_fake_B", "D_real_B", "D_fake_B"} <= set(logs[-1])
+    for log in logs:
+        assert all(v == v and abs(v) < 1e3 for v in log.values()), log
+
+
+@pytest.mark.timeout(600)
+def test_reference_shipped_pix2pix_recipe(tmp_path):
+    """options/i2i/train_pix2pix.yml as shipped: unet_net (unet_256: 8 down-samplings) + conditional PatchGAN (in_nc 6), batch 2,
+    256 x 256, use_amp, a pretrained generator.  It has no `gan_opt` either, and Pix2Pix calls the generator stage without the
+    real image (pix2pix_model.py:152-154): the REFERENCE raises on its own recipe (TypeError: conv2d on None at
+    losses.py:401-403, run in the build container) and so does the engine, at the same place, saying what to set.  With the one
+    line the recipe needs -- train.gan_opt.form: standard, like options/i2i/train_wbc.yml:137-138 -- it steps."""
+    opt, model, _ = _shipped_i2i_recipe(tmp_path, "train_pix2pix_reference.yml")
+    assert opt["network_G"]["type"] == "unet_net" and opt["network_D"]["input_nc"] == 6 and opt["use_amp"] is True
+    with pytest.raises(TypeError, match="gan_opt.form: standard"):
+        _i2i_steps(opt, model, 1, 910)
+    del model
+    tmp2 = tmp_path / "standard"
+    tmp2.mkdir()
+    opt, model, saved = _shipped_i2i_recipe(tmp2, "train_pix2pix_reference.yml", edit=lambda t: t.replace(
+        "    gan_weight: 1\n", "    gan_weight: 1\n    gan_opt:\n      form: standard\n", 1))
+    assert model.adversarial.form == "standard" and model.adversarial.conditional
+    k = next(kk for kk in saved["G"] if kk.endswith(".weight"))
+    assert torch.equal(model.netG.state_dict()[k].detach().cpu(), saved["G"][k])
+    logs = _i2i_steps(opt, model, 2, 920)
+    assert list(logs[-1]) == ["l_d_real", "l_d_fake", "D_real", "D_fake", "l_g_gan", "pix-l1"], list(logs[-1])
+    for log in logs:
+        assert all(v == v and abs(v) < 1e3 for v in log.values()), log
 
 
 @pytest.mark.timeout(600)

@@ -195,6 +195,57 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     assert torch.equal(a, model.fake_H) and model.netG._noise_calls == 3
 
 
+def _write_recipe(tmp_path, fixture, name):
+    root = str(tmp_path)
+    txt = open(os.path.join(FX.GOLDEN_DIR, fixture)).read().replace("@ROOT@", root)
+    path = os.path.join(root, name)
+    with open(path, "w") as fh:
+        fh.write(txt)
+    return path
+
+
+def test_reference_shipped_json_recipe(tmp_path, monkeypatch):
+    """options/sr/train_sr.json (tests/golden/train_sr_reference.json) is the same recipe as train_sr.yml in the JSON-with-comments
+    dialect of options.py:539-560: it parses to the same option tree (tests/test_cpu_host.py pins that on CPU), constructs the same
+    model and steps."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    shipped_recipe(tmp_path, monkeypatch)                      # the pretrained generator + VGG files the recipe names
+    opt = options.parse(_write_recipe(tmp_path, "train_sr_reference.json", "train_sr.json"), is_train=True)
+    torch.manual_seed(opt["train"]["manual_seed"])
+    model = create_model(opt, verbose=False)
+    assert opt["network_G"]["type"] == "rrdb_net" and opt["network_G"]["gaussian_noise"] is True and opt["use_amp"] is True
+    LR, HR = detrand.synthetic_pair(opt["datasets"]["train"]["batch_size"], opt["datasets"]["train"]["crop_size"], 501)
+    model.feed_data({"LR": LR, "HR": HR})
+    model.optimize_parameters(1)
+    log = model.get_current_log()
+    assert set(log) >= {"pix-l1", "fea-vgg19-l1", "l_g_gan", "l_d_real", "l_d_fake", "D_real", "D_fake"}
+    assert all(v == v and abs(v) < 1e4 for v in log.values()), log
+
+
+def test_reference_shipped_test_recipe(tmp_path):
+    """options/sr/test_sr.yml (tests/golden/test_sr_reference.yml), the inference recipe: `parse(is_train=False)` +
+    `create_model` load `pretrain_model_G` (RRDB_ESRGAN_x4.pth, here a seeded state_dict) into `network_G: esrgan`; `feed_data`
+    (LR only) + `test()` + `get_current_visuals(need_HR=False)` as codes/test.py:102-130 drives them.  eval() => no noise; the
+    image equals the oracle's RRDBNet-23 forward."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    g = FX.initial_state(FX.load("esrgan_nb23_crop128")["g_keys"], 103)
+    os.makedirs(os.path.join(str(tmp_path), "experiments", "pretrained_models"))
+    torch.save(g, os.path.join(str(tmp_path), "experiments", "pretrained_models", "RRDB_ESRGAN_x4.pth"))
+    opt = options.parse(_write_recipe(tmp_path, "test_sr_reference.yml", "test_sr.yml"), is_train=False)
+    assert opt["is_train"] is False and list(opt["datasets"]) == ["test_1", "test_2"] and opt["network_G"]["nb"] == 23
+    model = create_model(opt, verbose=False)
+    LR, _ = detrand.synthetic_pair(2, 128, 31)
+    model.feed_data({"LR": LR}, need_HR=False)
+    model.test()
+    vis = model.get_current_visuals(need_HR=False)
+    assert list(vis) == ["LR", "SR"] and tuple(vis["SR"].shape) == (3, 128, 128)
+    ref = O.rrdbnet_forward(LR, g, 23)
+    d = (model.fake_H.detach().cpu() - ref).abs()
+    assert d.max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), d.max().item()     # 23 blocks deep; nb = 2 nets are held to 2e-5
+
+
 @pytest.mark.parametrize("gaussian", [False, True])
 def test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian):
     """(gaussian: the ESRGAN+ noise on -- the float64 side is fed the engine's own draw, read back with tnr_gauss_mult.)

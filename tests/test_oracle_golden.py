@@ -66,7 +66,8 @@ def test_oracle_matches_reference(case):
         assert e < 2e-3, ("D running stats", k, e)   # carries the BN-shadowed conv bias random walk
 
 
-I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt", "pix2pix_unet128"]
+I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt", "pix2pix_unet128",
+             "cyclegan_rn1_relativistic"]
 
 
 @pytest.mark.parametrize("case", I2I_CASES)

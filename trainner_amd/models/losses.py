@@ -254,6 +254,12 @@ class Adversarial(nn.Module):
             pred_g_fake = netD(fake)
             if self.form == "standard":                # D(real) is not needed (losses.py:395-403,424-426)
                 return self.l_gan_w * self._label_loss(pred_g_fake, True)
+            if real is None:
+                # the reference reaches netD(None) here (losses.py:401-403: conv2d on None => TypeError) -- e.g. its shipped
+                # options/i2i/train_pix2pix.yml, which has no `gan_opt` and calls the generator stage without `real`
+                raise TypeError("the relativistic GAN form (the default when `train.gan_opt.form` is not given) needs the real "
+                                "image in the generator stage and none was passed (the reference fails at the same place): "
+                                "set train.gan_opt.form: standard")
             with torch.no_grad():
                 pred_g_real = netD(real)          # detached in the reference (losses.py:430)
             res = _RaGANFn.apply(pred_g_fake, pred_g_real, 0, self.l_gan_w, self.dp_group)

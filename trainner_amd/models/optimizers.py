@@ -80,9 +80,10 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step(holder.flat, holder.grad, m, v, group["lr"] / bc1, b1, b2, math.sqrt(bc2), group["eps"],
                               group["weight_decay"])
                 holder.touch()                       # packed weights of this network are stale now
-            shared = torch.tensor(float(t))
+            # one tensor PER parameter: torch.optim.Adam (the reference resuming from this state, base_model.py:479-491) increments
+            # each entry in place, and torch.save keeps aliasing -- a shared tensor would be bumped once per parameter per step
             for p in group["params"]:
-                self.state[p]["step"] = shared
+                self.state[p]["step"] = torch.tensor(float(t))
 
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffers in place (views stay attached to the parameters)."""
