@@ -166,3 +166,114 @@ def test_reference_resumes_an_engine_checkpoint(tmp_path):
     for o in ref.optimizers:
         steps = {int(st["step"]) for st in o.state_dict()["state"].values()}
         assert steps == {3}, steps
+
+
+# ----------------------------------------------------------------------------------------------------------------- CycleGAN
+# Two networks per optimizer (G_A + G_B, D_A + D_B: cyclegan_model.py:120-133), four checkpoint files, check_resume's _A / _B keys
+# (options.py:676-678,699-714).
+I2I = dict(model="cyclegan", batch=1, crop=64, n_blocks=1, ngf=16, ndf=16, pixel_weight=10.0, lr_scheme="Linear")
+LR_I2I = 2e-4
+NETS = ("G_A", "G_B", "D_A", "D_B")
+
+
+def _ab(s):
+    return (detrand.uniform((1, 3, 64, 64), 7000 + s, -1.0, 1.0), detrand.uniform((1, 3, 64, 64), 12000 + s, -1.0, 1.0))
+
+
+def _i2i_fill(model):
+    for i, n in enumerate(NETS):
+        net = getattr(model, "net" + n)
+        net.load_state_dict(detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, 310 + i))
+
+
+def _i2i_ref_step(ref, s):
+    A, B = _ab(s)
+    with R.reference_env():
+        ref.feed_data({"A": A, "B": B, "A_path": ["a"], "B_path": ["b"]})
+        ref.optimize_parameters(s)
+    return dict(ref.get_current_log())
+
+
+def _i2i_eng_step(eng, s):
+    A, B = _ab(s)
+    eng.feed_data({"A": A, "B": B, "A_path": ["a"]})
+    eng.optimize_parameters(s)
+    return dict(eng.get_current_log())
+
+
+def _i2i_check(eng, ref, log_e, log_r):
+    # (the D entries of CycleGAN's log lag one step -- they are folded in inside backward_G, cyclegan_model.py:296-307 -- so the
+    #  side that continues still shows the previous step's, the freshly constructed side has none yet: compare what both have)
+    common = [k for k in log_r if k in log_e]
+    assert len(common) >= 4 and (set(log_e) <= set(log_r) or set(log_r) <= set(log_e)), (list(log_e), list(log_r))
+    for k in common:
+        if k.startswith(("l_d_", "D_")) and len(log_e) != len(log_r):
+            continue
+        assert abs(log_e[k] - log_r[k]) <= 3e-3 * max(1.0, abs(log_r[k])) + 5e-6, (k, log_e[k], log_r[k])
+    for n in NETS:
+        sd_e, sd_r = getattr(eng, "net" + n).state_dict(), getattr(ref, "net" + n).state_dict()
+        skip = FX.norm_shadowed_biases([(k, tuple(v.shape)) for k, v in sd_r.items()], "instance") if n.startswith("G") else ()
+        tot = cnt = 0
+        for k, v in sd_r.items():
+            if v.dtype.is_floating_point and k not in skip and "running" not in k:
+                d = (sd_e[k].detach().cpu() - v.detach().cpu()).abs()
+                tot, cnt = tot + d.sum().item(), cnt + d.numel()
+        # lost moments or step counts would put every element ~lr apart (Adam's first step is +-lr); ReLU-gate flips between the
+        # chained generators move a few receptive fields the other way (tests/test_gpu_i2i.py header), hence 0.15 and not 0.02
+        assert tot / cnt <= 0.15 * LR_I2I, (n, tot / cnt / LR_I2I)
+
+
+def _steps_of(optimizers):
+    return [{int(st["step"]) for st in o.state_dict()["state"].values()} for o in optimizers]
+
+
+def test_cyclegan_checkpoints_interchange_with_the_reference(tmp_path):
+    import sys
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    # ---- reference -> engine
+    root = str(tmp_path / "r2e")
+    ropt, ref = R.build_reference_model(R.i2i_yaml(name="xcyc", out_root=root, **I2I), seed=0)
+    _i2i_fill(ref)
+    for s in (1, 2):
+        _i2i_ref_step(ref, s)
+    for key in ("models", "training_state"):
+        os.makedirs(ropt["path"][key], exist_ok=True)
+    with R.reference_env():
+        ref.save(2)
+        ref.save_training_state(0, 2)
+    state_path = os.path.join(ropt["path"]["training_state"], "2.state")
+    assert sorted(os.listdir(ropt["path"]["models"])) == ["2_D_A.pth", "2_D_B.pth", "2_G_A.pth", "2_G_B.pth"]
+    log_r = _i2i_ref_step(ref, 3)
+    eopt = options.parse(_resume_yaml(R.i2i_yaml(name="xcyc", out_root=root, gpu_ids="[0]", **I2I), state_path), is_train=True)
+    resume_state = torch.load(eopt["path"]["resume_state"], weights_only=False)
+    options.check_resume(eopt)
+    assert all(eopt["path"]["pretrain_model_" + n].endswith("2_%s.pth" % n) for n in NETS)
+    eng = create_model(eopt, verbose=False)
+    eng.resume_training(resume_state)
+    eng.update_schedulers(eopt["train"])
+    log_e = _i2i_eng_step(eng, 3)
+    _i2i_check(eng, ref, log_e, log_r)
+    assert _steps_of(eng.optimizers) == [{3}, {3}]
+    # ---- engine -> reference (the engine above goes on: saves at 3, both take step 4)
+    for key in ("models", "training_state"):
+        os.makedirs(eopt["path"][key], exist_ok=True)
+    eng.save(3)
+    eng.save_training_state(0, 3)
+    state3 = os.path.join(eopt["path"]["training_state"], "3.state")
+    log_e = _i2i_eng_step(eng, 4)
+    ryml = _resume_yaml(R.i2i_yaml(name="xcyc", out_root=root, **I2I), state3)
+    with R.reference_env():
+        for m in [k for k in sys.modules if k.split(".")[0] in ("models", "options", "utils", "dataops", "data", "cv2", "torchvision")]:
+            del sys.modules[m]
+        import options.options as O
+        from models import create_model as ref_create
+        ropt2 = O.parse(ryml, is_train=True)
+        rs = torch.load(ropt2["path"]["resume_state"], weights_only=False)
+        O.check_resume(ropt2)
+        ref2 = ref_create(ropt2, verbose=False)
+        ref2.resume_training(rs)
+        ref2.update_schedulers(ropt2["train"])
+    log_r = _i2i_ref_step(ref2, 4)
+    _i2i_check(eng, ref2, log_e, log_r)
+    assert _steps_of(ref2.optimizers) == [{4}, {4}]

@@ -353,9 +353,7 @@ class BaseModel:
             if grad_clip.lower() != "norm":
                 raise NotImplementedError("grad_clip [{}] is not implemented by the HIP engine".format(grad_clip))
             self.grad_clip = "norm"
-            self.grad_clip_value = train_opt.get("grad_clip_value", 0.1)
-            if self.grad_clip_value == "auto":
-                raise NotImplementedError("grad_clip_value 'auto' is not implemented by the HIP engine")
+            self.grad_clip_value = train_opt.get("grad_clip_value", 0.1)      # a number, or 'auto' (get_auto_norm)
             self.clip_nets = clip_nets
             logger.info("norm gradient clip enabled. Clip value: %s.", self.grad_clip_value)
 
@@ -456,8 +454,26 @@ class BaseModel:
         scaling launch over the flat gradient buffer."""
         if self.grad_clip is None:
             return
+        sums = []
         for net in self.clip_nets:
             holder = net.flat_params()
             ss = torch.empty(1, dtype=torch.float64, device=holder.grad.device)
             ops.sumsq(holder.grad, ss)
-            ops.clip_by_norm(holder.grad, ss, float(self.grad_clip_value))
+            sums.append((holder, ss))
+        value = self.get_auto_norm(sums=sums) if self.grad_clip_value == "auto" else self.grad_clip_value
+        for holder, ss in sums:
+            ops.clip_by_norm(holder.grad, ss, float(value))
+
+    def calc_gradnorm(self, net):
+        """L2 norm of a network's gradient (base_model.py:885-894), from the flat gradient buffer."""
+        holder = net.flat_params()
+        ss = torch.empty(1, dtype=torch.float64, device=holder.grad.device)
+        ops.sumsq(holder.grad, ss)
+        return float(ss.item()) ** 0.5
+
+    def get_auto_norm(self, clip_percentile=10, sums=None):
+        """`grad_clip_value: auto` (base_model.py:896-909): the clip norm is the 10th percentile of the history of per-step
+        gradient norms (mean over the clipped networks).  Like the reference this reads the norm back every step."""
+        norms = [float(ss.item()) ** 0.5 for _, ss in sums] if sums is not None else [self.calc_gradnorm(n) for n in self.clip_nets]
+        self.grad_history.append(sum(norms) / len(norms))
+        return torch.quantile(torch.FloatTensor(self.grad_history), clip_percentile / 100)

@@ -72,6 +72,10 @@ class SRModel(BaseModel):
             self.real_H = self._shard(data["HR"]).to(self.device, non_blocking=True)
             self.var_ref = self._shard(data.get("ref", data["HR"])).to(self.device, non_blocking=True)
 
+    def feed_data_batch(self, data, need_HR=True):
+        """sr_model.py:130-132: a ready LR batch (test_chop's patches)."""
+        self.var_L = data
+
     def forward(self, data=None, CEM_net=None):
         if isinstance(data, torch.Tensor):
             return self.netG(data)

@@ -197,17 +197,21 @@ def opt_get(opt=None, keys=None, default=None):
 
 
 def check_resume(opt, resume_iter=None):
-    """Point pretrain_model_G/D at the <iter>_G.pth / <iter>_D.pth next to a .state file."""
+    """Point the pretrain_model_* paths at the <iter>_<net>.pth files next to a .state file (options.py:661-714): _G / _D, for
+    CycleGAN _G_A, _G_B / _D_A, _D_B; the discriminators only when `train.gan_weight` is set."""
     state = opt["path"]["resume_state"]
     if not state:
         return
     opt["path"]["resume_state"] = os.path.normpath(state)
-    for key in ("pretrain_model_G", "pretrain_model_D"):
-        if opt["path"].get(key):
-            logger.warning("%s path ignored, resuming training from a .state file.", key)
+    keys = ["_A", "_B"] if opt.get("model") == "cyclegan" else [""]
+    for ptype in ("_G", "_D"):
+        for sufx in set([""] + keys):
+            if opt["path"].get("pretrain_model" + ptype + sufx):
+                logger.warning("pretrain_model%s%s path ignored, resuming training from a .state file.", ptype, sufx)
     idx = resume_iter if resume_iter else os.path.basename(opt["path"]["resume_state"]).split(".")[0]
     targets = ["_G"] + (["_D"] if opt["train"]["gan_weight"] else [])
     for ptype in targets:
-        path = os.path.normpath(os.path.join(opt["path"]["models"], "{}{}.pth".format(idx, ptype)))
-        opt["path"]["pretrain_model" + ptype] = path
-        logger.info("Set [pretrain_model%s] to %s", ptype, path)
+        for mkey in keys:
+            path = os.path.normpath(os.path.join(opt["path"]["models"], "{}{}{}.pth".format(idx, ptype, mkey)))
+            opt["path"]["pretrain_model" + ptype + mkey] = path
+            logger.info("Set [pretrain_model%s%s] to %s", ptype, mkey, path)
