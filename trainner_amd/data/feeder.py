@@ -15,7 +15,6 @@ device fp32 tensors, so SRModel.feed_data's `.to(device)` is a no-op.  Two slots
 only after the compute stream passed the point where the consumer asked for the next batch (event-ordered, the host
 never blocks on the GPU).
 """
-import collections
 
 import numpy as np
 import torch

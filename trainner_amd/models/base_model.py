@@ -15,7 +15,6 @@ from contextlib import contextmanager, nullcontext
 from shutil import copyfile
 
 import torch
-import torch.nn as nn
 
 from .. import dp as dpmod
 from .. import hip, ops

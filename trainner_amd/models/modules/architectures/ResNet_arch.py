@@ -37,8 +37,13 @@ class ConvTranspose2dHIP(nn.Module):
         super().__init__()
         self.in_channels, self.out_channels, self.kernel_size, self.stride = in_nc, out_nc, kernel_size, stride
         self.weight = nn.Parameter(torch.empty(in_nc, out_nc, kernel_size, kernel_size))
-        self.bias = nn.Parameter(torch.zeros(out_nc)) if bias else None
+        self.bias = nn.Parameter(torch.empty(out_nc)) if bias else None
+        # nn.ConvTranspose2d's default init, draw for draw (the same seed then gives the reference's initial weights: init_weights
+        # runs after construction and its draws follow these in the generator's stream)
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            bound = 1.0 / (out_nc * kernel_size * kernel_size) ** 0.5        # fan_in of the [in, out, k, k] layout = size(1) * k * k
+            nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
         raise RuntimeError("ConvTranspose2dHIP is executed by its owning network's HIP engine")
