@@ -537,7 +537,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.crop)
             out["cpu_reference"] = cpu_reference_record()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
