@@ -47,10 +47,15 @@ def _run_i2i(model):
                 d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
 
 
-def _build(tmp, seed_g, seed_d, gaussian=False):
+def _build(tmp, seed_g, seed_d, gaussian=False, accumulate=False):
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     yml = ref_harness.esrgan_yaml(name="dp_case", out_root=tmp, gpu_ids="[0]", gaussian=gaussian, **KW)
+    if accumulate:               # virtual_batch_size = 2 x batch_size: two calls per optimizer step (base_model.py:722-734)
+        txt = open(yml).read()
+        assert "virtual_batch_size: %d" % KW["batch"] in txt
+        with open(yml, "w") as fh:
+            fh.write(txt.replace("virtual_batch_size: %d" % KW["batch"], "virtual_batch_size: %d" % (2 * KW["batch"])))
     opt = options.parse(yml, is_train=True)
     model = create_model(opt, verbose=False)
     if gaussian:                 # ESRGAN+ noise: one seed on every rank (train.py seeds all of them alike); each rank draws the
@@ -65,9 +70,9 @@ def _build(tmp, seed_g, seed_d, gaussian=False):
     return model
 
 
-def _run(model, rank=None, world=1):
+def _run(model, rank=None, world=1, steps=STEPS):
     logs = []
-    for s in range(1, STEPS + 1):
+    for s in range(1, steps + 1):
         LR, HR = detrand.synthetic_pair(KW["batch"], KW["crop"], 70 + s)     # every rank is fed the GLOBAL batch
         model.feed_data({"LR": LR, "HR": HR})
         model.optimize_parameters(s)
@@ -77,7 +82,7 @@ def _run(model, rank=None, world=1):
                 d={k: v.detach().clone() for k, v in model.netD.state_dict().items()})
 
 
-def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False):
+def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False, accumulate=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     try:
         torch.set_num_threads(4)
@@ -86,8 +91,9 @@ def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False):
         dpmod.BUCKET_FLOATS = 100_000             # several buckets per network, fired from inside backward
         # rank 1 holds DIFFERENT weights (as after a per-rank init RNG): sync_replicas must bring it to rank 0's
         # (SRModel's constructor calls it as its last act; here the seeded load happens after construction)
-        build, run = (_build, lambda m: _run(m, rank, world)) if kind == "sr" else (_build_i2i, _run_i2i)
-        kw = dict(gaussian=gaussian) if kind == "sr" else {}
+        build, run = (_build, lambda m: _run(m, rank, world, 2 * STEPS if accumulate else STEPS)) if kind == "sr" else (_build_i2i, _run_i2i)
+        kw = dict(gaussian=gaussian, accumulate=accumulate) if kind == "sr" else {}
+
         model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666, **kw)
         assert model.dp.active and model.dp.world_size == world
         model.sync_replicas()
@@ -104,14 +110,18 @@ def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gaussian", [False, True])
-def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, gaussian):
+@pytest.mark.parametrize("variant", ["plain", "gaussian", "accumulate"])
+def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant):
     """gaussian: with the ESRGAN+ noise on (the reference's default) -- every rank must draw the field of its own samples of the
-    GLOBAL batch (`noise_pix0`), or the two halves of fake_H would not be the single process's."""
+    GLOBAL batch (`noise_pix0`), or the two halves of fake_H would not be the single process's.
+    accumulate: virtual_batch_size = 2 x batch_size -- gradients accumulate locally over two calls and are exchanged once, before
+    the optimizer step (the buckets do not leave from inside backward then); four calls = two optimizer steps."""
+    gaussian, accumulate = variant == "gaussian", variant == "accumulate"
+    steps = 2 * STEPS if accumulate else STEPS
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + (os.getpid() % 2000) + (7 if gaussian else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, "sr", gaussian)) for r in range(2)]
+    port = 31000 + (os.getpid() % 2000) + {"plain": 0, "gaussian": 7, "accumulate": 13}[variant]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, "sr", gaussian, accumulate)) for r in range(2)]
     for p in procs:
         p.start()
     # the single-process comparator runs meanwhile: full batch, per-half-batch BatchNorm statistics
@@ -121,9 +131,9 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, gaussian):
     monkeypatch.setattr(ops, "bn_train_fwd", f)
     monkeypatch.setattr(ops, "bn_train_bwd", b)
     torch.set_num_threads(4)
-    single = _build(str(tmp_path / "one"), 101, 202, gaussian)
-    assert single.netG.noise_sigma == (0.1 if gaussian else 0.0)
-    one = _run(single)
+    single = _build(str(tmp_path / "one"), 101, 202, gaussian, accumulate)
+    assert single.netG.noise_sigma == (0.1 if gaussian else 0.0) and single.accumulations == (2 if accumulate else 1)
+    one = _run(single, steps=steps)
     res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
@@ -135,12 +145,12 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, gaussian):
     shadow = FX.bn_shadowed_biases([(k, None) for k in one["d"]])
     for r in (0, 1):
         out = res[r]
-        for s in range(STEPS):
+        for s in range(steps):
             for k, v in one["logs"][s].items():
                 # every log entry is a global-batch quantity on every rank (G losses are all-reduced means)
                 # (after the first update the raw mean logits D_real / D_fake carry the +-lr walk of the BatchNorm-shadowed conv
                 #  biases, whose true gradient is exactly zero: tests/test_gpu_step.check_logs uses the same looser bound for them)
-                tol = 2e-3 if (s > 0 and k in ("D_real", "D_fake")) else 5e-5
+                tol = 2e-3 if (s >= (2 if accumulate else 1) and k in ("D_real", "D_fake")) else 5e-5
                 assert abs(out["logs"][s][k] - v) <= tol * abs(v) + 1e-7, (r, s, k, out["logs"][s][k], v)
         diff = (out["fake"] - one["fake"][r * per:(r + 1) * per]).abs().max().item()
         assert diff <= 1e-5, ("fake_H", r, diff)
