@@ -152,3 +152,45 @@ def norm_shadowed_biases(keys, norm_type):
         return set()
     biases = [k for k, _ in keys if k.endswith(".bias")]
     return set(biases[:-1])
+
+
+def shipped_recipe_tree(rel, root):
+    """tests/golden/shipped_recipes.json[rel] (oracle/make_golden_options.py: the option tree of the reference's
+    codes/options/<rel>, locations as @ROOT@/...) with the placeholder replaced by `root`."""
+    import json
+    from collections import OrderedDict
+    with open(os.path.join(GOLDEN_DIR, "shipped_recipes.json")) as f:
+        tree = json.load(f, object_pairs_hook=OrderedDict)[rel]
+
+    def sub(node):
+        if isinstance(node, dict):
+            return OrderedDict((k, sub(v)) for k, v in node.items())
+        if isinstance(node, list):
+            return [sub(v) for v in node]
+        if isinstance(node, str) and node.startswith("@ROOT@/"):
+            return os.path.join(root, node[len("@ROOT@/"):]) if node != "@ROOT@/" else root + "/"
+        return node
+    return sub(tree)
+
+
+def write_recipe(rel, root, edit=None):
+    """The recipe as a file `options.parse` reads: <root>/<basename of rel>, YAML or JSON by its extension.  `edit(tree)` may
+    change the tree first (returns None or the new tree)."""
+    import json
+    tree = shipped_recipe_tree(rel, root)
+    if edit is not None:
+        tree = edit(tree) or tree
+    path = os.path.join(root, os.path.basename(rel))
+    os.makedirs(root, exist_ok=True)
+    with open(path, "w") as f:
+        if rel.endswith(".json"):
+            json.dump(tree, f, indent=2)
+        else:
+            import yaml
+
+            class Dumper(yaml.SafeDumper):
+                pass
+
+            Dumper.add_representer(type(tree), lambda d, data: d.represent_dict(data.items()))
+            yaml.dump(tree, f, Dumper=Dumper, sort_keys=False, default_flow_style=False)
+    return path

@@ -74,27 +74,25 @@ def test_yaml_scientific_notation_and_json(tmp_path):
 
 
 def test_shipped_recipes_parse(tmp_path):
-    """Every recipe the reference ships for the paths in scope (tests/golden/*_reference.*: options/sr/train_sr.{yml,json},
-    sr/test_sr.yml, i2i/train_{pix2pix,cyclegan}.yml with the locations re-rooted) goes through `options.parse`; the JSON file is
+    """Every recipe the reference ships for the paths in scope (tests/golden/shipped_recipes.json: options/sr/train_sr.{yml,json},
+    sr/test_sr.yml, i2i/train_{pix2pix,cyclegan}.yml, locations re-rooted) goes through `options.parse`; the JSON file is
     the YAML recipe (one spelling differs, lr_downscale_types 'cubic' / 'bicubic', which parse maps to one interpolation), so
     both give the same option tree."""
     from trainner_amd.options import options
 
-    def parse(fixture, is_train=True):
-        p = tmp_path / fixture.replace("_reference", "")
-        p.write_text(open(os.path.join(FX.GOLDEN_DIR, fixture)).read().replace("@ROOT@", str(tmp_path)))
-        return options.parse(str(p), is_train=is_train)
+    def parse(rel, is_train=True):
+        return options.parse(FX.write_recipe(rel, str(tmp_path)), is_train=is_train)
 
-    y, j = parse("train_sr_reference.yml"), parse("train_sr_reference.json")
+    y, j = parse("sr/train_sr.yml"), parse("sr/train_sr.json")
     for k in ("network_G", "network_D", "train", "scale", "use_amp", "model", "gpu_ids", "logger"):
         a, b = y[k], j[k]
         assert (dict(a) == dict(b)) if isinstance(a, dict) else (a == b), (k, a, b)
     assert dict(y["datasets"]["train"]) == dict(j["datasets"]["train"])
     vy, vj = dict(y["datasets"]["val"]), dict(j["datasets"]["val"])
     assert vy.pop("lr_downscale_types") == ["linear", "bicubic"] and vj.pop("lr_downscale_types") == ["linear", "cubic"] and vy == vj
-    t = parse("test_sr_reference.yml", is_train=False)
+    t = parse("sr/test_sr.yml", is_train=False)
     assert t["is_train"] is False and t["network_G"]["type"] == "rrdb_net" and t["path"]["pretrain_model_G"].endswith("RRDB_ESRGAN_x4.pth")
-    p2p, cyc = parse("train_pix2pix_reference.yml"), parse("train_cyclegan_reference.yml")
+    p2p, cyc = parse("i2i/train_pix2pix.yml"), parse("i2i/train_cyclegan.yml")
     # (what the reference's own parse gives for these files, run in the build container)
     assert dict(p2p["network_D"]) == {"strict": True, "type": "patchgan", "input_nc": 6, "ndf": 64, "n_layers": 3, "get_feats": False,
                                       "patch": True, "use_spectral_norm": False}
@@ -102,6 +100,50 @@ def test_shipped_recipes_parse(tmp_path):
                                       "norm_type": "batch", "use_dropout": False, "upsample_mode": "deconv"}
     assert cyc["network_G"]["type"] == "resnet_net" and cyc["pool_size"] == 50 and cyc["train"]["lr_scheme"] == "Linear"
     assert "gan_opt" not in p2p["train"] and "gan_opt" not in cyc["train"]
+
+
+@pytest.mark.skipif(not ref_harness.reference_available(), reason="needs the reference checkout (build container)")
+def test_shipped_recipe_fixture_is_the_reference_files(tmp_path):
+    """tests/golden/shipped_recipes.json against the files themselves: (1) the fixture equals the trees the reference's files
+    denote (oracle/make_golden_options.reference_trees); (2) `options.parse` of the REAL file (comments, layout, `5e-3` scalars,
+    JSON with // comments) and of the file the tests write from the fixture give the same option tree, modulo the locations."""
+    import json
+    from collections import OrderedDict
+    from oracle import make_golden_options as M
+    from trainner_amd.options import options
+    with open(os.path.join(FX.GOLDEN_DIR, "shipped_recipes.json")) as f:
+        stored = json.load(f, object_pairs_hook=OrderedDict)
+    assert json.loads(json.dumps(M.reference_trees())) == json.loads(json.dumps(stored))
+
+    def flat(d, pre=""):
+        out = {}
+        if isinstance(d, dict):
+            for k, v in d.items():
+                out.update(flat(v, pre + str(k) + "."))
+        else:
+            out[pre[:-1]] = d
+        return out
+
+    wroot = str(tmp_path / "w")
+
+    def loc(v):
+        """a location with its root removed: '../x' (the real file, relative to codes/) and '<wroot>/x' (the written file) -> 'x'"""
+        if isinstance(v, list):
+            return [loc(x) for x in v]
+        if isinstance(v, str):
+            if v == ".." or v.startswith("../"):
+                return os.path.normpath(v[3:] or ".")
+            if v == wroot or v.startswith(wroot + "/"):
+                return os.path.normpath(os.path.relpath(v, wroot))
+        return v
+
+    for rel in M.RECIPES:
+        train = "train" in os.path.basename(rel)
+        real = flat(options.parse(os.path.join(ref_harness.REF_CODES, "options", rel), is_train=train))
+        mine = flat(options.parse(FX.write_recipe(rel, wroot), is_train=train))
+        for k in sorted(set(real) | set(mine)):
+            if k != "_options_dir":
+                assert loc(real.get(k)) == loc(mine.get(k)), (rel, k, real.get(k), mine.get(k))
 
 
 def test_defaults_reject_off_path_kinds():

@@ -77,16 +77,12 @@ def test_i2i_step_matches_reference_golden(case, tmp_path):
         assert e < (2e-3 if fx["spec"]["steps"] <= 2 else 1e-2), (n, "running stats", k, e)     # (carry the trajectory drift)
 
 
-def _shipped_i2i_recipe(tmp_path, fixture, edit=None):
-    """tests/golden/train_{pix2pix,cyclegan}_reference.yml (the reference's options/i2i/*.yml with the locations re-rooted,
+def _shipped_i2i_recipe(tmp_path, rel, edit=None):
+    """The reference's options/<rel> (tests/golden/shipped_recipes.json: every key and value, locations re-rooted,
     oracle/make_golden_options.py) + the pretrained generators the recipe names, here seeded state_dicts of the recipe's nets."""
     from trainner_amd.models import create_model
     from trainner_amd.options import options
-    root = str(tmp_path)
-    txt = open(os.path.join(FX.GOLDEN_DIR, fixture)).read().replace("@ROOT@", root)
-    yml = os.path.join(root, fixture.replace("_reference", ""))
-    with open(yml, "w") as fh:
-        fh.write(edit(txt) if edit else txt)
+    yml = FX.write_recipe(rel, str(tmp_path), edit)
     opt = options.parse(yml, is_train=True)
     pre = {k: v for k, v in opt["path"].items() if k.startswith("pretrain_model_") and v}
     bare = options.parse(yml, is_train=True)
@@ -124,7 +120,7 @@ def test_reference_shipped_cyclegan_recipe_runs_unmodified(tmp_path):
     50, Linear LR policy, two pretrained generators, and NO `gan_opt` => the relativistic form (golden cyclegan_rn1_relativistic
     pins that form against the real reference).  Constructs, loads both generators, steps; finite logs with the reference's keys."""
     random.seed(7)
-    opt, model, saved = _shipped_i2i_recipe(tmp_path, "train_cyclegan_reference.yml")
+    opt, model, saved = _shipped_i2i_recipe(tmp_path, "i2i/train_cyclegan.yml")
     assert opt["network_G"]["type"] == "resnet_net" and opt["network_D"]["type"] == "patchgan" and opt["use_amp"] is True
     assert opt["datasets"]["train"]["batch_size"] == 1 and opt["datasets"]["train"]["crop_size"] == 256 and opt["pool_size"] == 50
     assert model.adversarial.form == "relativistic" and list(model.model_names) == ["G_A", "G_B", "D_A", "D_B"]
@@ -146,15 +142,17 @@ def test_reference_shipped_pix2pix_recipe(tmp_path):
     real image (pix2pix_model.py:152-154): the REFERENCE raises on its own recipe (TypeError: conv2d on None at
     losses.py:401-403, run in the build container) and so does the engine, at the same place, saying what to set.  With the one
     line the recipe needs -- train.gan_opt.form: standard, like options/i2i/train_wbc.yml:137-138 -- it steps."""
-    opt, model, _ = _shipped_i2i_recipe(tmp_path, "train_pix2pix_reference.yml")
+    opt, model, _ = _shipped_i2i_recipe(tmp_path, "i2i/train_pix2pix.yml")
     assert opt["network_G"]["type"] == "unet_net" and opt["network_D"]["input_nc"] == 6 and opt["use_amp"] is True
     with pytest.raises(TypeError, match="gan_opt.form: standard"):
         _i2i_steps(opt, model, 1, 910)
     del model
     tmp2 = tmp_path / "standard"
     tmp2.mkdir()
-    opt, model, saved = _shipped_i2i_recipe(tmp2, "train_pix2pix_reference.yml", edit=lambda t: t.replace(
-        "    gan_weight: 1\n", "    gan_weight: 1\n    gan_opt:\n      form: standard\n", 1))
+    def standard_form(tree):
+        tree["train"]["gan_opt"] = {"form": "standard"}
+
+    opt, model, saved = _shipped_i2i_recipe(tmp2, "i2i/train_pix2pix.yml", edit=standard_form)
     assert model.adversarial.form == "standard" and model.adversarial.conditional
     k = next(kk for kk in saved["G"] if kk.endswith(".weight"))
     assert torch.equal(model.netG.state_dict()[k].detach().cpu(), saved["G"][k])

@@ -123,15 +123,12 @@ VGG19_FEATURE_IDX = [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28, 30, 32, 34]
 
 
 def shipped_recipe(tmp_path, monkeypatch):
-    """The reference's own options/sr/train_sr.yml (tests/golden/train_sr_reference.yml: its text with only the filesystem locations
-    re-rooted, oracle/make_golden_options.py) plus the two files it expects on disk: the pretrained generator
+    """The reference's own options/sr/train_sr.yml (tests/golden/shipped_recipes.json: every key and value of the file, only the
+    filesystem locations re-rooted, oracle/make_golden_options.py) plus the two files it expects on disk: the pretrained generator
     `experiments/pretrained_models/RRDB_PSNR_x4.pth` (here a seeded RRDBNet-23 state_dict in the reference's legacy checkpoint format,
     base_model.py:364-375) and torchvision's cached ImageNet VGG19 (here seeded weights under torchvision's file name in $TORCH_HOME)."""
     root = str(tmp_path)
-    txt = open(os.path.join(FX.GOLDEN_DIR, "train_sr_reference.yml")).read().replace("@ROOT@", root)
-    yml = os.path.join(root, "train_sr.yml")
-    with open(yml, "w") as fh:
-        fh.write(txt)
+    yml = FX.write_recipe("sr/train_sr.yml", root)
     g = FX.initial_state(FX.load("esrgan_nb23_crop128")["g_keys"], 101)
     os.makedirs(os.path.join(root, "experiments", "pretrained_models"))
     torch.save(g, os.path.join(root, "experiments", "pretrained_models", "RRDB_PSNR_x4.pth"), _use_new_zipfile_serialization=False)
@@ -195,23 +192,14 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     assert torch.equal(a, model.fake_H) and model.netG._noise_calls == 3
 
 
-def _write_recipe(tmp_path, fixture, name):
-    root = str(tmp_path)
-    txt = open(os.path.join(FX.GOLDEN_DIR, fixture)).read().replace("@ROOT@", root)
-    path = os.path.join(root, name)
-    with open(path, "w") as fh:
-        fh.write(txt)
-    return path
-
-
 def test_reference_shipped_json_recipe(tmp_path, monkeypatch):
-    """options/sr/train_sr.json (tests/golden/train_sr_reference.json) is the same recipe as train_sr.yml in the JSON-with-comments
+    """options/sr/train_sr.json is the same recipe as train_sr.yml in the JSON-with-comments
     dialect of options.py:539-560: it parses to the same option tree (tests/test_cpu_host.py pins that on CPU), constructs the same
     model and steps."""
     from trainner_amd.models import create_model
     from trainner_amd.options import options
     shipped_recipe(tmp_path, monkeypatch)                      # the pretrained generator + VGG files the recipe names
-    opt = options.parse(_write_recipe(tmp_path, "train_sr_reference.json", "train_sr.json"), is_train=True)
+    opt = options.parse(FX.write_recipe("sr/train_sr.json", str(tmp_path)), is_train=True)
     torch.manual_seed(opt["train"]["manual_seed"])
     model = create_model(opt, verbose=False)
     assert opt["network_G"]["type"] == "rrdb_net" and opt["network_G"]["gaussian_noise"] is True and opt["use_amp"] is True
@@ -224,7 +212,7 @@ def test_reference_shipped_json_recipe(tmp_path, monkeypatch):
 
 
 def test_reference_shipped_test_recipe(tmp_path):
-    """options/sr/test_sr.yml (tests/golden/test_sr_reference.yml), the inference recipe: `parse(is_train=False)` +
+    """options/sr/test_sr.yml, the inference recipe: `parse(is_train=False)` +
     `create_model` load `pretrain_model_G` (RRDB_ESRGAN_x4.pth, here a seeded state_dict) into `network_G: esrgan`; `feed_data`
     (LR only) + `test()` + `get_current_visuals(need_HR=False)` as codes/test.py:102-130 drives them.  eval() => no noise; the
     image equals the oracle's RRDBNet-23 forward."""
@@ -233,7 +221,7 @@ def test_reference_shipped_test_recipe(tmp_path):
     g = FX.initial_state(FX.load("esrgan_nb23_crop128")["g_keys"], 103)
     os.makedirs(os.path.join(str(tmp_path), "experiments", "pretrained_models"))
     torch.save(g, os.path.join(str(tmp_path), "experiments", "pretrained_models", "RRDB_ESRGAN_x4.pth"))
-    opt = options.parse(_write_recipe(tmp_path, "test_sr_reference.yml", "test_sr.yml"), is_train=False)
+    opt = options.parse(FX.write_recipe("sr/test_sr.yml", str(tmp_path)), is_train=False)
     assert opt["is_train"] is False and list(opt["datasets"]) == ["test_1", "test_2"] and opt["network_G"]["nb"] == 23
     model = create_model(opt, verbose=False)
     LR, _ = detrand.synthetic_pair(2, 128, 31)
