@@ -90,6 +90,15 @@ def test_oracle_resize_linear_cubic_are_torch_interpolate():
 def test_oracle_resize_area_closed_forms():
     img = np.random.RandomState(0).rand(24, 36)
     assert np.allclose(DO.resize(img, (12, 18), "area"), img.reshape(12, 2, 18, 2).mean((1, 3)))      # integer box filter
+    # third-party statements of the integer-ratio case (where every definition of "area" agrees): torch's adaptive average
+    # pooling (F.interpolate mode='area') and PIL's exact box reduction (Image.reduce), per-axis factors 2, 3, 4, 6 and mixed
+    from PIL import Image
+    for size in ((12, 18), (8, 12), (6, 9), (4, 6), (12, 9), (6, 36), (24, 12)):
+        got = DO.resize(img, size, "area")
+        tm = torch.nn.functional.interpolate(torch.from_numpy(img)[None, None], size=size, mode="area")[0, 0].numpy()
+        assert np.abs(got - tm).max() < 1e-12, size
+        pil = np.asarray(Image.fromarray(img.astype(np.float32), mode="F").reduce((36 // size[1], 24 // size[0])))
+        assert np.abs(got - pil).max() < 2e-6, size
     assert np.allclose(DO.resize(img, (24, 36), "linear"), img) and np.allclose(DO.resize(img, (24, 36), "cubic"), img)
     # fractional shrink: every output = coverage-weighted mean of the source cells its box [d s, (d + 1) s) overlaps; the weights of a
     # row sum to 1 and a constant image stays constant
@@ -127,6 +136,12 @@ def test_device_filter2d_and_resize():
             tm = torch.nn.functional.interpolate(torch.from_numpy(img), size=size, mode={"linear": "bilinear", "cubic": "bicubic"}[mode],
                                                  align_corners=False).numpy()
             assert np.abs(got - tm).max() < 2e-5, (mode, size)
+    # area at integer ratios (every definition agrees there): torch's adaptive average pooling
+    img2 = rs.rand(2, 3, 36, 54).astype(np.float32)
+    for size in ((18, 27), (12, 18), (9, 27), (36, 9), (6, 6)):
+        got = D.resize(torch.from_numpy(img2).cuda(), size, "area").cpu().numpy()
+        tm = torch.nn.functional.interpolate(torch.from_numpy(img2), size=size, mode="area").numpy()
+        assert np.abs(got - tm).max() < 2e-6, size
 
 
 @pytest.mark.gpu
