@@ -123,6 +123,12 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     TS.test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch)
 
 
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_checkpoint_and_state_resume_continues_bit_for_bit(tmp_path, gaussian):
+    """save + save_training_state, the train.py resume flow on a fresh model, bit-identical continuation (emulated C ABI)."""
+    TS.test_checkpoint_and_state_resume_continues_bit_for_bit(tmp_path, gaussian)
+
+
 def test_reference_shipped_test_recipe(tmp_path):
     """options/sr/test_sr.yml (inference: is_train False, pretrained RRDB_ESRGAN_x4) over the emulated C ABI."""
     TS.test_reference_shipped_test_recipe(tmp_path)

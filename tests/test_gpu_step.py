@@ -465,6 +465,69 @@ def test_validation_forward_and_self_ensemble(tmp_path):
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("gaussian", [False, True])
+def test_checkpoint_and_state_resume_continues_bit_for_bit(tmp_path, gaussian):
+    """`save(iter)` + `save_training_state(epoch, iter)` half way, then the train.py resume flow on a fresh model (path.resume_state
+    -> options.check_resume -> create_model loads <iter>_G.pth / <iter>_D.pth -> resume_training -> update_schedulers): the resumed
+    run's next steps equal the uninterrupted run's bit for bit -- weights, Adam moments and step counts, scheduler state all travel
+    through the files (the files themselves are interchanged with the live reference in tests/test_cpu_resume_reference.py).
+    gaussian: with the ESRGAN+ noise the draw is keyed by (seed, training-forward count, block): the resumed model is told the
+    count (`_noise_calls`), as a resumed train.py run would re-seed; everything else must follow."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    kw = dict(nb=2, batch=2, crop=64, d_nf=16, gaussian=gaussian)
+    opt, a = build_engine_model(kw, tmp_path)
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in a.netG.state_dict().items()}, 101)
+    d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in a.netD.state_dict().items()}, 202)
+    f = FX.vgg_state(77)
+    load_initial(a, g, d, f)
+    a.netG.noise_seed = 4242
+
+    def steps(m, first, last):
+        logs = []
+        for s in range(first, last + 1):
+            LR, HR = detrand.synthetic_pair(2, 64, 900 + s)
+            m.feed_data({"LR": LR, "HR": HR})
+            m.optimize_parameters(s)
+            m.update_learning_rate(s, warmup_iter=-1)
+            logs.append(dict(m.get_current_log()))
+        return logs
+
+    steps(a, 1, 3)
+    a.save(3)
+    a.save_training_state(0, 3)
+    state_path = os.path.join(opt["path"]["training_state"], "3.state")
+    assert os.path.isfile(state_path)
+    logs_a = steps(a, 4, 5)
+
+    yml = ref_harness.esrgan_yaml(name="engine_case", out_root=str(tmp_path), gpu_ids="[0]", **kw)      # same experiment folders
+    txt = open(yml).read().replace("path:\n", "path:\n  resume_state: %s\n" % state_path, 1)
+    with open(yml, "w") as fh:
+        fh.write(txt)
+    ropt = options.parse(yml, is_train=True)
+    resume_state = torch.load(ropt["path"]["resume_state"], weights_only=False)
+    options.check_resume(ropt)
+    b = create_model(ropt, verbose=False)
+    netF = [l["function"].network for l in b.generatorlosses.loss_list if "fea" in l["name"]][0]
+    sd = netF.state_dict()
+    sd.update(f)
+    netF.load_state_dict(sd)
+    b.resume_training(resume_state)
+    b.update_schedulers(ropt["train"])
+    b.netG.noise_seed, b.netG._noise_calls = 4242, 3
+    logs_b = steps(b, 4, 5)
+    assert logs_a == logs_b, (logs_a, logs_b)
+    for net in ("netG", "netD"):
+        sa, sb = getattr(a, net).state_dict(), getattr(b, net).state_dict()
+        for k, v in sa.items():
+            assert torch.equal(v, sb[k]), (net, k)
+    for oa, ob in zip(a.optimizers, b.optimizers):
+        for (ka, va), (kb, vb) in zip(oa.state_dict()["state"].items(), ob.state_dict()["state"].items()):
+            assert ka == kb and float(va["step"]) == float(vb["step"]) == 5.0
+            assert torch.equal(va["exp_avg"], vb["exp_avg"]) and torch.equal(va["exp_avg_sq"], vb["exp_avg_sq"])
+    assert a.get_current_learning_rate() == b.get_current_learning_rate()
+
+
 def test_full_config_properties(tmp_path):
     """BASELINE.json configs[1] (batch 16, 128 -> 512, all losses): properties that do not need the CPU
     oracle at full size -- finiteness, run-to-run bit reproducibility, and batch linearity of the
