@@ -144,7 +144,7 @@ def shipped_recipe(tmp_path, monkeypatch):
     return yml, g
 
 
-def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
+def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch, nsteps=3, repeat=True):
     """Drop-in boundary: `options.parse` + `create_model` on the reference's shipped ESRGAN recipe, then three
     G+D steps.  The recipe says network_G: esrgan (=> gaussian_noise True, defaults.py:59), use_amp: true, network_D:
     discriminator_vgg (size = crop_size 128), batch 8, pretrain_model_G, lr_steps_rel, metrics 'psnr,ssim,lpips' (read at validation
@@ -158,7 +158,7 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
         torch.manual_seed(opt["train"]["manual_seed"])          # train.py:107 (util.set_random_seed)
         model = create_model(opt, verbose=False)
         logs = []
-        for s in (1, 2, 3):
+        for s in range(1, nsteps + 1):
             LR, HR = detrand.synthetic_pair(opt["datasets"]["train"]["batch_size"], opt["datasets"]["train"]["crop_size"], 500 + s)
             model.feed_data({"LR": LR, "HR": HR})
             model.optimize_parameters(s)
@@ -169,7 +169,7 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     assert opt["network_G"]["type"] == "rrdb_net" and opt["network_G"]["gaussian_noise"] is True and opt["network_G"]["nb"] == 23
     assert opt["network_D"]["type"] == "discriminator_vgg" and opt["network_D"]["size"] == 128 and opt["use_amp"] is True
     assert opt["train"]["lr_steps"] == [50000, 100000, 200000, 300000] and opt["datasets"]["train"]["batch_size"] == 8
-    assert model.netG.noise_sigma == 0.1 and model.netG._noise_calls == 3 and model.netG.training
+    assert model.netG.noise_sigma == 0.1 and model.netG._noise_calls == nsteps and model.netG.training
     netF = [l["function"].network for l in model.generatorlosses.loss_list if "fea" in l["name"]][0]
     assert netF.weights_source.endswith("vgg19-dcbb9e9d.pth")
     for log in logs:
@@ -178,18 +178,19 @@ def test_reference_shipped_recipe_runs_unmodified(tmp_path, monkeypatch):
     # the pretrained generator was loaded (not the kaiming init) and has been trained for three steps since
     w0 = g["model.1.sub.0.RDB1.conv1.0.weight"]
     w = model.netG.state_dict()["model.1.sub.0.RDB1.conv1.0.weight"].detach().cpu()
-    assert 0 < (w - w0).abs().max().item() <= 3.05e-4
-    _, model2, logs2 = run()
-    assert logs2 == logs
-    for k, v in model.netG.state_dict().items():
-        assert torch.equal(v, model2.netG.state_dict()[k]), k
+    assert 0 < (w - w0).abs().max().item() <= 1.02e-4 * nsteps
+    if repeat:
+        _, model2, logs2 = run()
+        assert logs2 == logs
+        for k, v in model.netG.state_dict().items():
+            assert torch.equal(v, model2.netG.state_dict()[k]), k
     # validation forward: eval() => no noise (block.py:595), deterministic
     LR, HR = detrand.synthetic_pair(1, 128, 7)
     model.feed_data({"LR": LR, "HR": HR})
     model.test()
     a = model.fake_H.clone()
     model.test()
-    assert torch.equal(a, model.fake_H) and model.netG._noise_calls == 3
+    assert torch.equal(a, model.fake_H) and model.netG._noise_calls == nsteps
 
 
 def test_reference_shipped_json_recipe(tmp_path, monkeypatch):
