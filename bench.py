@@ -325,7 +325,7 @@ def main():
         os.environ["LOCAL_RANK"] = "0"
         args.crop, args.batch, args.no_roofline, args.no_cpu_baseline = 64, 2, True, True
         device = torch.device("cpu")
-        torch.set_num_threads(4)
+        torch.set_num_threads(max(1, min(4, (os.cpu_count() or 1) // world)))
     else:
         hip.require_device()
         torch.cuda.set_device(local)
@@ -386,7 +386,7 @@ def main():
         comm = {"exposed_ms_per_step": {k: round(v / args.steps, 3) for k, v in per.items()},
                 "what": "compute-stream time between the last backward kernel and the first optimiser kernel of a network (bucket flush + wait for "
                         "the all-reduces still in flight on the side stream), rank 0",
-                "g_overlapped_with_backward": bool(ops.dense_blocks_overlap_collectives()) and os.environ.get("TNR_DP_OVERLAP_G", "auto") != "0",
+                "g_overlapped_with_backward": bool(ops.g_buckets_leave_in_backward()),
                 "dense_blocks_one_launch_next_to_collectives": ops.COUNTERS["one_launch_next_to_collectives"],
                 "dense_blocks_per_layer_next_to_collectives": ops.COUNTERS["per_layer_next_to_collectives"]}
     if world > 1:

@@ -423,6 +423,15 @@ int tnr_sumsq(const float *g, int64_t n, double *out, void *ws, void *stream);
 int tnr_clip_by_norm(float *g, int64_t n, const double *sumsq, float max_norm, void *stream);
 int tnr_adam_step(float *p, const float *g, float *m, float *v, int64_t n, float step_size, float b1,
                   float b2, float bc2_sqrt, float eps, float weight_decay, void *stream);
+/* The same update behind a guard: if *fault (a device word, see tnr_set_fault_word) is nonzero when the launch runs, p / m / v are
+ * left untouched -- a step whose activations came out of a timed-out tile hand-off is never applied. */
+int tnr_adam_step_guarded(float *p, const float *g, float *m, float *v, int64_t n, float step_size, float b1,
+                          float b2, float bc2_sqrt, float eps, float weight_decay, const uint32_t *fault, void *stream);
+/* Register ONE caller-owned, zero-initialised device word per process (one process drives one GPU) as the engine's fault latch:
+ * the one-launch dense-block kernels (tnr_conv_chain, tnr_conv_sweep) set it to 1 when a bounded wait for a neighbouring tile gives
+ * up (instead of the last word of their own workspace, which they use while no latch is registered).  Sticky: nothing in the
+ * library ever clears it.  NULL unregisters. */
+int tnr_set_fault_word(uint32_t *dev_word);
 
 #ifdef __cplusplus
 }

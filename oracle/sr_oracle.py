@@ -413,18 +413,89 @@ class OracleSRStep:
         self.opt_g.step(grads)
         # ---- D (sr_model.py:253-267, base_model.py:852-883)
         if self.d is not None:
-            for p in self.d_params:
-                p.requires_grad_(True)
-            pf = self.netD(fake.detach())                                  # losses.py:471-478
-            pr = self.netD(HR)
-            l_real, l_fake = ragan_d_loss(pf, pr)
-            l_d = (l_fake + l_real) * 0.5
-            log["l_d_real"], log["l_d_fake"] = l_real.item(), l_fake.item()
-            log["D_real"], log["D_fake"] = pr.detach().mean().item(), pf.detach().mean().item()
-            dgr = list(torch.autograd.grad(l_d, self.d_params))
-            self.last_d_grads = [g.clone() for g in dgr]
-            self.opt_d.step(dgr)
+            self.HR = HR
+            self._d_stage(fake)
         return OrderedDict(log)
+
+    def step_chunked(self, LR, HR, chunk=1):
+        """The same step (sr_model.py:195-267) for batches whose generator activations do not fit host memory (RRDBNet-23 at
+        128 -> 512 saves ~3.5 GB per image for backward; BASELINE configs[1] is batch 16).  RRDBNet has no cross-sample
+        coupling (RRDBNet_arch.py:48-60,150-163: convolutions and LeakyReLU only), so the chain rule may be cut at fake_H:
+          (i)   fake_H = G(LR) chunk by chunk without a graph;
+          (ii)  every generator loss on the FULL batch w.r.t. a leaf fake_H (the discriminator's BatchNorm statistics and the
+                relativistic means, losses.py:432-433, couple the samples there) -> dL/dfake_H;
+          (iii) per chunk: G forward with a graph, backward with that chunk's rows of dL/dfake_H injected, parameter
+                gradients summed over chunks (the only difference from `step`: the summation order of the weight gradients);
+          (iv)  clip + Adam(G), then the discriminator stage on the full batch exactly as in `step` (sr_model.py:253-267).
+        Pinned against the REAL reference's batch-2 / batch-4 goldens by tests/test_oracle_golden.py."""
+        log = self.log
+        self.HR = HR
+        N = LR.shape[0]
+        cuts = [(a, min(a + chunk, N)) for a in range(0, N, chunk)]
+        noise = self.noise
+
+        def g_chunk(a, b):
+            self.noise = None if noise is None else [m[a:b] for m in noise]
+            return self.netG(LR[a:b])
+
+        if self.d is not None:
+            for p in self.d_params:
+                p.requires_grad_(False)
+        with torch.no_grad():
+            fake = torch.cat([g_chunk(a, b) for a, b in cuts])
+        self.fake_H = fake
+        leaf = fake.clone().requires_grad_(True)
+        total = 0
+        if self.pw:
+            l_pix = self.pw * F.l1_loss(leaf, HR)
+            log["pix-l1"] = l_pix.item()
+            total = total + l_pix
+        if self.vgg is not None:
+            fx = vgg19_conv54(leaf, self.vgg)
+            fy = vgg19_conv54(HR.detach(), self.vgg)
+            l_fea = 1 * (F.l1_loss(fx, fy) * 1 * self.fw)
+            log["fea-vgg19-l1"] = l_fea.item()
+            total = total + l_fea
+            del fx, fy
+        if self.d is not None:
+            pf = self.netD(leaf)
+            pr = self.netD(HR)
+            l_gan = self.gw * ragan_g_loss(pf, pr)
+            log["l_g_gan"] = l_gan.item()
+            total = total + l_gan
+        (dfake,) = torch.autograd.grad(total, [leaf])
+        del total, leaf
+        g_params = list(self.g.values())
+        grads = [torch.zeros_like(p) for p in g_params]
+        for a, b in cuts:
+            out = g_chunk(a, b)
+            part = torch.autograd.grad(out, g_params, grad_outputs=dfake[a:b])
+            for acc, g in zip(grads, part):
+                acc.add_(g)
+            del out, part
+        self.noise = noise
+        if self.clip:
+            clip_grad_norm(grads, self.clip)
+        self.last_g_grads = [g.clone() for g in grads]
+        self.opt_g.step(grads)
+        if self.d is not None:
+            self._d_stage(fake)
+        return OrderedDict(log)
+
+    def _d_stage(self, fake):
+        """Discriminator stage (sr_model.py:253-267, base_model.py:852-883; losses.py:471-478,503-512)."""
+        log = self.log
+        for p in self.d_params:
+            p.requires_grad_(True)
+        pf = self.netD(fake.detach())
+        pr = self.netD(self.HR)
+        l_real, l_fake = ragan_d_loss(pf, pr)
+        l_d = (l_fake + l_real) * 0.5
+        log["l_d_real"], log["l_d_fake"] = l_real.item(), l_fake.item()
+        log["D_real"], log["D_fake"] = pr.detach().mean().item(), pf.detach().mean().item()
+        dgr = list(torch.autograd.grad(l_d, self.d_params))
+        self.last_d_grads = [g.clone() for g in dgr]
+        self.opt_d.step(dgr)
 
     def g_state(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.g.items())

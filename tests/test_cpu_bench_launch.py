@@ -25,3 +25,23 @@ def test_bench_self_launches_two_ranks():
     for k in ("metric", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "variant_f32_mfma"):
         assert k in j, k
     assert j["variant_f32_mfma"] is None and j["dtype"] == "f32 (bf16x3)" and j["config"]["mma"].startswith("fp32 arithmetic on the bf16 matrix core")
+
+
+def test_bench_under_the_drivers_eight_rank_launch():
+    """The scaling run's own command line at N = 8 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`), as a CPU dry run: eight ranks rendezvous, shard a global batch
+    of 8 x the per-rank batch, step the data-parallel model and rank 0 alone prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    port = 29700 + os.getpid() % 200
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                          "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["world_size_observed"] == 8 and j["config"]["parallelism"] == "dp8"
+    assert j["config"]["global_batch"] == 16 and j["scaling"] == "weak" and j["steps"] == 1 and j["warmup"] == 1
+    assert j["value"] is None and j["invalid"] == "dry run"
+    assert all(v == v for v in j["losses"].values())

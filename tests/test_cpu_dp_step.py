@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 import emul_backend
 from oracle import detrand, fixtures as FX, ref_harness
 
-KW = dict(nb=1, batch=4, crop=64, d_nf=16)
+KW = dict(nb=1, batch=int(os.environ.get("TNR_TEST_DP_BATCH", "4")), crop=64, d_nf=16)     # (the env reaches the spawned ranks)
 STEPS = 2
 BN_BIAS = None
 
@@ -85,7 +85,7 @@ def _run(model, rank=None, world=1, steps=STEPS):
 def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False, accumulate=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     try:
-        torch.set_num_threads(4)
+        torch.set_num_threads(4 if world <= 2 else 1)
         emul_backend.install()
         from trainner_amd import dp as dpmod
         dpmod.BUCKET_FLOATS = 100_000             # several buckets per network, fired from inside backward
@@ -94,7 +94,7 @@ def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False, accumulate=Fal
         build, run = (_build, lambda m: _run(m, rank, world, 2 * STEPS if accumulate else STEPS)) if kind == "sr" else (_build_i2i, _run_i2i)
         kw = dict(gaussian=gaussian, accumulate=accumulate) if kind == "sr" else {}
 
-        model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555, 202 if rank == 0 else 666, **kw)
+        model = build(os.path.join(tmp, "r%d" % rank), 101 if rank == 0 else 555 + rank, 202 if rank == 0 else 666 + rank, **kw)
         assert model.dp.active and model.dp.world_size == world
         model.sync_replicas()
         out = run(model)
@@ -110,8 +110,17 @@ def _worker(rank, world, port, tmp, q, kind="sr", gaussian=False, accumulate=Fal
             dist.destroy_process_group()
 
 
+def test_eight_rank_step_equals_single_process(tmp_path, monkeypatch):
+    """World 8 -- the node the scaling run uses (BASELINE configs[2]: batch 128 global = 16 per rank; here 16 global = 2 per rank at
+    tiny shapes): eight gloo ranks against one process for the losses, each rank's slice of fake_H, the post-step weights and the
+    ESRGAN+ noise field (rank r draws samples [2 r, 2 r + 2) of the global batch's field, `noise_sample0`)."""
+    monkeypatch.setenv("TNR_TEST_DP_BATCH", "16")
+    monkeypatch.setitem(KW, "batch", 16)
+    test_two_rank_step_equals_single_process(tmp_path, monkeypatch, "gaussian", world=8)
+
+
 @pytest.mark.parametrize("variant", ["plain", "gaussian", "accumulate"])
-def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant):
+def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant, world=2):
     """gaussian: with the ESRGAN+ noise on (the reference's default) -- every rank must draw the field of its own samples of the
     GLOBAL batch (`noise_pix0`), or the two halves of fake_H would not be the single process's.
     accumulate: virtual_batch_size = 2 x batch_size -- gradients accumulate locally over two calls and are exchanged once, before
@@ -121,29 +130,29 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31000 + (os.getpid() % 2000) + {"plain": 0, "gaussian": 7, "accumulate": 13}[variant]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q, "sr", gaussian, accumulate)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + world, str(tmp_path), q, "sr", gaussian, accumulate)) for r in range(world)]
     for p in procs:
         p.start()
     # the single-process comparator runs meanwhile: full batch, per-half-batch BatchNorm statistics
     emul_backend.install(monkeypatch)
     from trainner_amd import ops
-    f, b = emul_backend.chunked_bn(2)
+    f, b = emul_backend.chunked_bn(world)
     monkeypatch.setattr(ops, "bn_train_fwd", f)
     monkeypatch.setattr(ops, "bn_train_bwd", b)
-    torch.set_num_threads(4)
+    torch.set_num_threads(4 if world <= 2 else 1)
     single = _build(str(tmp_path / "one"), 101, 202, gaussian, accumulate)
     assert single.netG.noise_sigma == (0.1 if gaussian else 0.0) and single.accumulations == (2 if accumulate else 1)
     one = _run(single, steps=steps)
     res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    for r in (0, 1):
+    for r in range(world):
         assert res[r].endswith(".pt"), res[r]
         res[r] = torch.load(res[r], weights_only=False)
-    per = KW["batch"] // 2
+    per = KW["batch"] // world
     lr_steps = 1e-4 * STEPS
     shadow = FX.bn_shadowed_biases([(k, None) for k in one["d"]])
-    for r in (0, 1):
+    for r in range(world):
         out = res[r]
         for s in range(steps):
             for k, v in one["logs"][s].items():
@@ -171,12 +180,13 @@ def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant):
             # Adam's first steps are sign-like: an element whose gradient is at rounding-noise level can move
             # +-lr either way, so the mean is bounded tightly and the worst element loosely
             assert tot / cnt < 2e-3 and worst[0] < 1.0, (name, r, worst, tot / cnt)
-    # both replicas hold identical weights after the steps (same reduced gradients, same Adam)
-    for k, v in res[0]["g"].items():
-        assert torch.equal(v, res[1]["g"][k]), k
-    for k, v in res[0]["d"].items():
-        if ".running_" not in k and v.is_floating_point():
-            assert torch.equal(v, res[1]["d"][k]), k
+    # all replicas hold identical weights after the steps (same reduced gradients, same Adam)
+    for r in range(1, world):
+        for k, v in res[0]["g"].items():
+            assert torch.equal(v, res[r]["g"][k]), k
+        for k, v in res[0]["d"].items():
+            if ".running_" not in k and v.is_floating_point():
+                assert torch.equal(v, res[r]["d"][k]), k
 
 
 def test_two_rank_pix2pix_step_equals_single_process(tmp_path, monkeypatch):

@@ -76,7 +76,9 @@ def _launch(tmp_path, world, backend, mma, overlap="auto"):
     env["TNR_MMA"] = mma or "bf16x3"                  # the workers compute in the arithmetic this test instance runs in
     if world == 1:
         env["TNR_DP_SELFTEST"] = "1"
-    env["TNR_DP_OVERLAP_G"] = {"auto": "auto", "forced": "1", "off": "0"}[overlap]
+    env.pop("TNR_DP_OVERLAP_G", None)
+    if overlap != "default":
+        env["TNR_DP_OVERLAP_G"] = {"auto": "auto", "forced": "1", "off": "0"}[overlap]
     if overlap == "forced":
         env["TNR_CHAIN_WITH_COLLECTIVES"] = "1"       # fp32 matrix core: tnr_conv_chain stays one launch next to the collectives
     port = 29500 + (os.getpid() + world * 7 + (13 if backend == "abi" else 0)) % 1000
@@ -107,17 +109,17 @@ def _single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("overlap", ["auto", "forced", "off"])
+@pytest.mark.parametrize("overlap", ["default", "auto", "forced", "off"])
 @pytest.mark.parametrize("backend", ["torch", "abi"])
 @pytest.mark.parametrize("world", [1, 2])
 def test_rccl_ranks_equal_single_process(world, backend, overlap, tmp_path, mma_mode):
-    """overlap: how the GENERATOR's gradient buckets travel.  auto = the default policy (sr_model.backward_G): from inside its backward
-    when the dense blocks stay one launch each next to the collectives (the dispensed sweep of TNR_MMA_BF16X3), at the optimizer step
-    otherwise; forced = TNR_DP_OVERLAP_G=1 TNR_CHAIN_WITH_COLLECTIVES=1 (one-launch dense blocks next to RCCL in either arithmetic);
+    """overlap: how the GENERATOR's gradient buckets travel.  default (no TNR_DP_OVERLAP_G) = off = at the optimizer step; auto = from
+    inside its backward when the dense blocks stay one launch each next to the collectives (the dispensed sweep of TNR_MMA_BF16X3), at
+    the optimizer step otherwise; forced = TNR_DP_OVERLAP_G=1 TNR_CHAIN_WITH_COLLECTIVES=1 (one-launch dense blocks next to RCCL in either arithmetic);
     off = at the optimizer step.  The discriminator's buckets always leave from inside its backward."""
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d visible GPUs (this box has %d)" % (world, torch.cuda.device_count()))
-    if overlap != "auto" and backend == "abi":
+    if overlap != "default" and backend == "abi":
         pytest.skip("the overlap policy is independent of the communicator backend: covered with the torch group")
     one = _single_process(tmp_path)
     res = _launch(tmp_path, world, backend, mma_mode, overlap)
@@ -125,7 +127,7 @@ def test_rccl_ranks_equal_single_process(world, backend, overlap, tmp_path, mma_
     for r, out in enumerate(res):
         assert out["observed"] == world and out["backend"] == backend          # the communicator's own rank count
         sweep_mode = (mma_mode or "bf16x3") == "bf16x3"
-        if overlap == "off":
+        if overlap in ("off", "default"):
             assert out["counters"]["one_launch_next_to_collectives"] == 0 and out["counters"]["per_layer_next_to_collectives"] == 0, out["counters"]
         elif overlap == "forced" or sweep_mode:
             # G's backward ran with buckets on the wire and its dense blocks (3 forward-shaped gradient blocks per step) stayed one launch

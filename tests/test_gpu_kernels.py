@@ -798,6 +798,38 @@ def test_linear_and_losses_and_optim():
     assert (pd.cpu() - pt.detach()).abs().max().item() < 2e-7, "adam"
 
 
+def test_fault_latch_blocks_the_optimizer_step(tmp_path):
+    """The fault latch (tnr_set_fault_word): once a tile hand-off wait of a one-launch dense block has given up, every Adam launch
+    (tnr_adam_step_guarded) leaves weights and moments untouched ON THE DEVICE -- no host sync is needed to keep a faulted step from
+    being applied -- and the next host-side check (log read-out / checkpoint) raises.  The latch is set by hand here."""
+    import test_gpu_step as TS
+    n = 5000
+    p0, g0 = rnd(n, seed=60), rnd(n, seed=61) * 0.01
+    pd, gd_ = p0.to(DEV), g0.to(DEV)
+    md, vd = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    word = ops.fault_word(pd.device)
+    assert ops.chain_error_flag() == 0
+    opt, model = TS.build_engine_model(dict(nb=1, batch=2, crop=64, d_nf=16), tmp_path)
+    LR, HR = __import__("oracle.detrand", fromlist=["x"]).synthetic_pair(2, 64, 5)
+    try:
+        word.fill_(1)
+        ops.adam_step(pd, gd_, md, vd, 1e-4, 0.9, 0.999, 1.0, 1e-8)
+        assert torch.equal(pd.cpu(), p0) and float(md.abs().max()) == 0.0 and float(vd.abs().max()) == 0.0
+        before = {k: v.detach().clone() for k, v in model.netG.state_dict().items()}
+        model.feed_data({"LR": LR, "HR": HR})
+        model.optimize_parameters(1)                    # runs, but applies nothing
+        for k, v in model.netG.state_dict().items():
+            assert torch.equal(v, before[k]), k
+        with pytest.raises(hip.HipEngineError):
+            model.get_current_log()
+        with pytest.raises(hip.HipEngineError):
+            model.save(1)
+    finally:
+        word.zero_()
+    ops.adam_step(pd, gd_, md, vd, 1e-4, 0.9, 0.999, 1.0, 1e-8)
+    assert not torch.equal(pd.cpu(), p0) and ops.chain_error_flag() == 0
+
+
 @pytest.mark.parametrize("t", [0, 1, 2, 3, 4])
 def test_dense_block_gradient_pack(t):
     """tnr_pack_dense_dgrad + conv_tile == sum over consumers of conv_transpose(g_k, W_k[:, target])."""

@@ -376,6 +376,83 @@ def test_step_matches_oracle_at_benchmark_resolution(tmp_path):
         assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
 
 
+def _mem_available_gb():
+    with open("/proc/meminfo") as f:
+        for line in f:
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    return 0.0
+
+
+_HEADLINE_ORACLE = {}
+
+
+@pytest.mark.timeout(1500)
+def test_step_matches_oracle_at_headline_config(tmp_path):
+    """BASELINE.json configs[1] ITSELF: ESRGAN RRDBNet-23 + Discriminator_VGG(512) + VGG19, batch 16, 128 -> 512, one live G+D
+    step against the CPU oracle in its chunked form (OracleSRStep.step_chunked: generator backward two images at a time, every
+    batch-coupled stage -- BatchNorm statistics over 16 images, relativistic means over 16 logits, the L1 / VGG means -- on the
+    full batch; pinned to the REAL reference's batch-2 / batch-4 goldens by tests/test_oracle_golden.py).  What batch 1-4 cannot
+    show: 1 024 LR / 16 384 HR tiles dispensed to 256 workgroups, 1.07 GB tensors, BN partial counts over 16 images.
+    Bounds: DEFAULT_TOL of the golden tests for logs and the SR image, |dPSNR| <= 0.05 dB on every image of the batch,
+    post-step weights mean |dp| <= 2 % of lr, BatchNorm running statistics 2e-3."""
+    need = 24.0
+    have = _mem_available_gb()
+    if have < need:
+        pytest.skip("chunked batch-16 oracle needs ~%d GB of host memory, MemAvailable = %.1f GB" % (need, have))
+    kw = dict(nb=23, batch=16, crop=512, d_nf=64)
+    opt, model = build_engine_model(kw, tmp_path)
+    g = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netG.state_dict().items()}, 101)
+    d = detrand.fill_state_dict_({k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}, 202)
+    f = FX.vgg_state(77)
+    load_initial(model, g, d, f)
+    LR, HR = detrand.synthetic_pair(16, 512, 1600)
+    model.feed_data({"LR": LR, "HR": HR})
+    model.optimize_parameters(1)
+    log = model.get_current_log()
+    got = model.fake_H.detach().cpu()
+    gs = {k: v.detach().cpu() for k, v in model.netG.state_dict().items()}
+    ds = {k: v.detach().cpu() for k, v in model.netD.state_dict().items()}
+    del model
+    torch.cuda.empty_cache()
+    if not _HEADLINE_ORACLE:                               # once for both arithmetic modes: the oracle does not depend on them
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        orc = O.OracleSRStep(g, d, f, arch="rrdb_net", nb=23, d_size=512, d_nf=64)
+        _HEADLINE_ORACLE.update(log=orc.step_chunked(LR, HR, chunk=2), fake=orc.fake_H.detach(), g=orc.g_state(), d=orc.d_state())
+        del orc
+    ref_log, ref, og, od = (_HEADLINE_ORACLE[k] for k in ("log", "fake", "g", "d"))
+    print("headline-config logs (engine / oracle):", dict(log), dict(ref_log))
+    check_logs(log, ref_log, tol=DEFAULT_TOL["log"])
+    scale = max(1.0, ref.abs().max().item())
+    diff = (got - ref).abs()
+    assert diff.mean().item() <= DEFAULT_TOL["fake_mean"] * scale and diff.max().item() <= DEFAULT_TOL["fake_max"] * scale, \
+        (diff.mean().item(), diff.max().item())
+    for i in range(16):
+        assert abs(O.psnr_reference(got[i], HR[i]) - O.psnr_reference(ref[i], HR[i])) <= 0.05, i
+
+    def state_err(mine, theirs, skip=()):
+        tot, cnt, worst, wk = 0.0, 0, 0.0, None
+        for k, v in theirs.items():
+            if k in skip or ".running_" in k or k.endswith("num_batches_tracked"):
+                continue
+            e = (mine[k].double() - v.double()).abs() / 1e-4
+            tot, cnt = tot + e.sum().item(), cnt + e.numel()
+            if e.max().item() > worst:
+                worst, wk = e.max().item(), k
+        return tot / cnt, worst, wk
+
+    mean, worst, k = state_err(gs, og)
+    assert mean < DEFAULT_TOL["st_mean"] and worst < DEFAULT_TOL["st_worst"], ("G state", k, worst, mean)
+    mean, worst, k = state_err(ds, od, FX.bn_shadowed_biases([(k, None) for k in od]))
+    assert mean < DEFAULT_TOL["st_mean"] and worst < DEFAULT_TOL["st_worst"], ("D state", k, worst, mean)
+    for k, v in od.items():
+        if ".running_" in k:
+            e = (ds[k].double() - v.double()).abs().max().item() / max(1.0, v.abs().max().item())
+            assert e < DEFAULT_TOL["bn"], ("D running stats", k, e)
+        if k.endswith("num_batches_tracked"):
+            assert int(ds[k]) == int(v) == 4
+
+
 @pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
 def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
     """`use_amp: true` (options/sr/train_sr.yml:6): bf16 matrix-core operands, fp32 everything else.  Three G+D steps

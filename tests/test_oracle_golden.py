@@ -66,6 +66,46 @@ def test_oracle_matches_reference(case):
         assert e < 2e-3, ("D running stats", k, e)   # carries the BN-shadowed conv bias random walk
 
 
+@pytest.mark.parametrize("case,chunk", [("esrgan_nb2_crop64_gauss", 1),     # three steps, noise fields sliced per chunk
+                                        ("esrgan_nb23_crop512_b4", 2)])     # batch 4 as 2 chunks of 2
+def test_chunked_oracle_matches_reference(case, chunk):
+    """OracleSRStep.step_chunked (the form that fits BASELINE configs[1]'s batch 16 into host memory: the chain rule cut at
+    fake_H, generator backward chunk by chunk) against the REAL reference's goldens, with the bounds of
+    test_oracle_matches_reference.  The batch-16 GPU test (tests/test_gpu_step.py) rests on this pin."""
+    torch.set_num_threads(8)
+    fx = FX.load(case)
+    orc = FX.oracle_for(fx)
+    for (s, (LR, HR)), ref_log in zip(FX.batches(fx), fx["logs"]):
+        if fx["spec"].get("noise_seed") is not None:
+            from oracle import gauss_noise
+            N, _, h, w = LR.shape
+            orc.noise = [1.0 + 0.1 * gauss_noise.normals_nchw(N, 64, h, w, fx["spec"]["noise_seed"], s - 1, i) for i in range(3 * orc.nb)]
+        log = orc.step_chunked(LR, HR, chunk=chunk)
+        tol = LOG_RTOL if s <= 2 else 3e-4
+        for k, v in ref_log.items():
+            assert abs(log[k] - v) <= tol * max(1.0, abs(v)) + 2e-6, (case, s, k, log[k], v)
+        if s == 1:
+            for k, g in zip([k for k, _ in fx["g_keys"]], orc.last_g_grads):
+                e_s, e_n = FX.probe_error(g, fx["grads_step1"]["G"][k])
+                assert e_s < 2e-3 and e_n < 2e-3, (case, "G grad", k, e_s, e_n)
+            pnames = [k for k, _ in fx["d_keys"] if k in fx["grads_step1"]["D"]]
+            shadow = FX.bn_shadowed_biases(fx["d_keys"])
+            for k, g in zip(pnames, orc.last_d_grads):
+                if k not in shadow:
+                    e_s, e_n = FX.probe_error(g, fx["grads_step1"]["D"][k])
+                    assert e_s < 2e-3 and e_n < 2e-3, (case, "D grad", k, e_s, e_n)
+    ref = fx["fake_H"]
+    diff = (orc.fake_H.detach() - ref).abs()
+    assert diff.max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), diff.max().item()
+    lr_steps = 1e-4 * fx["spec"]["steps"]
+    worst, mean, k = FX.state_error(orc.g_state(), fx["g_state"], lr_steps=lr_steps)
+    assert mean < STATE_MEAN and worst < STATE_WORST, ("G state", k, worst, mean)
+    worst, mean, k = FX.state_error(orc.d_state(), fx["d_state"], FX.bn_shadowed_biases(fx["d_keys"]), lr_steps=lr_steps)
+    assert mean < STATE_MEAN and worst < STATE_WORST, ("D state", k, worst, mean)
+    e, k = FX.buffers_error(orc.d_state(), fx["d_state"])
+    assert e < 2e-3, ("D running stats", k, e)
+
+
 I2I_CASES = ["pix2pix_rn2_crop64", "pix2pix_rn1_bn_lsgan", "cyclegan_rn2_crop64", "cyclegan_rn1_noidt", "pix2pix_unet128",
              "cyclegan_rn1_relativistic"]
 

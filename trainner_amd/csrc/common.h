@@ -16,6 +16,7 @@ constexpr int TNR_PST = TNR_CK + 4;
 
 void tnr_set_error(const char *fmt, ...);
 int tnr_check_launch(const char *what);
+unsigned *tnr_fault_word_or(unsigned *fallback);      // the registered fault latch (tnr_set_fault_word), else `fallback`
 
 #define TNR_REQUIRE(cond, ...)            \
     do {                                  \

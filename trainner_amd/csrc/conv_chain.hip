@@ -377,7 +377,7 @@ extern "C" int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_
     c.progress = ws;
     c.cu_ctr = ws + (ws_bytes / 4 - 1 - 4 - CH_CU_KEYS);      // (behind the progress counters of either tile grid)
     c.tile_ctr = c.cu_ctr + CH_CU_KEYS;
-    c.err = ws + ws_bytes / 4 - 1;
+    c.err = tnr_fault_word_or(ws + ws_bytes / 4 - 1);
     c.set = (int)(epoch & 1u);
     c.base = epoch * (uint32_t)(TNR_CHAIN_MAX + 2);
     for (int i = 0; i < n; ++i) {

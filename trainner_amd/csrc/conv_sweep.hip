@@ -29,7 +29,9 @@
 // Deadlock freedom: the grid is at most one workgroup per CU and covers WHOLE images per round (dependencies never cross images).
 // Eight-wave form: tiles dealt statically, so every workgroup must be resident (a waited-for tile always belongs to a running workgroup
 // at an earlier program point).  Four-wave form: tiles DISPENSED in order from an atomic counter -- a waited-for tile was taken by a
-// workgroup that is running; progress needs only tiles_x + 2 resident workgroups.  Waits are bounded either way (error word).
+// workgroup that is running, or is the next to be dispensed.  Stage s of tile T reads stage s - 1 of tile T + tiles_x + 1, so T
+// completes once tiles up to T + 4 (tiles_x + 1) are held: progress needs 4 (tiles_x + 1) + 1 RESIDENT workgroups (21 on a 128-wide
+// image; never more than the tiles of one image, which the grid always covers), not the whole grid.  Waits are bounded either way (fault latch, tnr_set_fault_word).
 // Arithmetic (split, kept partial products and their order, channel and tap order, epilogue) is that of conv_tile_body<.., BF = 2>:
 // results are bit-identical to five tnr_conv_forward launches in TNR_MMA_BF16X3.
 #include <stddef.h>
@@ -1281,7 +1283,7 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
     c.tiles = c.tpi * d0.N;
     TNR_REQUIRE(c.tpi <= cus, "conv_sweep: the %d tiles of an image exceed the %d co-resident workgroups", c.tpi, cus);
     c.progress = ws;
-    c.err = ws + ws_bytes / 4 - 1;
+    c.err = tnr_fault_word_or(ws + ws_bytes / 4 - 1);
     static const int nxcd = [] { const char *e = getenv("TNR_SWEEP_DISPENSERS"); return e ? atoi(e) : 1; }();
     c.nxcd = nxcd == 1 ? 1 : 8;
     c.disp = ws + (ws_bytes / 4 - 1 - 4 - CH_CU_KEYS - CH_SWEEP_WORDS);      // (words of their own, zero-initialised; every launch leaves them at zero)

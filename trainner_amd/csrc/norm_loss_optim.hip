@@ -552,7 +552,8 @@ __global__ void clip_by_norm_kernel(float *g, int64_t n, const double *sumsq, fl
 }
 
 __global__ void adam_kernel(float *p, const float *g, float *m, float *v, int64_t n, float step_size, float b1, float b2,
-                            float bc2_sqrt, float eps, float wd) {
+                            float bc2_sqrt, float eps, float wd, const unsigned *fault) {
+    if (fault != nullptr && *fault != 0u) return;      // a faulted step is never applied (uniform: every thread reads the same word)
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         float gr = g[e];
         const float pv = p[e];
@@ -801,6 +802,14 @@ extern "C" int tnr_adam_step(float *p, const float *g, float *m, float *v, int64
                              float bc2_sqrt, float eps, float weight_decay, void *stream) {
     TNR_REQUIRE(p && g && m && v && n > 0, "adam: bad arguments");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, b1, b2,
-                       bc2_sqrt, eps, weight_decay);
+                       bc2_sqrt, eps, weight_decay, (const unsigned *)nullptr);
+    return tnr_check_launch("adam");
+}
+
+extern "C" int tnr_adam_step_guarded(float *p, const float *g, float *m, float *v, int64_t n, float step_size, float b1, float b2,
+                                     float bc2_sqrt, float eps, float weight_decay, const uint32_t *fault, void *stream) {
+    TNR_REQUIRE(p && g && m && v && n > 0, "adam: bad arguments");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, b1, b2,
+                       bc2_sqrt, eps, weight_decay, (const unsigned *)fault);
     return tnr_check_launch("adam");
 }

@@ -22,6 +22,13 @@ int tnr_check_launch(const char *what) {
 }
 
 extern "C" const char *tnr_last_error(void) { return g_err; }
+
+static unsigned *g_fault_word = nullptr;
+unsigned *tnr_fault_word_or(unsigned *fallback) { return g_fault_word ? g_fault_word : fallback; }
+extern "C" int tnr_set_fault_word(uint32_t *dev_word) {
+    g_fault_word = dev_word;
+    return TNR_OK;
+}
 extern "C" int tnr_version(void) { return 1; }
 
 extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t kind, int32_t *KoutP,

@@ -151,6 +151,8 @@ _SIGS = {
     "tnr_sumsq": (c_i, [c_p, c_l, c_p, c_p, c_p]),
     "tnr_clip_by_norm": (c_i, [c_p, c_l, c_p, c_f, c_p]),
     "tnr_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+    "tnr_adam_step_guarded": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "tnr_set_fault_word": (c_i, [c_p]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -125,12 +125,13 @@ class BaseModel:
         return str(network), sum(p.numel() for p in network.parameters())
 
     def check_engine_errors(self):
-        """Cheap host-side check at points that synchronise anyway (log read-out, checkpoint): a tnr_conv_chain
-        dependency wait that timed out computed with unpublished neighbour tiles -- the step is invalid, so a
-        training run stops here instead of continuing on corrupted activations."""
+        """Host-side read of the fault latch (ops.fault_word) at points that synchronise anyway (log read-out, checkpoint).  A tile
+        hand-off wait of a one-launch dense block that timed out computed with unpublished neighbour tiles: the latch is sticky and
+        every Adam launch runs behind it ON THE DEVICE (tnr_adam_step_guarded), so no optimiser step is applied from the faulted
+        launch on -- the weights here are those of the last healthy step -- and the run stops at this check."""
         if ops.chain_error_flag():
-            raise hip.HipEngineError("a tnr_conv_chain dependency wait timed out (another tenant on the GPU kept the "
-                                     "grid from being co-resident?): results since the last check are invalid; set "
+            raise hip.HipEngineError("a tile hand-off wait inside a one-launch dense block timed out (another tenant on the GPU kept "
+                                     "the workgroups from being resident?): no optimiser step has been applied since; restart with "
                                      "TNR_CONV_CHAIN=0 to run one launch per layer")
 
     # ------------------------------------------------------------------ checkpoints

@@ -90,14 +90,14 @@ class SRModel(BaseModel):
             l_g_gan = self.adversarial(self.fake_H, self.var_ref, netD=self.netD, stage="generator", fsfilter=self.f_high)
             self.log_dict["l_g_gan"] = l_g_gan.detach()
             l_g_total = l_g_total + (l_g_gan if self.accumulations == 1 else l_g_gan / self.accumulations)
-        # G's gradient buckets (67 MB) leave for RCCL from inside its backward, on the side stream (north star; SURVEY.md 8(e) collective 1),
-        # whenever the dense blocks can stay one launch each next to the collectives -- the dispensed four-wave sweep of the default
-        # arithmetic does (ops.dense_blocks_overlap_collectives).  Where they cannot (tnr_conv_chain: fp32 matrix core, use_amp), the
-        # per-layer fallback would cost the trunk's backward more (~8 ms) than the overlap hides (~1 ms of xGMI time): there the buckets
-        # go out in one sweep at the optimizer step (_sync_gradients).  TNR_DP_OVERLAP_G=1 / 0 forces either.
+        # G's gradient buckets (67 MB) CAN leave for RCCL from inside its backward, on the side stream, with the dense blocks staying one
+        # launch each next to the collectives (the dispensed four-wave sweep, ops.g_buckets_leave_in_backward).  That combination --
+        # tile hand-offs inside a launch while RCCL kernels that wait for PEERS hold CUs -- has never run on more than one GPU, so it is
+        # opt-in (TNR_DP_OVERLAP_G=auto / 1) and the default sends G's buckets in one sweep at the optimizer step (_sync_gradients; about
+        # 1 ms of exposed xGMI time per 238 ms step).  D's buckets (110 MB, the larger share) always leave inside its backward: the
+        # discriminator has no one-launch dense blocks.
         from .. import ops
-        want = os.environ.get("TNR_DP_OVERLAP_G", "auto")
-        if want == "1" or (want == "auto" and ops.dense_blocks_overlap_collectives()):
+        if ops.g_buckets_leave_in_backward():
             self._arm_bucket_schedule([self.netG], passes=1)
         self.calc_gradients(l_g_total)
 

@@ -380,6 +380,15 @@ def dense_blocks_overlap_collectives():
     sweep of TNR_MMA_BF16X3, or TNR_CHAIN_WITH_COLLECTIVES=1): the generator's all-reduce can then overlap its backward for free."""
     return CHAIN_WITH_COLLECTIVES or (CONV_CHAIN and CONV_SWEEP and SWEEP_DISPENSED and
                                       ((CHAIN_X3 and MMA == hip.MMA_BF16X3) or (AMP_SWEEP and MMA == hip.MMA_BF16)))
+
+
+def g_buckets_leave_in_backward():
+    """TNR_DP_OVERLAP_G: 0 (default) = the generator's gradient buckets go out at its optimizer step; auto = from inside its backward
+    whenever the dense blocks stay one launch next to them; 1 = from inside its backward regardless (per-layer launches where needed)."""
+    want = os.environ.get("TNR_DP_OVERLAP_G", "0")
+    return want == "1" or (want == "auto" and dense_blocks_overlap_collectives())
+
+
 _chain_epoch = {}
 _sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
 
@@ -417,8 +426,11 @@ def conv_chain(stages):
     assert 1 <= n <= CHAIN_MAX
     eligible = all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages)
     # gradient buckets on the wire: tnr_conv_chain (and the eight-wave sweep) need their whole grid co-resident, which RCCL's
-    # kernels on the same CUs could delay -> one launch per layer meanwhile.  The four-wave sweep DISPENSES its tiles (a waited-for
-    # tile always belongs to a running workgroup; tiles_x + 2 resident workgroups are enough): it stays one launch.
+    # kernels on the same CUs could delay -> one launch per layer meanwhile.  The four-wave sweep DISPENSES its tiles in order (a
+    # waited-for tile was either taken by a running workgroup or is the next to be dispensed).  Stage s of tile T reads stage s - 1 of
+    # T + tiles_x + 1, so T finishes its five stages once tiles up to T + 4 (tiles_x + 1) are held: 4 (tiles_x + 1) + 1 resident
+    # workgroups guarantee progress (21 on the 128-wide trunk, never more than the tiles of one image): it may
+    # stay one launch -- opt-in (TNR_DP_OVERLAP_G=1, models/sr_model.py) until a multi-GPU run has exercised it.
     crowded = COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES
     sweep_ok = CONV_SWEEP and n == 5 and ((MMA == hip.MMA_BF16X3 and CHAIN_X3) or (MMA == hip.MMA_BF16 and AMP_SWEEP))
     if not CONV_CHAIN or not eligible or (crowded and not (sweep_ok and SWEEP_DISPENSED)):
@@ -440,6 +452,7 @@ def conv_chain(stages):
         fresh[i] = -1 if ff is None else ff
         flops += 2.0 * st["y"].pixels * 9 * min(st["x"].C, st["wp"].KinP) * st["y"].C
     dev = stages[0]["x"].buf.device
+    fault_word(dev)
     need = lib.tnr_conv_chain_workspace_bytes(C.byref(descs[0]))
     key = ("chain", str(dev), hip.stream(), need)    # one counter set per (stream, tile grid)
     ws = WS.bufs.get(key)
@@ -471,10 +484,24 @@ def conv_chain(stages):
         PROFILE.end("conv_chain", flops, t0, (x0.C, yl.C, yl.H, stages[0]["wp"].kind))
 
 
+_FAULT = None
+
+
+def fault_word(device=None):
+    """The engine's fault latch: one zero-initialised device word, registered with the library (tnr_set_fault_word) before the first
+    one-launch dense block runs.  A bounded tile hand-off wait that gives up sets it; it is never cleared.  adam_step() launches
+    behind it (a faulted step is not applied) and check_engine_errors() raises on it at the next host synchronisation."""
+    global _FAULT
+    if _FAULT is None:
+        _FAULT = torch.zeros(1, dtype=torch.int32, device=device if device is not None else hip.engine_device())
+        hip.check(hip.load().tnr_set_fault_word(_FAULT.data_ptr()), "set_fault_word")
+    return _FAULT
+
+
 def chain_error_flag():
-    """Nonzero if a tnr_conv_chain dependency wait ever gave up in this process (checked by tests / smoke)."""
-    bad = 0
-    for key, ws in WS.bufs.items():
+    """Nonzero if a tile hand-off wait of tnr_conv_chain / tnr_conv_sweep ever gave up in this process (one host sync)."""
+    bad = 0 if _FAULT is None else int(_FAULT.item() != 0)
+    for key, ws in WS.bufs.items():       # (workspace tail words: only written while no latch was registered)
         if isinstance(key, tuple) and key[0] == "chain":
             bad += int(ws[-1].item() != 0)
     return bad
@@ -837,5 +864,7 @@ def clip_by_norm(g, sumsq_t, max_norm):
 
 
 def adam_step(p, g, m, v, step_size, b1, b2, bc2_sqrt, eps, wd=0.0):
-    hip.check(hip.load().tnr_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), step_size, b1,
-                                       b2, bc2_sqrt, eps, wd, hip.stream()), "adam_step")
+    """One Adam launch over a flat buffer, behind the fault latch: if a tile hand-off of this process ever timed out, the update is
+    NOT applied (the weights stay those of the last healthy step until check_engine_errors() raises)."""
+    hip.check(hip.load().tnr_adam_step_guarded(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), step_size, b1,
+                                               b2, bc2_sqrt, eps, wd, fault_word(p.device).data_ptr(), hip.stream()), "adam_step")
