@@ -237,6 +237,54 @@ def pmc_traffic(family="conv_tile_3x3", mode=None):
         return None, None
 
 
+def pmc_family_records(mode):
+    """(mfma_busy record, traffic record) of this matrix-core mode -- the newest committed profiles/*_pmc_{mfma_busy,traffic}_<mode>.json
+    whose kernel-source stamp is this tree's (else None): per-family entries keyed like ops.ConvProfile's families (tools/pmc_families.py)."""
+    import glob
+    out = []
+    for kind in ("mfma_busy", "traffic"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_%s_%s.json" % (kind, mode))))
+        rec = None
+        if files:
+            try:
+                with open(files[-1]) as fh:
+                    rec = json.load(fh)
+                if not _pmc_record_current(rec):
+                    rec = None
+                else:
+                    rec["_file"] = os.path.relpath(files[-1], ROOT)
+            except (OSError, ValueError):
+                rec = None
+        out.append(rec)
+    return out
+
+
+def family_table(summ, nprof, peak, mode, sustained=None):
+    """roofline.families: EVERY matrix-core kernel family of the step, so that the whole MFMA share of the step can be re-derived from
+    this line alone: HIP-event time and algorithmic FLOP of its launches (ops.ConvProfile, the instrumented pass), TFLOP/s, fraction of
+    the mode's dense peak (and of the sustained ceiling where one is measured), and -- from the committed PMC passes of this command on
+    these kernel sources -- MFMA-busy and HBM bytes per launch (None when no current record exists)."""
+    busy, traffic = pmc_family_records(mode)
+    fams = {}
+    for name, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+        if v["ms"] <= 0 or v["flops"] <= 0:
+            continue
+        tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        vector_alu = name in ("conv_thin", "wgrad_thin")          # 3-channel sides: no matrix instruction in these kernels
+        e = {"ms_per_step": round(v["ms"] / nprof, 3), "launches_per_step": v["launches"] // nprof,
+             "flop_per_step": v["flops"] / nprof, "tflops": round(tf, 2),
+             "frac": None if vector_alu else round(tf / peak, 4),
+             "mfma_busy": None if (busy is None or name not in busy) else busy[name]["mfma_busy"],
+             "traffic": None if (traffic is None or name not in traffic) else round(traffic[name]["hbm_bytes_per_launch"])}
+        if sustained and not vector_alu:
+            e["frac_of_sustained_mfma"] = round(tf / sustained, 4)
+        if vector_alu:
+            e["note"] = "vector-ALU kernel (<= 4 channels on one side): HBM-bound, no MFMA roofline"
+        fams[name] = e
+    return {"families": fams, "families_mfma_ms_per_step": round(sum(e["ms_per_step"] for e in fams.values()), 2),
+            "families_counters_source": {"mfma_busy": busy and busy["_file"], "traffic": traffic and traffic["_file"]}}
+
+
 def _source_hash():
     from trainner_amd.build import source_hash
     return source_hash()
@@ -449,6 +497,8 @@ def main():
                     "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                     "flop_per_launch_avg": dom["flops"] / dom["launches"],
                     "kernel_ms_per_step": per_step_ms}
+            roof.update(family_table(summ, nprof, peak, "bf16x3amp" if args.amp else args.mma,
+                                     307.8 if (args.mma == "bf16x3" and not args.amp) else None))
             if args.amp:
                 kname = "conv_sweep4_kernel<true, true> (a dense block's 5 convolutions per launch, bf16 operands)" if (fam == "conv_chain" and ops.CONV_SWEEP and ops.AMP_SWEEP) else kname
                 roof["kernel"] = kname

@@ -803,6 +803,8 @@ def test_fault_latch_blocks_the_optimizer_step(tmp_path):
     (tnr_adam_step_guarded) leaves weights and moments untouched ON THE DEVICE -- no host sync is needed to keep a faulted step from
     being applied -- and the next host-side check (log read-out / checkpoint) raises.  The latch is set by hand here."""
     import test_gpu_step as TS
+    from trainner_amd import hip
+    ops = _ops()
     n = 5000
     p0, g0 = rnd(n, seed=60), rnd(n, seed=61) * 0.01
     pd, gd_ = p0.to(DEV), g0.to(DEV)

@@ -157,6 +157,22 @@ def main():
     log = model.get_current_log()
     imgs = args.batch * args.steps
     fl = step_flop(args.model, args.size)
+    # instrumented pass (HIP events around every convolution-family launch on the launch stream), as in bench.py
+    sys.path.insert(0, ROOT)
+    import bench as B
+    prof = ops.ConvProfile()
+    ops.PROFILE = prof
+    for _ in range(2):
+        step += 1
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    ops.PROFILE = None
+    summ = prof.summary()
+    mode = "bf16x3amp" if args.amp else ("bf16x3" if ops.MMA == hip.MMA_BF16X3 else "f32")
+    peak = 2516.6 if args.amp else (2516.6 / 6.0 if ops.MMA == hip.MMA_BF16X3 else 157.3)
+    fam_tab = B.family_table(summ, 2, peak, "i2i_%s_%s_%s" % (args.model, args.netg, mode), 307.8 if mode == "bf16x3" else None)
+    dom_name = max((f for f in summ if f not in ("conv_thin", "wgrad_thin", "gconv")), key=lambda f: summ[f]["ms"])
+    dom = fam_tab["families"][dom_name]
     print(json.dumps({
         "metric": "images/sec (G+D step), %s %dx%d" % (args.model, args.size, args.size), "value": round(imgs / dt, 2), "unit": "img/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
@@ -168,10 +184,15 @@ def main():
         "conv_gflop_per_img": round(fl / 1e9, 1) if args.netg == "resnet" else None,
         "step_tflops": round(fl * imgs / dt / 1e12, 2) if args.netg == "resnet" else None,
         # the same convention as bench.py's roofline: fp32-equivalent ceiling of the split arithmetic = bf16 dense peak / 6
-        "roofline": ({"bound": "mfma", "achieved": round(fl * imgs / dt / 1e12, 2), "unit": "TFLOP/s",
-                      "peak": round((2516.6 if args.amp else (2516.6 / 6.0 if ops.MMA == hip.MMA_BF16X3 else 157.3)), 1),
-                      "frac": round(fl * imgs / dt / 1e12 / (2516.6 if args.amp else (2516.6 / 6.0 if ops.MMA == hip.MMA_BF16X3 else 157.3)), 4),
-                      "scope": "whole step (every convolution of G and D, forward and both gradients; wall clock)"} if args.netg == "resnet" else None),
+        # the dominant MATRIX-CORE kernel family of this step (bench.py's convention: algorithmic FLOP of its launches / their HIP-event time,
+        # against the mode's dense peak; fp32-equivalent ceiling of the split arithmetic = bf16 dense peak / 6), every family beside it,
+        # and the whole step's wall-clock view where the step's FLOP are counted (ResNet generator)
+        "roofline": dict({"bound": "mfma", "kernel": dom_name, "achieved": dom["tflops"], "unit": "TFLOP/s", "peak": round(peak, 1), "frac": dom["frac"],
+                          "frac_of_sustained_mfma": dom.get("frac_of_sustained_mfma"), "mfma_busy": dom["mfma_busy"], "traffic": dom["traffic"],
+                          "launches_per_step": dom["launches_per_step"],
+                          "whole_step": ({"achieved": round(fl * imgs / dt / 1e12, 2), "frac": round(fl * imgs / dt / 1e12 / peak, 4),
+                                          "scope": "every convolution of G and D, forward and both gradients; wall clock"} if args.netg == "resnet" else None)},
+                         **fam_tab),
         "losses": {k: round(v, 5) for k, v in log.items()}}))
 
 

@@ -12,8 +12,7 @@ def main(summary_csv, out_json):
     with open(summary_csv) as fh:
         for r in csv.DictReader(fh):
             per.setdefault(r["kernel"], {})[r["counter"]] = (int(r["dispatches"]), float(r["total"]))
-    fams = {"conv_tile_3x3": ("conv_tile_kernel<0,", "conv3x3_x3w8_kernel", "conv3x3_d4_kernel"), "conv_chain": ("conv_chain_kernel", "conv_sweep_kernel", "conv_sweep4_kernel"),
-            "wgrad_tile": ("wgrad_tile_kernel",)}
+    from pmc_families import FAMILIES as fams
     out = {"source": summary_csv, "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)", "kernels": {}}
     acc = {k: [0.0, 0.0, 0] for k in fams}
     for k, c in per.items():

@@ -1,0 +1,13 @@
+"""Kernel-name prefixes of the MFMA kernel families bench.py's `roofline.families` reports (ops.ConvProfile family names), shared by
+tools/pmc_busy.py and tools/pmc_traffic.py so that every family of the driver's line has its counters in the committed PMC records."""
+FAMILIES = {
+    # the dense-block launches: conv_chain_kernel (fp32 matrix core) or conv_sweep4_kernel / conv_sweep_kernel (bf16x3, use_amp)
+    "conv_chain": ("conv_chain_kernel", "conv_sweep_kernel", "conv_sweep4_kernel"),
+    "conv_tile_3x3": ("conv_tile_kernel<0,", "conv3x3_x3w8_kernel", "conv3x3_d4_kernel"),
+    "conv_tile_3x3_up2": ("conv_tile_kernel<1,",),
+    "conv_tile_4x4s2": ("conv_tile_kernel<2,",),
+    "conv_tile_dgrad4x4s2": ("conv_tile_kernel<3,",),
+    "conv_tile_1x1": ("conv_tile_kernel<4,",),
+    "conv_tile_3x3_c4": ("conv_tile_kernel<5,",),
+    "wgrad_tile": ("wgrad_tile_kernel",),
+}

@@ -20,8 +20,8 @@ def read(path, counter):
 def main(fetch_csv, write_csv, out_json):
     f, w = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
     kernels = {}
-    # family "conv_chain" = the dense-block launches: conv_chain_kernel (fp32 matrix core) or conv_sweep4_kernel / conv_sweep_kernel (bf16x3)
-    fams = {"conv_tile_3x3": [("conv_tile_kernel<0,", "conv3x3_x3w8_kernel", "conv3x3_d4_kernel"), 0.0, 0], "conv_chain": [("conv_chain_kernel", "conv_sweep_kernel", "conv_sweep4_kernel"), 0.0, 0]}
+    from pmc_families import FAMILIES
+    fams = {name: [prefixes, 0.0, 0] for name, prefixes in FAMILIES.items()}
     for k in f:
         if k not in w:
             continue

@@ -684,22 +684,31 @@ def mask_copy(dst, src, y, mslope=0.2):
 def gconv_fwd(x, w, y, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, slope=0.2):
     """y = act(conv(x, w) + bias): any square kernel / stride, zero or reflection padding (tnr_gconv_fwd); w OIHW."""
     Cout, Cin, k, _ = w.shape
+    t0 = PROFILE.begin() if PROFILE is not None else None
     hip.check(hip.load().tnr_gconv_fwd(x.c(), x.N, x.H, x.W, Cin, w.data_ptr(), hip.ptr(bias), y.c(), y.H, y.W, Cout, k, stride, pad,
                                        int(reflect), act, slope, hip.stream()), "gconv_fwd")
+    if PROFILE is not None:
+        PROFILE.end("gconv", 2.0 * y.pixels * k * k * Cin * Cout, t0, (Cin, Cout, y.H, k))
 
 
 def gconv_dgrad(g, w, gx, stride=1, pad=0, reflect=False):
     Cout, Cin, k, _ = w.shape
+    t0 = PROFILE.begin() if PROFILE is not None else None
     hip.check(hip.load().tnr_gconv_dgrad(g.c(), gx.N, gx.H, gx.W, Cin, w.data_ptr(), gx.c(), g.H, g.W, Cout, k, stride, pad, int(reflect),
                                          hip.stream()), "gconv_dgrad")
+    if PROFILE is not None:
+        PROFILE.end("gconv", 2.0 * g.pixels * k * k * Cin * Cout, t0, (Cin, Cout, g.H, k + 100))
 
 
 def gconv_wgrad(x, g, dw, db=None, stride=1, pad=0, reflect=False, alpha=1.0, beta=1.0):
     Cout, Cin, k, _ = dw.shape
     lib = hip.load()
     ws = WS.get("gconv_wgrad@%x" % hip.stream(), lib.tnr_gconv_wgrad_workspace_bytes(Cout, Cin, k), x.buf.device)
+    t0 = PROFILE.begin() if PROFILE is not None else None
     hip.check(lib.tnr_gconv_wgrad(x.c(), x.N, x.H, x.W, Cin, g.c(), g.H, g.W, Cout, k, stride, pad, int(reflect), dw.data_ptr(), hip.ptr(db),
                                   alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "gconv_wgrad")
+    if PROFILE is not None:
+        PROFILE.end("gconv", 2.0 * g.pixels * k * k * Cin * Cout, t0, (Cin, Cout, g.H, k + 200))
 
 
 def bias_grad(g, db, alpha=1.0, beta=1.0):
