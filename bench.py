@@ -401,7 +401,7 @@ def main():
             degrade = RealESRGANDegradation(scale=4, seed=rank)
         feeder = DeviceFeeder(HostBatches(args.warmup + args.steps, args.batch, args.crop, 1000 + rank, args.feed == "paired"),
                               device=device, degrade=degrade)
-        batches = iter(feeder)
+        batches = feeder.iterate()
 
     last_batch = [None]
 
@@ -441,6 +441,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    if feeder is not None:
+        feeder.close()
     log = model.get_current_log()
     if ops.chain_error_flag():
         raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")

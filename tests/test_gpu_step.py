@@ -127,7 +127,13 @@ def shipped_recipe(tmp_path, monkeypatch):
     filesystem locations re-rooted, oracle/make_golden_options.py) plus the two files it expects on disk: the pretrained generator
     `experiments/pretrained_models/RRDB_PSNR_x4.pth` (here a seeded RRDBNet-23 state_dict in the reference's legacy checkpoint format,
     base_model.py:364-375) and torchvision's cached ImageNet VGG19 (here seeded weights under torchvision's file name in $TORCH_HOME)."""
+    import sys
     root = str(tmp_path)
+    # (a test that ran the live reference earlier in this process leaves oracle/stubs' torchvision importable: the recipe must take the
+    #  cached-file route whatever ran before)
+    for name in [m for m in sys.modules if m == "torchvision" or m.startswith("torchvision.")]:
+        monkeypatch.setitem(sys.modules, name, None)
+    monkeypatch.setitem(sys.modules, "torchvision", None)
     yml = FX.write_recipe("sr/train_sr.yml", root)
     g = FX.initial_state(FX.load("esrgan_nb23_crop128")["g_keys"], 101)
     os.makedirs(os.path.join(root, "experiments", "pretrained_models"))
@@ -279,12 +285,11 @@ def test_step_gate_pinned_fp64_trajectory(tmp_path, gaussian):
         dsd = {k: v.detach().cpu().clone() for k, v in model.netD.state_dict().items()}
 
         def moments(optim, net):
-            m, v, t = {}, {}, 0
+            m, v, t = {}, {}, optim.group_steps()[0]
             for k, p in net.named_parameters():
                 st = optim.state.get(p, {})
                 m[k] = st["exp_avg"].detach().cpu().clone() if "exp_avg" in st else torch.zeros_like(p, device="cpu")
                 v[k] = st["exp_avg_sq"].detach().cpu().clone() if "exp_avg_sq" in st else torch.zeros_like(p, device="cpu")
-                t = int(float(st["step"])) if "step" in st else 0
             return m, v, t
 
         state = {"G": moments(model.optimizer_G, model.netG), "D": moments(model.optimizer_D, model.netD)}

@@ -161,6 +161,7 @@ class DeviceFeeder:
         launches the training step.  The consumer hands a slot back (with a fresh `free` event) when it returns for the next batch."""
         import queue
         import threading
+        hip.load()                          # the library handle is created on THIS thread, before the worker can race for it
         todo, done = queue.Queue(), queue.Queue()
         STOP = object()
 
@@ -209,6 +210,19 @@ class DeviceFeeder:
             worker.join()
             for q in out:
                 self._mark_free(q)
+
+    def iterate(self):
+        """iter(self), remembered so that close() can end it (bench / trainer: an abandoned iterator would only be torn down at
+        garbage collection or interpreter exit, where its `finally` would make runtime calls)."""
+        self.close()
+        self._active = iter(self)
+        return self._active
+
+    def close(self):
+        """Stop the worker thread of the iterator handed out by iterate() and release its slots (idempotent)."""
+        it, self._active = getattr(self, "_active", None), None
+        if it is not None:
+            it.close()                      # GeneratorExit at the yield -> the generator's `finally`
 
     def _mark_free(self, s):
         if s.free is None:

@@ -184,6 +184,12 @@ class BaseModel:
             return
         state = {"epoch": epoch, "iter": iter_step, "schedulers": [s.state_dict() for s in self.schedulers],
                  "optimizers": [o.state_dict() for o in self.optimizers]}
+        # engine-only entry (the reference's resume reads the four keys above and ignores the rest): the position of every network's
+        # counter-based ESRGAN+ noise stream, so that a resumed run continues the stream instead of replaying it from forward 0
+        noise = {name: [getattr(getattr(self, "net" + name), "_noise_calls"), getattr(getattr(self, "net" + name), "noise_seed")]
+                 for name in self.model_names if hasattr(getattr(self, "net" + name), "_noise_calls")}
+        if noise:
+            state["tnr_engine"] = {"noise_streams": noise}
         fname = "latest.state" if latest else "{}.state".format(iter_step)
         save_path = os.path.join(self.opt["path"]["training_state"], fname)
         os.makedirs(os.path.dirname(save_path), exist_ok=True)
@@ -201,6 +207,12 @@ class BaseModel:
             if hasattr(s, "milestones") and isinstance(s.milestones, Counter) and isinstance(st.get("milestones"), list):
                 st["milestones"] = Counter(st["milestones"])
             s.load_state_dict(st)
+        for name, (calls, seed) in (resume_state.get("tnr_engine") or {}).get("noise_streams", {}).items():
+            net = getattr(self, "net" + name, None)
+            if net is not None and hasattr(net, "_noise_calls"):
+                net._noise_calls = int(calls)
+                if seed is not None and net.noise_seed is None:
+                    net.noise_seed = int(seed)
         self.sync_replicas()
 
     def update_schedulers(self, train_opt):
@@ -382,7 +394,19 @@ class BaseModel:
         for o in self.optimizers:
             for mv in getattr(o, "_moments", {}).values():
                 tensors += list(mv)
+        # ESRGAN+ noise: ONE stream for all replicas (each rank draws the field of its own samples of the global batch): rank 0's
+        # seed -- torch.initial_seed() differs per rank when manual_seed is unset -- and rank 0's position in the stream
+        noisy = [getattr(self, "net" + n) for n in self.model_names if hasattr(getattr(self, "net" + n), "_noise_calls")]
+        dev = tensors[0].device
+        meta = torch.tensor([v for net in noisy for v in ((torch.initial_seed() if net.noise_seed is None else int(net.noise_seed)) & ((1 << 62) - 1),
+                                                              net._noise_calls)], dtype=torch.int64, device=dev) if noisy else None
+        if meta is not None:
+            tensors.append(meta)
         self.dp.broadcast_from_rank0(tensors)
+        if meta is not None:
+            vals = meta.cpu().tolist()
+            for i, net in enumerate(noisy):
+                net.noise_seed, net._noise_calls = int(vals[2 * i]), int(vals[2 * i + 1])
         for name in self.model_names:
             getattr(self, "net" + name).flat_params().touch()
 

@@ -32,6 +32,8 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._moments = {}     # id(FlatParams) -> (exp_avg_flat, exp_avg_sq_flat)
+        self._t = {}           # group index -> optimiser steps taken (ONE host counter per group; the per-parameter `step` tensors of
+                               # torch.optim.Adam's layout exist only in state_dict(), where the reference resuming from it needs them)
 
     def _holders(self, group):
         """The distinct flat buffers the group's parameters live in (insertion ordered)."""
@@ -62,17 +64,15 @@ class FusedAdam(torch.optim.Optimizer):
                     if old_m is not None:          # state arrived through load_state_dict
                         st["exp_avg"].copy_(old_m)
                         st["exp_avg_sq"].copy_(old_v)
-                    if "step" not in st:
-                        st["step"] = torch.tensor(0.0)
 
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closures are not supported")
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             self._ensure_state(group)
             b1, b2 = group["betas"]
-            t = int(float(self.state[group["params"][0]]["step"])) + 1   # one counter per group
+            t = self._t.get(gi, 0) + 1
             bc1 = 1.0 - b1 ** t
             bc2 = 1.0 - b2 ** t
             for holder in self._holders(group):
@@ -80,10 +80,23 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_step(holder.flat, holder.grad, m, v, group["lr"] / bc1, b1, b2, math.sqrt(bc2), group["eps"],
                               group["weight_decay"])
                 holder.touch()                       # packed weights of this network are stale now
-            # one tensor PER parameter: torch.optim.Adam (the reference resuming from this state, base_model.py:479-491) increments
-            # each entry in place, and torch.save keeps aliasing -- a shared tensor would be bumped once per parameter per step
+            self._t[gi] = t
+
+    def group_steps(self):
+        """Optimiser steps taken, per parameter group."""
+        return [self._t.get(gi, 0) for gi in range(len(self.param_groups))]
+
+    def state_dict(self):
+        """torch.optim.Adam's layout.  `step` is materialised here, one tensor PER parameter: torch.optim.Adam (the reference resuming
+        from this state, base_model.py:479-491) increments each entry in place and torch.save keeps aliasing -- a shared tensor would be
+        bumped once per parameter per step."""
+        for gi, group in enumerate(self.param_groups):
+            if self._moments or gi in self._t:
+                self._ensure_state(group)
             for p in group["params"]:
-                self.state[p]["step"] = torch.tensor(float(t))
+                if p in self.state and "exp_avg" in self.state[p]:
+                    self.state[p]["step"] = torch.tensor(float(self._t.get(gi, 0)))
+        return super().state_dict()
 
     def zero_grad(self, set_to_none=False):
         """Zero the flat gradient buffers in place (views stay attached to the parameters)."""
@@ -95,7 +108,13 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._moments = {}       # re-home the loaded moments into flat buffers on next use
-        for group in self.param_groups:
+        self._t = {}
+        for gi, group in enumerate(self.param_groups):
+            steps = {int(float(self.state[p]["step"])) for p in group["params"] if p in self.state and "step" in self.state[p]}
+            if len(steps) > 1:
+                raise ValueError("FusedAdam: the parameters of one group carry different step counts %s" % sorted(steps))
+            if steps:
+                self._t[gi] = steps.pop()
             self._ensure_state(group)
 
 

@@ -324,10 +324,17 @@ def _wq_image(lib, d, wp, dev):
         return None
     owner = wp.owner
     cache, gen = (_wq_oneoff, None) if owner is None else (owner.__dict__.setdefault("_wq_images", {}), owner.gen)
-    key = wp.t.data_ptr()
+    # one-off packs (no owning packer): an image per (packed weights, stream) -- it is re-packed on every call on the CURRENT stream,
+    # so two streams must not share one -- and at most 64 of them (least recently used out: the addresses change as tensors come and go)
+    key = wp.t.data_ptr() if owner is not None else (wp.t.data_ptr(), hip.stream())
     ent = cache.get(key)
+    if owner is None and ent is not None:
+        cache[key] = cache.pop(key)          # most recently used last
     if ent is None or ent[0].numel() * 4 < need:
         ent = cache[key] = [torch.empty(need // 4, dtype=torch.float32, device=dev), None]
+        if owner is None:
+            while len(cache) > 64:
+                cache.pop(next(iter(cache)))
     if gen is None or ent[1] != gen:
         hip.check(lib.tnr_conv_wq_pack(C.byref(d), ent[0].data_ptr(), need, hip.stream()), "conv_wq_pack")
         ent[1] = gen
@@ -406,10 +413,15 @@ def _sweep_image(lib, descs, n, stages, dev):
     else:
         cache = owner.__dict__.setdefault("_sweep_images", {})
         gen = owner.gen
-    key = tuple(st["wp"].t.data_ptr() for st in stages)
+    key = tuple(st["wp"].t.data_ptr() for st in stages) + (() if owner is not None else (hip.stream(),))
     ent = cache.get(key)
+    if owner is None and ent is not None:
+        cache[key] = cache.pop(key)          # one-off packs: per stream, least recently used out (see _wq_image)
     if ent is None or ent[0].numel() * 4 < need:
         ent = cache[key] = [torch.empty(need // 4, dtype=torch.float32, device=dev), None]
+        if owner is None:
+            while len(cache) > 64:
+                cache.pop(next(iter(cache)))
     if gen is None or ent[1] != gen:
         hip.check(lib.tnr_conv_sweep_pack(descs, n, ent[0].data_ptr(), need, hip.stream()), "conv_sweep_pack")
         ent[1] = gen
