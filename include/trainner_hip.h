@@ -145,6 +145,13 @@ typedef struct tnr_wgrad_desc {
     float *ws; int64_t ws_bytes;                   /* >= tnr_wgrad_workspace_bytes()                  */
     int32_t mma;                                   /* TNR_MMA_F32 | TNR_MMA_BF16 (see tnr_conv_desc)   */
     int32_t pad_mode;                              /* TNR_CONV_3x3: 0 zero padding, 1 reflection (tnr_conv_desc) */
+    /* Two layers in one job ("cout pair"; cout_split = 0: off).  When the gradients of two layers that read the SAME input channels
+     * stand side by side in one buffer -- a dense block's [g4 | g3] and [g2 | g1] (RRDBNet_arch.py:150-163) -- `g` may cover both
+     * (Cout = 64): output channels [0, cout_split) then belong to the layer of dw / cin_total / db, channels [cout_split, Cout) to a
+     * second layer dw2 / cin_total2 / db2 (same cin_begin, alpha, beta).  The pair runs in the 64-cout workgroup tile class: one
+     * read of the input tile feeds both layers.  cout_split is a multiple of 32.                                               */
+    float *dw2; int32_t cout_split, cin_total2;
+    float *db2;
 } tnr_wgrad_desc;
 
 typedef struct tnr_pack_item {
@@ -249,7 +256,7 @@ int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
  * 32-channel input blocks per workgroup: e.g. the 64-input pieces of a dense block's conv1/conv3/conv4);
  * each needs its own workspace of tnr_wgrad_workspace_bytes().  Results equal n single launches up to
  * the summation order of the split-K partials (still run-to-run deterministic).                     */
-#define TNR_WGRAD_GROUP_MAX 8
+#define TNR_WGRAD_GROUP_MAX 12
 int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void *stream);
 
 /* --- image-to-image family (Pix2Pix / CycleGAN: ResnetGenerator ResNet_arch.py:11-90, NLayerDiscriminator

@@ -514,8 +514,14 @@ def conv_chain(stages):
 
 def wgrad_group(items, mode=ops.CONV_3x3):
     for it in items:
-        wgrad(it["x"], it["g"], it["dw"], it.get("db"), mode=mode, cin_begin=it.get("cin_begin", 0),
-              alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0), reflect=it.get("reflect", False))
+        kw = dict(mode=mode, cin_begin=it.get("cin_begin", 0), alpha=it.get("alpha", 1.0), beta=it.get("beta", 1.0), reflect=it.get("reflect", False))
+        if it.get("pair") is not None:           # cout pair (tnr_wgrad_desc.cout_split): two layers' gradients side by side in g
+            dw2, db2, split = it["pair"]
+            g = it["g"]
+            wgrad(it["x"], ops.View(g.buf, g.coff, split), it["dw"], it.get("db"), **kw)
+            wgrad(it["x"], ops.View(g.buf, g.coff + split, g.C - split), dw2, db2, **kw)
+        else:
+            wgrad(it["x"], it["g"], it["dw"], it.get("db"), **kw)
 
 
 _NAMES = ["gauss_mult", "bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",

@@ -635,6 +635,49 @@ def test_wgrad_group_dense_block():
                          dict(x=ops.View(xb, 0, 96), g=ops.View(gbuf, 96, gc), dw=torch.zeros(gc, 96, 3, 3, device=DEV))])
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 40), (1, 37, 19), (3, 16, 16)])
+def test_wgrad_cout_pairs_of_a_dense_block(shape):
+    """tnr_wgrad_desc.cout_split: a dense block's [g4 | g3] over x | x1 | x2 (128 channels) and [g2 | g1] over x (64) as 64-cout PAIR jobs
+    next to conv5's 64 x 192 job in ONE launch (what RRDBNet's backward enqueues per RRDB), plus the two 32-channel remainders in a
+    second launch -- every layer's weight and bias gradient against autograd, with alpha / beta, and the untouched parts of dw intact."""
+    ops = _ops()
+    N, H, W = shape
+    nf, gc = 64, 32
+    x = rnd(N, 192, H, W, seed=71)
+    g5 = rnd(N, nf, H, W, seed=72)
+    gs = {k: rnd(N, gc, H, W, seed=73 + k) for k in range(4)}           # k = 0 .. 3 <-> conv1 .. conv4
+    xb = nhwc_buf(x, 192, 0)
+    GP = torch.zeros((N, H, W, 192), device=DEV)
+    GP[..., :nf] = g5.permute(0, 2, 3, 1).to(DEV)
+    for k in range(4):
+        o = nf + (3 - k) * gc
+        GP[..., o:o + gc] = gs[k].permute(0, 2, 3, 1).to(DEV)
+    ref, dw, db, dw0, db0 = {}, {}, {}, {}, {}
+    for k in range(5):
+        cin, cout, gk = nf + gc * k, (gc if k < 4 else nf), (gs[k] if k < 4 else g5)
+        w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+        (rw,) = torch.autograd.grad(F.conv2d(x[:, :cin], w, None, padding=1), w, gk)
+        dw0[k], db0[k] = rnd(cout, cin, 3, 3, seed=80 + k), rnd(cout, seed=90 + k)
+        dw[k], db[k] = dw0[k].to(DEV), db0[k].to(DEV)
+        ref[k] = (dw0[k] + 0.5 * rw, db0[k] + 0.5 * gk.sum(dim=(0, 2, 3)))
+    V = ops.View
+    big = [dict(x=V(xb), g=V(GP, 0, nf), dw=dw[4], db=db[4], alpha=0.5, beta=1.0)]
+    rest = []
+    for ka, kb in ((3, 2), (1, 0)):
+        cin = nf + gc * kb
+        big.append(dict(x=V(xb, 0, cin), g=V(GP, nf + (3 - ka) * gc, 2 * gc), dw=dw[ka], db=db[ka], alpha=0.5, beta=1.0,
+                        pair=(dw[kb], db[kb], gc)))
+        rest.append(dict(x=V(xb, cin, gc), g=V(GP, nf + (3 - ka) * gc, gc), dw=dw[ka], cin_begin=cin, alpha=0.5, beta=1.0))
+    ops.wgrad_group(big)
+    ops.wgrad_group(rest)
+    for k in range(5):
+        scale = ref[k][0].abs().max().item() + 1.0
+        assert (dw[k].cpu() - ref[k][0]).abs().max().item() <= 5e-5 * scale, ("dw", k)
+        assert (db[k].cpu() - ref[k][1]).abs().max().item() <= 5e-5 * (ref[k][1].abs().max().item() + 1.0), ("db", k)
+    with pytest.raises(RuntimeError, match="cout pair"):
+        ops.wgrad_group([dict(x=V(xb, 0, 64), g=V(GP, nf, 2 * gc), dw=dw[3], pair=(dw[2], None, 16))])
+
+
 def test_layout_roundtrip_and_norm():
     ops = _ops()
     x = rnd(2, 3, 10, 14, seed=31)

@@ -823,6 +823,8 @@ wgrad_tile_kernel(const WgK ga) {
 
 struct RedJob {
     const float *ws; const float *dbp; float *dw; float *db;
+    float *dw2; float *db2;       // cout pair (tnr_wgrad_desc.cout_split): output channels >= split belong to a second layer
+    int split, cin_total2;        // split = Cout when the job is a single layer
     int KoutP, KinVP, cinp32, Cout, Cin, cin_total, cin_begin;
     int blk_begin, nrows;         // blockIdx.x range [blk_begin, blk_begin + nrows + bias blocks)
     float alpha, beta;
@@ -859,8 +861,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
             float sum = 0.f;
 #pragma unroll
             for (int l = 0; l < 8; ++l) sum += sh[l][el];
-            const float prev = (a.beta != 0.f) ? a.beta * a.db[c] : 0.f;
-            a.db[c] = prev + a.alpha * sum;
+            float *dbc = c < a.split ? a.db + c : a.db2 + (c - a.split);
+            const float prev = (a.beta != 0.f) ? a.beta * *dbc : 0.f;
+            *dbc = prev + a.alpha * sum;
         }
         return;
     }
@@ -897,9 +900,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
             kx = tap - ky * ga.kw;
         }
         if (co < a.Cout && ci < a.Cin) {
-            const size_t o = (((size_t)co * a.cin_total + a.cin_begin + ci) * ga.kh + ky) * ga.kw + kx;
-            const float prev = (a.beta != 0.f) ? a.beta * a.dw[o] : 0.f;
-            a.dw[o] = prev + a.alpha * sum;
+            const bool second = co >= a.split;
+            const size_t o = (((size_t)(second ? co - a.split : co) * (second ? a.cin_total2 : a.cin_total) + a.cin_begin + ci) * ga.kh + ky) * ga.kw + kx;
+            float *dst = (second ? a.dw2 : a.dw) + o;
+            const float prev = (a.beta != 0.f) ? a.beta * *dst : 0.f;
+            *dst = prev + a.alpha * sum;
         }
     }
 }
@@ -1062,6 +1067,11 @@ int check_wgrad_desc(const tnr_wgrad_desc *d) {
     TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->g.ctot % 4) == 0 && (d->g.coff % 4) == 0,
                 "wgrad: views must be 4-channel aligned");
     TNR_REQUIRE(d->db == nullptr || d->cin_begin == 0, "wgrad: bias gradient only with cin_begin == 0");
+    if (d->cout_split != 0) {
+        TNR_REQUIRE(d->cout_split > 0 && d->cout_split < d->Cout && d->cout_split % 32 == 0 && d->dw2 != nullptr && d->cin_total2 >= d->cin_begin + d->Cin,
+                    "wgrad: bad cout pair (split %d of %d output channels)", d->cout_split, d->Cout);
+        TNR_REQUIRE((d->db == nullptr) == (d->db2 == nullptr), "wgrad: a cout pair takes both bias gradients or none");
+    }
     if (d->mode == TNR_CONV_3x3) TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "wgrad3x3: size mismatch");
     if (d->mode == TNR_CONV_3x3_UP2) TNR_REQUIRE(d->Ho == 2 * d->H && d->Wo == 2 * d->W, "wgrad3x3_up2: size mismatch");
     if (d->mode == TNR_CONV_4x4_S2) TNR_REQUIRE(2 * d->Ho == d->H && 2 * d->Wo == d->W, "wgrad4x4s2: size mismatch");
@@ -1117,6 +1127,7 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
         job_begin += p.ncib * p.ncob;
         RedJob &q = r.job[i];
         q.ws = d->ws; q.dbp = j.dbp; q.dw = d->dw; q.db = d->db;
+        q.dw2 = d->dw2; q.db2 = d->db2; q.split = d->cout_split > 0 ? d->cout_split : d->Cout; q.cin_total2 = d->cin_total2;
         q.KoutP = p.KoutP; q.KinVP = p.KinVP; q.cinp32 = p.cinp32; q.Cout = d->Cout; q.Cin = d->Cin;
         q.cin_total = d->cin_total; q.cin_begin = d->cin_begin; q.alpha = d->alpha; q.beta = d->beta;
         q.blk_begin = blk_begin;

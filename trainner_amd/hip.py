@@ -51,6 +51,7 @@ class WgradDesc(C.Structure):
         ("dw", c_p), ("cin_total", c_i), ("cin_begin", c_i),
         ("db", c_p), ("alpha", c_f), ("beta", c_f),
         ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i), ("pad_mode", c_i),
+        ("dw2", c_p), ("cout_split", c_i), ("cin_total2", c_i), ("db2", c_p),
     ]
 
 

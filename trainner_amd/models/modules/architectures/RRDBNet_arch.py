@@ -209,6 +209,20 @@ class RRDBNet(HipNet):
             # no padded MFMA slot (wgrad_tile.hip), and the pieces of one class over the RRDB's three dense blocks
             # share a launch: 4 weight-gradient launches per RRDB instead of 9.
             pend.setdefault("c5", []).append(convs[4].wgrad_item(View(buf), g, alpha=0.2 * s))
+            if ops.WGRAD_PAIR and gc == 32 and nf == 64:
+                # conv4 + conv3 and conv2 + conv1 as COUT PAIRS: their gradients stand side by side in GP ([g4 | g3], [g2 | g1]) and
+                # both layers of a pair read the channels the narrower one reads (x | x1 | x2 = 128, x = 64), so a pair is one
+                # 64-cout job of conv5's tile class (tnr_wgrad_desc.cout_split): the RRDB's 64-cout work -- 3 x (conv5 + two pairs) --
+                # is ONE launch, the two 32-channel remainders (conv4 over x3, conv2 over x1) a second one.
+                for ka, kb in ((3, 2), (1, 0)):                # (wider layer first: its gradient comes first in GP)
+                    cin = nf + gc * kb                         # channels both layers read
+                    gpair = View(GP, nf + (3 - ka) * gc, 2 * gc)
+                    it = convs[ka].wgrad_item(View(buf, 0, cin), gpair)
+                    it["pair"] = (convs[kb].mod.weight.grad, None if it["db"] is None else convs[kb].mod.bias.grad, gc)
+                    pend["c5"].append(it)
+                    ga = View(GP, nf + (3 - ka) * gc, gc)
+                    pend.setdefault(gc, []).append(convs[ka].wgrad_item(View(buf, cin, gc), ga, cin_begin=cin))
+                return
             for k in (3, 2, 1, 0):
                 cin = nf + gc * k
                 gk = View(GP, nf + (3 - k) * gc, gc)

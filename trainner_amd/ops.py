@@ -568,11 +568,12 @@ def conv_col(x, wp_col, y, k, stride=1, pad=1, **epi):
     conv(View(col.view(torch.float32)[:M * K].view(y.N, y.H, y.W, K)), wp_col, y, mode=CONV_1x1, **epi)
 
 
-WGRAD_GROUP_MAX = 8
+WGRAD_GROUP_MAX = 12
+WGRAD_PAIR = os.environ.get("TNR_WGRAD_PAIR", "1") != "0"   # dense blocks: conv4+conv3 and conv2+conv1 as 64-cout pairs (A/B switch)
 WGRAD_X3 = os.environ.get("TNR_WGRAD_X3", "1") == "1"   # TNR_MMA=bf16x3 also in the weight-gradient kernel (A/B switch)
 
 
-def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
+def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False, pair=None):
     d.x = x.c()
     d.N, d.H, d.W, d.Cin = x.N, x.H, x.W, x.C
     d.g = g.c()
@@ -583,6 +584,9 @@ def _wgrad_desc(d, x, g, dw, db, mode, cin_begin, alpha, beta, reflect=False):
     d.alpha, d.beta = alpha, beta
     d.mma = hip.MMA_F32 if (MMA == hip.MMA_BF16X3 and not WGRAD_X3) else MMA
     d.pad_mode = 1 if reflect else 0
+    if pair is not None:           # cout pair: g covers two layers' gradients, channels >= split belong to (dw2, db2)
+        dw2, db2, split = pair
+        d.dw2, d.cin_total2, d.cout_split, d.db2 = dw2.data_ptr(), dw2.shape[1], split, hip.ptr(db2)
 
 
 def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0, reflect=False):
@@ -592,14 +596,14 @@ def wgrad(x, g, dw, db=None, mode=CONV_3x3, cin_begin=0, alpha=1.0, beta=1.0, re
 
 def wgrad_group(items, mode=CONV_3x3):
     """Several weight gradients of one pixel geometry and one workgroup tile class in a single launch
-    (tnr_conv_wgrad_group).  items: dicts with x, g, dw and optional db, cin_begin, alpha, beta."""
+    (tnr_conv_wgrad_group).  items: dicts with x, g, dw and optional db, cin_begin, alpha, beta, pair = (dw2, db2, cout_split)."""
     lib = hip.load()
     n = len(items)
     assert 1 <= n <= WGRAD_GROUP_MAX
     descs = (WgradDesc * n)()
     for d, it in zip(descs, items):
         _wgrad_desc(d, it["x"], it["g"], it["dw"], it.get("db"), mode, it.get("cin_begin", 0),
-                    it.get("alpha", 1.0), it.get("beta", 1.0), it.get("reflect", False))
+                    it.get("alpha", 1.0), it.get("beta", 1.0), it.get("reflect", False), it.get("pair"))
     dev = items[0]["x"].buf.device
     for i, d in enumerate(descs):
         need = lib.tnr_wgrad_workspace_bytes(C.byref(d))
