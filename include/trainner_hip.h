@@ -392,6 +392,13 @@ int tnr_bn_replay_running(float *running_mean, float *running_var, int64_t *num_
 int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz, int64_t pixels, int32_t C,
                      const float *gamma, const float *save_mean, const float *save_invstd, float mslope,
                      float *dgamma, float *dbeta, float acc_beta, void *ws, void *stream);
+/* The same with the LeakyReLU / ReLU mask RECOMPUTED from z instead of read from y: y > 0 <=> ((z - mean) invstd) gamma + beta > 0 is
+ * the forward's own expression (tnr_bn_train_fwd; the library is built with -ffp-contract=off), so the mask -- and every result -- is
+ * bit-for-bit that of tnr_bn_train_bwd; one of the two passes' three reads per element disappears.  gamma / beta must be the
+ * values the forward ran with (true between a forward and its backward).                                                       */
+int tnr_bn_train_bwd_z(tnr_view gy, tnr_view z, tnr_view gz, int64_t pixels, int32_t C, const float *gamma, const float *beta,
+                       const float *save_mean, const float *save_invstd, float mslope, float *dgamma, float *dbeta,
+                       float acc_beta, void *ws, void *stream);
 /* InstanceNorm2d without affine parameters or running statistics (the ResnetGenerator's norm layer, ResNet_arch.py:40-50 ->
  * nn.InstanceNorm2d defaults) over a whole batch: the BatchNorm kernels with one statistics group per image.
  * y = act((z - mean[n,c]) * invstd[n,c]); save_mean / save_invstd: [N * C].  bwd: gz from gy (masked by act'(y), slope mslope:

@@ -392,7 +392,7 @@ def bn_train_fwd(z, y, gamma, beta, running_mean, running_var, num_batches, save
     y.dense().copy_(out.permute(0, 2, 3, 1))
 
 
-def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2):
+def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2, beta=None):
     g = _nchw(gy) * _mask(_nchw(y), mslope)
     zin = _nchw(z)
     n = zin.numel() / zin.shape[1]

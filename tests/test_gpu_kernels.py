@@ -756,6 +756,12 @@ def test_batchnorm_train(C):
     close(to_nchw(gzb, 0, C), gz_ref, tol=1e-4, what="bn bwd dx")
     close(dg.cpu() - 1, gg_ref, tol=1e-4, what="bn dgamma")
     close(dbt.cpu() - 1, gb_ref, tol=1e-4, what="bn dbeta")
+    # the mask recomputed from z (tnr_bn_train_bwd_z; what Discriminator_VGG's backward calls): BIT-identical to the mask read from y
+    gzb2 = torch.zeros_like(zb)
+    dg2, dbt2 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    assert ops.BN_MASK_FROM_Z
+    ops.bn_train_bwd(ops.View(nhwc_buf(gy)), None, ops.View(zb), ops.View(gzb2), gd, sm, si, dgamma=dg2, dbeta=dbt2, acc_beta=1.0, beta=bd)
+    assert torch.equal(gzb2, gzb) and torch.equal(dg2, dg) and torch.equal(dbt2, dbt)
 
 
 def test_linear_and_losses_and_optim():

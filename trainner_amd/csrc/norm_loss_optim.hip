@@ -27,17 +27,21 @@ __device__ __forceinline__ double block_reduce_sum(double v, double *sh) {
 // partial[b][c] = {sum f(z), sum g(z)} over the block's pixel range, per channel.
 // MODE 0 (fwd):  f = z,            g = z*z
 // MODE 1 (bwd):  f = gy*mask(y),   g = gy*mask(y)*(z - mean[c])
+// MODE 2 (bwd):  the same with the activation mask RECOMPUTED from z (y is not read): y > 0 <=> ((z - mean) invstd) gamma + beta > 0,
+//                the forward's own expression (bn_fwd_apply_kernel; -ffp-contract=off), so the mask is bit-for-bit the one y carries;
+//                `y` then points at {invstd[C], gamma[C], beta[C]} pointers packed by the caller: see BnMaskK
+struct BnMaskK { const float *invstd, *gamma, *beta; };
 template <int MODE>
 __global__ void bn_partial_kernel(const float *z, int z_ct, int z_co, const float *gy, int g_ct, int g_co, const float *y,
                                   int y_ct, int y_co, const float *mean, float mslope, int64_t pixels, int C,
-                                  int64_t pix_per_block, double *partial) {
+                                  int64_t pix_per_block, double *partial, BnMaskK mk = BnMaskK{nullptr, nullptr, nullptr}) {
     extern __shared__ double sh_d[];  // [lanes][C][2]
     {   // blockIdx.y = statistics group (InstanceNorm: one image; BatchNorm launches have one group): `pixels` per group
         const size_t go = (size_t)blockIdx.y * (size_t)pixels;
         z += go * z_ct;
-        if (MODE == 1) {
+        if (MODE >= 1) {
             gy += go * g_ct;
-            y += go * y_ct;
+            if (MODE == 1) y += go * y_ct;
             mean += (size_t)blockIdx.y * C;
         }
         partial += (size_t)blockIdx.y * gridDim.x * C * 2;
@@ -51,8 +55,13 @@ __global__ void bn_partial_kernel(const float *z, int z_ct, int z_co, const floa
     if (p1 > pixels) p1 = pixels;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (pl < lanes) {
-        f32x4 mu = {0.f, 0.f, 0.f, 0.f};
-        if (MODE == 1) mu = *reinterpret_cast<const f32x4 *>(mean + cg * 4);
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, ga = mu, be = mu;
+        if (MODE >= 1) mu = *reinterpret_cast<const f32x4 *>(mean + cg * 4);
+        if (MODE == 2) {
+            is = *reinterpret_cast<const f32x4 *>(mk.invstd + cg * 4);
+            ga = *reinterpret_cast<const f32x4 *>(mk.gamma + cg * 4);
+            be = *reinterpret_cast<const f32x4 *>(mk.beta + cg * 4);
+        }
         for (int64_t p = p0 + pl; p < p1; p += lanes) {
             const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + p * z_ct + z_co + cg * 4);
             if (MODE == 0) {
@@ -63,7 +72,13 @@ __global__ void bn_partial_kernel(const float *z, int z_ct, int z_co, const floa
                 }
             } else {
                 const f32x4 gv = *reinterpret_cast<const f32x4 *>(gy + p * g_ct + g_co + cg * 4);
-                const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
+                f32x4 yv;
+                if (MODE == 1) {
+                    yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) yv[k] = ((zv[k] - mu[k]) * is[k]) * ga[k] + be[k];
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float g = gv[k] * (yv[k] > 0.f ? 1.f : mslope);
@@ -192,17 +207,18 @@ bn_bwd_finalize_kernel(const double *partial, int nblocks, int C, const float *i
     }
 }
 
+template <bool FROMZ>      // FROMZ: the activation mask recomputed from z (bn_partial_kernel MODE 2); y is not read, beta is
 __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const float *y, int y_ct, int y_co, const float *z,
                                     int z_ct, int z_co, float *gz, int o_ct, int o_co, int64_t pixels, int C,
                                     const float *gamma, const float *mean, const float *invstd, const double *sums,
-                                    float mslope) {
+                                    float mslope, const float *beta) {
     const int G = C / 4;
     const int64_t total = pixels * G;
     const float inv_n = 1.f / (float)pixels;
     {   // statistics group (see bn_partial_kernel)
         const size_t go = (size_t)blockIdx.y * (size_t)pixels;
         gy += go * g_ct;
-        y += go * y_ct;
+        if (!FROMZ) y += go * y_ct;
         z += go * z_ct;
         gz += go * o_ct;
         mean += (size_t)blockIdx.y * C;
@@ -215,10 +231,11 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
         // computed once, with the same expressions as below (bit-identical), and the pixel index advances by a constant --
         // no 64-bit division, no double-precision loads per element (3.8 TB/s before)
         const int cg = (int)(e0 % G);
-        float is4[4], gm4[4], kk4[4], mu4[4], ga4[4];
+        float is4[4], gm4[4], kk4[4], mu4[4], ga4[4], be4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = cg * 4 + k;
+            be4[k] = FROMZ ? beta[c] : 0.f;
             is4[k] = invstd[c];
             gm4[k] = (float)sums[2 * c + 0] * inv_n;
             kk4[k] = (float)sums[2 * c + 1] * is4[k] * is4[k] * inv_n;
@@ -228,8 +245,14 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
         const int64_t pstep = stride / G;
         for (int64_t p = e0 / G; p < pixels; p += pstep) {
             const f32x4 gv = *reinterpret_cast<const f32x4 *>(gy + p * g_ct + g_co + cg * 4);
-            const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
             const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + p * z_ct + z_co + cg * 4);
+            f32x4 yv;
+            if constexpr (FROMZ) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) yv[k] = ((zv[k] - mu4[k]) * is4[k]) * ga4[k] + be4[k];
+            } else {
+                yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
+            }
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -244,8 +267,14 @@ __global__ void bn_bwd_apply_kernel(const float *gy, int g_ct, int g_co, const f
         const int cg = (int)(e % G);
         const int64_t p = e / G;
         const f32x4 gv = *reinterpret_cast<const f32x4 *>(gy + p * g_ct + g_co + cg * 4);
-        const f32x4 yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
         const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + p * z_ct + z_co + cg * 4);
+        f32x4 yv;
+        if constexpr (FROMZ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[k] = ((zv[k] - mean[cg * 4 + k]) * invstd[cg * 4 + k]) * (gamma ? gamma[cg * 4 + k] : 1.f) + beta[cg * 4 + k];
+        } else {
+            yv = *reinterpret_cast<const f32x4 *>(y + p * y_ct + y_co + cg * 4);
+        }
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -645,10 +674,31 @@ extern "C" int tnr_bn_train_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz
                        y.ptr, y.ctot, y.coff, save_mean, mslope, pixels, C, ppb, partial);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tnr_cdiv(C, 32)), dim3(256), 0, s, partial, nblocks, C, save_invstd, sums,
                        dgamma, dbeta, acc_beta);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
                        y.ctot, y.coff, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, gamma, save_mean,
-                       save_invstd, sums, mslope);
+                       save_invstd, sums, mslope, (const float *)nullptr);
     return tnr_check_launch("bn_train_bwd");
+}
+
+extern "C" int tnr_bn_train_bwd_z(tnr_view gy, tnr_view z, tnr_view gz, int64_t pixels, int32_t C, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, float mslope, float *dgamma, float *dbeta,
+                                  float acc_beta, void *ws, void *stream) {
+    TNR_REQUIRE(gy.ptr && z.ptr && gz.ptr && gamma && beta && save_mean && save_invstd && ws, "bn_bwd_z: null pointer");
+    TNR_REQUIRE((C % 4) == 0 && C / 4 <= 256, "bn_bwd_z: unsupported C %d", C);
+    TNR_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bn_bwd_z: dgamma and dbeta go together");
+    int nblocks; int64_t ppb; size_t lds;
+    bn_plan(pixels, C, nblocks, ppb, lds);
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)ws;
+    double *sums = partial + (size_t)RED_BLOCKS * C * 2;
+    hipLaunchKernelGGL(bn_partial_kernel<2>, dim3(nblocks), dim3(256), lds, s, z.ptr, z.ctot, z.coff, gy.ptr, gy.ctot, gy.coff,
+                       (const float *)nullptr, 0, 0, save_mean, mslope, pixels, C, ppb, partial, BnMaskK{save_invstd, gamma, beta});
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tnr_cdiv(C, 32)), dim3(256), 0, s, partial, nblocks, C, save_invstd, sums,
+                       dgamma, dbeta, acc_beta);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff,
+                       (const float *)nullptr, 0, 0, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, gamma, save_mean,
+                       save_invstd, sums, mslope, beta);
+    return tnr_check_launch("bn_train_bwd_z");
 }
 
 // InstanceNorm2d (no affine, no running statistics: ResNet_arch.py:40-50) forward / backward over a batch in ONE set of
@@ -692,9 +742,9 @@ extern "C" int tnr_instnorm_bwd(tnr_view gy, tnr_view y, tnr_view z, tnr_view gz
                        nullptr, nullptr, 0.f);
     int64_t gx = tnr_cdiv64(pixels * (C / 4), 256);
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)gx, N), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)gx, N), dim3(256), 0, s, gy.ptr, gy.ctot, gy.coff, y.ptr,
                        y.ctot, y.coff, z.ptr, z.ctot, z.coff, gz.ptr, gz.ctot, gz.coff, pixels, C, nullptr, save_mean,
-                       save_invstd, sums, mslope);
+                       save_invstd, sums, mslope, (const float *)nullptr);
     return tnr_check_launch("instnorm_bwd");
 }
 

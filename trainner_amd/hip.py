@@ -137,6 +137,7 @@ _SIGS = {
     "tnr_bn_train_fwd_stats": (c_i, [CView, CView, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_i, c_f, c_p, c_p]),
     "tnr_bn_replay_running": (c_i, [c_p, c_p, c_p, c_p, c_i, c_f, c_p]),
     "tnr_bn_train_bwd": (c_i, [CView, CView, CView, CView, c_l, c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]),
+    "tnr_bn_train_bwd_z": (c_i, [CView, CView, CView, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p]),
     "tnr_instnorm_workspace_bytes": (c_l, [c_i, c_i]),
     "tnr_instnorm_fwd": (c_i, [CView, CView, c_i, c_l, c_i, c_f, c_p, c_p, c_i, c_f, c_p, c_p]),
     "tnr_instnorm_bwd": (c_i, [CView, CView, CView, CView, c_i, c_l, c_i, c_p, c_p, c_f, c_p, c_p]),

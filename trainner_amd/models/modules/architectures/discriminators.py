@@ -122,7 +122,7 @@ class Discriminator_VGG(HipNet):
             if bn is not None:
                 gz = View(new_act(N, y.H, y.W, y.C, dev))
                 ops.bn_train_bwd(gy, y, z, gz, bn.weight, mean, invstd, dgamma=bn.weight.grad if W else None,
-                                 dbeta=bn.bias.grad if W else None, mslope=sl)
+                                 dbeta=bn.bias.grad if W else None, mslope=sl, beta=bn.bias)
             else:
                 gz = gy                                         # already masked by the consumer's dgrad epilogue
             if W:

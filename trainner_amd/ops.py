@@ -796,9 +796,19 @@ def bn_replay_running(running_mean, running_var, num_batches, stat64, momentum=0
                                                running_mean.numel(), momentum, hip.stream()), "bn_replay_running")
 
 
-def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2):
+BN_MASK_FROM_Z = os.environ.get("TNR_BN_MASK_FROM_Z", "1") != "0"      # A/B switch
+
+
+def bn_train_bwd(gy, y, z, gz, gamma, save_mean, save_invstd, dgamma=None, dbeta=None, acc_beta=1.0, mslope=0.2, beta=None):
+    """Backward of y = act(BatchNorm_train(z)).  beta (the forward's shift) given: the activation mask is recomputed from z
+    (tnr_bn_train_bwd_z: bit-identical, y is not read)."""
     lib = hip.load()
     ws = WS.get("bn", lib.tnr_bn_workspace_bytes(z.C), z.buf.device)
+    if beta is not None and BN_MASK_FROM_Z:
+        hip.check(lib.tnr_bn_train_bwd_z(gy.c(), z.c(), gz.c(), z.pixels, z.C, gamma.data_ptr(), beta.data_ptr(), save_mean.data_ptr(),
+                                         save_invstd.data_ptr(), mslope, hip.ptr(dgamma), hip.ptr(dbeta), acc_beta, ws.data_ptr(),
+                                         hip.stream()), "bn_train_bwd_z")
+        return
     hip.check(lib.tnr_bn_train_bwd(gy.c(), y.c(), z.c(), gz.c(), z.pixels, z.C, gamma.data_ptr(),
                                    save_mean.data_ptr(), save_invstd.data_ptr(), mslope, hip.ptr(dgamma),
                                    hip.ptr(dbeta), acc_beta, ws.data_ptr(), hip.stream()), "bn_train_bwd")
