@@ -460,9 +460,10 @@ def test_step_matches_oracle_at_headline_config(tmp_path):
 
 @pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
 def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
-    """`use_amp: true` (options/sr/train_sr.yml:6): bf16 matrix-core operands, fp32 everything else.  Three G+D steps
-    against the fp32 CPU oracle: the SR image within 0.05 dB PSNR (north star), the losses within bf16's resolution
-    (2^-8 relative per operand; stated bound 3 % on the loss scalars), and the mode really is bf16 (not bit-equal to fp32)."""
+    """`use_amp: true` (options/sr/train_sr.yml:6): bf16 matrix-core operands, fp32 everything else.  K = 10 consecutive G+D steps
+    against the fp32 CPU oracle: the SR image within 0.05 dB PSNR at EVERY step (north star), the losses within bf16's resolution
+    over the first three (2^-8 relative per operand; stated bound 3 % on the loss scalars) and within 10 % after ten steps of
+    two diverging trajectories, and the mode really is bf16 (not bit-equal to fp32)."""
     from trainner_amd import hip, ops
     kw = dict(nb=2, batch=2, crop=64, d_nf=16, d_type=d_type)
     try:
@@ -476,7 +477,7 @@ def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
         worst = 0.0
         seen = []
         model.netG.register_forward_pre_hook(lambda m, i: seen.append(ops.MMA))
-        for s in (1, 2, 3):
+        for s in range(1, 11):
             LR, HR = detrand.synthetic_pair(2, 64, 40 + s)
             ref_log = orc.step(LR, HR)
             model.feed_data({"LR": LR, "HR": HR})
@@ -484,11 +485,11 @@ def test_amp_bf16_step_tracks_the_fp32_oracle(tmp_path, d_type):
             assert seen[-1] == hip.MMA_BF16 and ops.MMA == ops.FP32_MMA     # bf16 operands inside the step, restored after it
             log = model.get_current_log()
             for k in ("pix-l1", "fea-vgg19-l1", "l_g_gan", "l_d_real", "l_d_fake"):
-                assert abs(log[k] - ref_log[k]) <= 0.03 * abs(ref_log[k]) + 1e-5, (s, k, log[k], ref_log[k])
+                assert abs(log[k] - ref_log[k]) <= (0.03 if s <= 3 else 0.10) * abs(ref_log[k]) + 1e-5, (s, k, log[k], ref_log[k])
             got, ref = model.fake_H.detach().cpu(), orc.fake_H.detach()
             worst = max(worst, (got - ref).abs().max().item())
             assert abs(O.psnr_reference(got, HR) - O.psnr_reference(ref, HR)) <= 0.05
-        assert 1e-5 < worst < 2e-2, worst                  # bf16-sized differences: neither fp32-exact nor broken
+        assert 1e-5 < worst < 5e-2, worst                  # bf16-sized differences: neither fp32-exact nor broken
         model.test()                                       # validation forwards run in fp32 like the reference's (sr_model.py:269-277)
         assert seen[-1] == ops.FP32_MMA
     finally:
