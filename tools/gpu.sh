@@ -39,9 +39,27 @@ prof() {
   cd $R
 }
 
+# PMC passes (HBM traffic, MFMA busy) of one step of tools/bench_i2i.py: records *_pmc_{traffic,mfma_busy}_i2i_<model>_<netg>_bf16x3.json
+prof_i2i() {
+  local MODEL=${1:-pix2pix} NETG=${2:-resnet}
+  local SFX=i2i_${MODEL}_${NETG}_bf16x3
+  cd /tmp && export TMPDIR=/tmp
+  for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    local N=$(echo $C | cut -d' ' -f1)
+    rm -rf /tmp/pmc_$N
+    timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$N -- python $R/tools/bench_i2i.py --model $MODEL --netg $NETG --steps 1 --warmup 1 > $O/${TAG}_pmc_run_${N}_${SFX}.log 2>&1
+    python $R/tools/pmc_summary.py /tmp/pmc_$N > $O/${TAG}_pmc_${N}_${SFX}.summary.csv
+  done
+  python $R/tools/pmc_traffic.py $O/${TAG}_pmc_FETCH_SIZE_${SFX}.summary.csv $O/${TAG}_pmc_WRITE_SIZE_${SFX}.summary.csv $O/${TAG}_pmc_traffic_${SFX}.json
+  python $R/tools/pmc_busy.py $O/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES_${SFX}.summary.csv $O/${TAG}_pmc_mfma_busy_${SFX}.json
+  python $R/tools/pmc_stamp.py $O/${TAG}_pmc_traffic_${SFX}.json $O/${TAG}_pmc_mfma_busy_${SFX}.json
+  cd $R
+}
+
 case $CMD in
   suite) suite "$@" ;;
   prof) prof "$@" ;;
+  prof_i2i) prof_i2i "$@" ;;
   final)
     suite
     ( time timeout 900 python bench.py ) > $O/${TAG}_bench_default.json.log 2> $O/${TAG}_bench_default.err
