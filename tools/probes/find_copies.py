@@ -28,6 +28,16 @@ for ev in prof.events():
     if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::add_", "aten::mul", "aten::add", "aten::sum", "aten::div", "aten::mul_"):
         st = [f for f in (ev.stack or []) if "trainner_amd" in f]
         sites[(ev.name, st[0] if st else "?")] += 1
+par = collections.Counter()
+for ev in prof.events():
+    if "Memcpy" in ev.name or "memcpy" in ev.name:
+        q, chain = ev.cpu_parent, []
+        while q is not None and len(chain) < 4:
+            chain.append(q.name[:40])
+            q = q.cpu_parent
+        par[(ev.name, " < ".join(chain))] += 1
+for k, n in par.most_common(25):
+    print("%5d  %s" % (n, k))
 names = collections.Counter(ev.name for ev in prof.events())
 for name, n in names.most_common(60):
     print("%5d  %s" % (n, name[:100]))

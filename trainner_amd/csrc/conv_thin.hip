@@ -20,9 +20,20 @@ struct ThinK {
 
 constexpr int TT = 16, THW = TT + 2, TPST = TNR_PST;
 
+#ifndef THIN_SCALAR_W
+#define THIN_SCALAR_W 1        /* the chunk's weights through the scalar cache into SGPR operands (0: staged in LDS, read as broadcasts) */
+#endif
 __global__ void __launch_bounds__(256) conv_thin_kernel(const ThinK a) {
     __shared__ __attribute__((aligned(16))) float s_in[THW * THW * TPST];
+#if !THIN_SCALAR_W
     __shared__ __attribute__((aligned(16))) float s_w[9 * TNR_CK * 4];
+#else
+    // every lane multiplies by the SAME weight: the [tap][channel][4 cout] table is read with wave-uniform addresses from constant
+    // address space (s_load: scalar cache -> SGPR operand of the FMA) instead of one LDS broadcast read per four FMAs, which kept the
+    // LDS pipe as busy as the vector ALUs (the launch ran at 2 TB/s of its 1.07 GB input, a quarter of what HBM delivers)
+    typedef const __attribute__((address_space(4))) f32x4 cf32x4;
+    cf32x4 *wtab = (cf32x4 *)(a.wp);
+#endif
     const int tid = threadIdx.x;
     int bid = blockIdx.x;
     const int tx = bid % a.tiles_x;
@@ -55,10 +66,12 @@ __global__ void __launch_bounds__(256) conv_thin_kernel(const ThinK a) {
             if (in_off[it] >= 0 && c0 + (i & 3) * 4 < a.Cin) v = *reinterpret_cast<const f32x4 *>(a.x + (size_t)in_off[it] + c0);
             if (i < IN_ITEMS) *reinterpret_cast<f32x4 *>(s_in + (i >> 2) * TPST + (i & 3) * 4) = v;
         }
+#if !THIN_SCALAR_W
         for (int i = tid; i < 9 * TNR_CK; i += 256) {   // one float4 (4 couts) per (tap, channel)
             const int t = i / TNR_CK, c = i - t * TNR_CK;
             *reinterpret_cast<f32x4 *>(s_w + i * 4) = *reinterpret_cast<const f32x4 *>(a.wp + ((size_t)t * a.KinP + c0 + c) * 4);
         }
+#endif
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -68,7 +81,11 @@ __global__ void __launch_bounds__(256) conv_thin_kernel(const ThinK a) {
                 const f32x4 xv = *reinterpret_cast<const f32x4 *>(xp + c4 * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+#if THIN_SCALAR_W
+                    const f32x4 w = wtab[t * a.KinP + c0 + c4 * 4 + k];                                       // wave-uniform: s_load
+#else
                     const f32x4 w = *reinterpret_cast<const f32x4 *>(s_w + (t * TNR_CK + c4 * 4 + k) * 4);   // broadcast
+#endif
 #pragma unroll
                     for (int o = 0; o < 4; ++o) acc[o] = __builtin_fmaf(xv[k], w[o], acc[o]);
                 }

@@ -831,12 +831,16 @@ struct RedJob {
 };
 struct RedK {
     int splits, ntaps, kh, kw, s2d, njobs;
+    int rpb;                      // slab rows per block: 1 (8 split lanes per row, many splits) or 8 (one thread per row element, <= 32 splits)
     RedJob job[TNR_WGRAD_GROUP_MAX];
 };
 
 // One block per slab row (tap, co, 32-channel block): 256 threads = 32 channels x 8 split lanes.  The
 // row's partials [split][32] are contiguous, so the 8 lanes stream 1 KiB per step; lane sums are combined
 // in a fixed order through LDS (deterministic).
+// Grouped launches have few splits per job (one chip-filling wave of workgroups over all their jobs: 14 for an RRDB's 18 jobs): there a
+// block takes EIGHT rows, one thread per (row, channel) walking all splits with eight independent partial sums in a fixed order -- no
+// LDS, no barrier, 1/8 of the blocks (rpb = 8; a block per row spent its time on the prologue and the barrier: 32 us per launch).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
     __shared__ float sh[8][33];
     int ji = 0;
@@ -849,9 +853,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
     const int nblk = a.KinVP >> 5;
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int nrows = a.nrows;
-    if (bx >= nrows) {
+    const int nrowblk = (nrows + ga.rpb - 1) / ga.rpb;
+    if (bx >= nrowblk) {
         // bias blocks: 32 output channels each, the 8 split lanes stream dbp[co][split]
-        const int c = (bx - nrows) * 32 + el;
+        const int c = (bx - nrowblk) * 32 + el;
         float part = 0.f;
         if (c < a.Cout)
             for (int q = sl; q < splits; q += 8) part += a.dbp[(size_t)c * splits + q];
@@ -867,13 +872,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
         }
         return;
     }
-    const int row = bx;                                 // ((tap * KoutP) + co) * nblk + blk
+    const int row = ga.rpb == 8 ? bx * 8 + sl : bx;     // ((tap * KoutP) + co) * nblk + blk
+    if (row >= nrows) return;                           // (rpb = 8: the last block's spare rows; no barrier on that path)
     const int blk = row % nblk;
     const int co = (row / nblk) % a.KoutP;
     const int tap = row / (nblk * a.KoutP);
     const float *src = a.ws + (size_t)row * splits * 32 + el;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    int s = sl;
+    float sum_all = 0.f;
+    if (ga.rpb == 8) {
+        float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s8 = 0;
+        for (; s8 + 8 <= splits; s8 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] += src[(size_t)(s8 + k) * 32];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s8 + k < splits) q[k] += src[(size_t)(s8 + k) * 32];
+        sum_all = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
+    int s = ga.rpb == 8 ? splits : sl;
     for (; s + 24 < splits; s += 32) {                  // four independent loads in flight per lane
         p0 += src[(size_t)s * 32];
         p1 += src[(size_t)(s + 8) * 32];
@@ -881,12 +900,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const RedK ga) {
         p3 += src[(size_t)(s + 24) * 32];
     }
     for (; s < splits; s += 8) p0 += src[(size_t)s * 32];
-    sh[sl][el] = (p0 + p1) + (p2 + p3);
-    __syncthreads();
-    if (sl == 0) {
-        float sum = 0.f;
+    if (ga.rpb != 8) {
+        sh[sl][el] = (p0 + p1) + (p2 + p3);
+        __syncthreads();
+    }
+    if (sl == 0 || ga.rpb == 8) {
+        float sum = sum_all;
+        if (ga.rpb != 8) {
 #pragma unroll
-        for (int l = 0; l < 8; ++l) sum += sh[l][el];
+            for (int l = 0; l < 8; ++l) sum += sh[l][el];
+        }
         const int civ = blk * 32 + el;
         int ci, ky, kx;
         if (ga.s2d) {
@@ -1108,6 +1131,10 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
     TNR_REQUIRE(jobs <= 65535, "wgrad_group: too many channel blocks");
     WgK k;
     RedK r;
+    static const int red_rpb = [] { const char *e = getenv("TNR_WGRAD_REDUCE_RPB"); return e ? atoi(e) : 8; }();      // (A/B switch: 1 = a block per row always)
+    WgPlan pg = plans[0];
+    if (n > 1) plan_wgrad(&descs[0], pg, jobs);
+    const int rpb = (red_rpb == 8 && pg.splits <= 32) ? 8 : 1;
     int job_begin = 0, blk_begin = 0;
     for (int i = 0; i < n; ++i) {
         const tnr_wgrad_desc *d = &descs[i];
@@ -1132,7 +1159,7 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
         q.cin_total = d->cin_total; q.cin_begin = d->cin_begin; q.alpha = d->alpha; q.beta = d->beta;
         q.blk_begin = blk_begin;
         q.nrows = p.ntaps * p.KoutP * (p.KinVP / 32);
-        blk_begin += q.nrows + (d->db ? tnr_cdiv(d->Cout, 32) : 0);
+        blk_begin += tnr_cdiv(q.nrows, rpb) + (d->db ? tnr_cdiv(d->Cout, 32) : 0);
     }
     for (int i = n; i < TNR_WGRAD_GROUP_MAX; ++i) { k.job[i] = k.job[0]; r.job[i] = r.job[0]; }
     const tnr_wgrad_desc &d0 = descs[0];
@@ -1155,7 +1182,7 @@ extern "C" int tnr_conv_wgrad_group(const tnr_wgrad_desc *descs, int32_t n, void
     }
     if (rc != TNR_OK) return rc;
     r.splits = p0.splits; r.ntaps = p0.ntaps; r.s2d = d0.mode == TNR_CONV_4x4_S2;
-    r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.njobs = n;
+    r.kh = r.s2d ? 4 : 3; r.kw = r.kh; r.njobs = n; r.rpb = rpb;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blk_begin), dim3(256), 0, s, r);
     return tnr_check_launch("wgrad_reduce");
 }
