@@ -330,3 +330,35 @@ def test_noise_key_derivation_matches_its_restatement():
     # distinct blocks / forwards / seeds -> distinct keys
     keys = {ops.noise_key(s, c, b) for s in (0, 1) for c in range(4) for b in range(69)}
     assert len(keys) == 2 * 4 * 69
+
+
+def test_bench_family_table_and_pmc_family_map():
+    """bench.py's `roofline.families` (every matrix-core family of the step, auditable from the driver's line) and the kernel-name map the
+    PMC tools use for the same families: every family ops.ConvProfile can emit has a PMC entry, the table's arithmetic is what it says,
+    and counters are quoted only from records stamped with THIS tree's kernel-source hash."""
+    import importlib
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    fams = importlib.import_module("pmc_families").FAMILIES
+    src = open(os.path.join(root, "trainner_amd", "ops.py")).read()
+    emitted = set(re.findall(r'"(conv_tile_[0-9a-z_]+|conv_chain|wgrad_tile)"', src))
+    assert emitted and emitted <= set(fams), emitted - set(fams)
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    summ = {"conv_chain": {"launches": 276, "flops": 2 * 17.3e12, "ms": 2 * 81.0}, "wgrad_tile": {"launches": 152, "flops": 2 * 11.7e12, "ms": 2 * 55.0},
+            "conv_thin": {"launches": 6, "flops": 1e11, "ms": 2.2}, "idle": {"launches": 1, "flops": 0.0, "ms": 1.0}}
+    tab = bench.family_table(summ, 2, 419.4, "no_such_mode", 307.8)
+    f = tab["families"]
+    assert list(f) == ["conv_chain", "wgrad_tile", "conv_thin"]                      # largest first, zero-FLOP rows dropped
+    assert f["conv_chain"]["launches_per_step"] == 138 and abs(f["conv_chain"]["tflops"] - 17.3e12 / 81.0e-3 / 1e12) < 0.01
+    assert abs(f["conv_chain"]["frac"] - f["conv_chain"]["tflops"] / 419.4) < 1e-3 and abs(f["conv_chain"]["frac_of_sustained_mfma"] - f["conv_chain"]["tflops"] / 307.8) < 1e-3
+    assert f["conv_thin"]["frac"] is None and "vector-ALU" in f["conv_thin"]["note"]
+    assert f["wgrad_tile"]["mfma_busy"] is None and f["wgrad_tile"]["traffic"] is None      # no PMC record of that mode: never guessed
+    assert abs(tab["families_mfma_ms_per_step"] - (81.0 + 55.0 + 1.1)) < 0.01
+    # the committed records of the default mode belong to this tree's kernels (tools/pmc_stamp.py) and cover the families of the headline step
+    busy, traffic = bench.pmc_family_records("bf16x3")
+    if busy is not None:
+        for name in ("conv_chain", "conv_tile_3x3", "wgrad_tile", "conv_tile_4x4s2", "conv_tile_dgrad4x4s2"):
+            assert 0.0 < busy[name]["mfma_busy"] <= 1.0 and traffic[name]["hbm_bytes_per_launch"] > 0, name
