@@ -2,6 +2,7 @@
 # The ONE runner for everything that goes to the GPU box (gpurun -- 'bash tools/gpu.sh <cmd> <tag> ...'); logs land in gpurun_out/<tag>_*.
 #   suite <tag> [pytest args]        the -m gpu suite (both arithmetic modes, tests/conftest.py) + smoke
 #   prof  <tag> <bf16x3|f32> [bench args]   rocprofv3 kernel stats of 3 bench steps + separate PMC passes (HBM traffic, MFMA busy) of 1
+#   prof_i2i <tag> <pix2pix|cyclegan> <resnet|unet>   the PMC passes of one step of tools/bench_i2i.py
 #   final <tag>                      suite + default bench line (with cpu_baseline) + prof bf16x3: the validation of a tree
 #   power <tag> <name> <cmd...>      the command with rocm-smi sampled every 0.5 s next to it (clock, socket power, temperature)
 #   run   <tag> <name> <cmd...>      any command, output to gpurun_out/<tag>_<name>.txt (tail printed)
