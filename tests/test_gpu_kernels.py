@@ -302,6 +302,50 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
     assert ops.chain_error_flag() == 0
 
 
+def test_dense_block_sweeps_next_to_other_queues(mma_mode):
+    """One-launch dense blocks while OTHER hardware queues oversubscribe the chip -- what a data-parallel run's RCCL kernels or a
+    feeder's kernels do to them: two streams each running dense-block sweeps over their own buffers (2 x 256 workgroups that want a
+    CU each) and a third running 64-cout convolutions, enqueued without any synchronisation between them.  Every sweep must still
+    be bit-identical to its single-stream result and no hand-off wait may report a timeout.  The waits are bounded by a POLL COUNT
+    (conv_handoff.h): the clock-based bound they used to have fired spuriously next to other queues in tools/probes/overlap_probe.py
+    (4 runs of 11 against 0 of 11 with the poll count, results correct either way: profiles/r08a_handoff_bound.txt) -- this test
+    covers the situation; it did not reproduce that failure in 8 runs of the old bound, the probe is the record of it."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the sweep kernel is the dense block of the bf16x3 arithmetic")
+    from tools.probes.sweep_check import block
+    runs = [block(16, 128, 128, seed=51 + i, grad_shape=bool(i & 1), with_r2=True) for i in range(2)]
+    sets = []
+    for run in runs:
+        rb, ro, st = run("sweep")                        # single stream: the reference (and the stage list, bound to rb / ro)
+        sets.append((st, rb.clone(), ro.clone()))
+    # a third population: plain 64-cout 3x3 layers (weight-stream kernel, two workgroups per CU)
+    x3 = rnd(4, 64, 256, 256, seed=60)
+    w3 = rnd(64, 64, 3, 3, seed=61) * 0.1
+    xb3, yb3 = nhwc_buf(x3), torch.zeros((4, 256, 256, 64), device=DEV)
+    wp3, keep = pack(ops, w3.to(DEV), ops.PACK_FWD)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        # (the situation in which the clock-based bound fired in the probe: a deep queue of sweeps on the launch stream, the same blocks
+        #  -- same values, so the same results -- enqueued on a second stream meanwhile, other kernels on a third)
+        for _ in range(3):
+            for st, _, _ in sets:
+                ops.conv_chain(st)
+        for (st, _, _), s in zip(sets, streams):
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    ops.conv_chain(st)
+        with torch.cuda.stream(streams[2]):
+            for _ in range(4):
+                ops.conv(ops.View(xb3), wp3, ops.View(yb3))
+    torch.cuda.synchronize()
+    assert ops.chain_error_flag() == 0, "a hand-off wait reported a timeout next to other queues"
+    for i, (st, rb, ro) in enumerate(sets):
+        assert torch.equal(st[0]["x"].buf, rb) and torch.equal(st[-1]["y"].buf, ro), "sweep %d differs from its single-stream result" % i
+
+
 @pytest.mark.parametrize("case", [(2, 40, 72, 64, 64, "lrelu", False), (1, 8, 32, 32, 64, "plain", False), (3, 17, 33, 128, 128, "res", False),
                                   (2, 64, 64, 256, 256, "mask", True), (1, 32, 32, 512, 512, "plain", False), (2, 96, 160, 64, 128, "lrelu", True),
                                   (1, 9, 45, 96, 192, "res", False), (2, 24, 40, 64, 64, "noise", False),

@@ -46,11 +46,24 @@ struct ChainWait {
             const int yy = ty + t / 3 - 1, xx = tx + t % 3 - 1;
             if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) {
                 const unsigned *p = progress + ((size_t)n * tiles_y + yy) * tiles_x + xx;
+                // Bounded by the NUMBER OF POLLS, not by a clock: a poll is an agent-scope load round trip plus the sleep (>= ~0.5 us),
+                // so 2^22 of them are seconds of waiting.  The bound used to be s_memtime() - t0 > 2^32; with several queues
+                // oversubscribing the chip (two sweep launches and a third kernel on three streams, tools/probes/overlap_probe.py) it
+                // fired within milliseconds in 2 runs of 5 -- a wave that is context-saved and restored meanwhile does not see a
+                // continuous clock -- and a spurious timeout is worse than none: the tile reads unpublished data and the latch stops
+                // the run.  A poll count only advances while the wave runs.
+                unsigned polls = 0;
+#ifdef TNR_HANDOFF_CLOCK_BOUND     /* (probe build: the clock-based bound of rounds 2-4, kept to show the test next to other queues catches it) */
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
                 // (int) difference: robust to the counter base wrapping around
                 while ((int)(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) < 0) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {   // ~2 s: report instead of hanging the GPU
+#ifdef TNR_HANDOFF_CLOCK_BOUND
+                    if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {
+#else
+                    if (++polls > (1u << 22)) {                               // seconds: report instead of hanging the GPU
+#endif
                         *err = 1u;
                         break;
                     }
