@@ -501,6 +501,14 @@ def main():
                     "kernel_ms_per_step": per_step_ms}
             roof.update(family_table(summ, nprof, peak, "bf16x3amp" if args.amp else args.mma,
                                      307.8 if (args.mma == "bf16x3" and not args.amp) else None))
+            # Two of the ~25 boxes met in round 5 ran ONLY the dense-block sweep 1.6 x slower (935-941 vs 587-606 us per launch at this
+            # configuration; same MFMA-busy cycles, every other kernel at its usual rate: DESIGN.md 3.2, profiles/r07a_slowbox_*,
+            # r08b_slowbox_*).  Say so in the line when this run is one of them, so that the number is read for what it is.
+            if fam == "conv_chain" and args.mma == "bf16x3" and not args.amp and args.batch == BATCH_PER_GPU and args.crop == CROP \
+                    and roof["avg_launch_us"] > 760.0:
+                roof["box_note"] = ("the dense-block sweep ran %.0f us per launch on this box; 587-606 us on 23 of the 25 boxes measured in round 5 "
+                                    "(69 img/s there), 935-941 us on the other two, where the kernel's system-coherent tile hand-off path was slow "
+                                    "while every other kernel ran at its usual rate (DESIGN.md 3.2)" % roof["avg_launch_us"])
             if args.amp:
                 kname = "conv_sweep4_kernel<true, true> (a dense block's 5 convolutions per launch, bf16 operands)" if (fam == "conv_chain" and ops.CONV_SWEEP and ops.AMP_SWEEP) else kname
                 roof["kernel"] = kname
