@@ -571,6 +571,8 @@ def main():
                        "mma": "bf16 operands (use_amp)" if args.amp else MMA_TEXT[args.mma],
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none",
+                       # per-box choice between the one-launch dense block and five per-layer launches (bit-identical; ops.SWEEP_AUTO)
+                       "dense_block_form": dict(ops.SWEEP_AUTO_STATE),
                        "gradient_exchange": comm},
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of

@@ -302,6 +302,32 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
     assert ops.chain_error_flag() == 0
 
 
+def test_dense_block_form_is_chosen_per_box(mma_mode, monkeypatch):
+    """ops.SWEEP_AUTO: the first full-size dense block of a process is timed as one launch and as five per-layer launches and the
+    per-layer path is taken only where the sweep is more than 10 % slower (boxes whose coherent hand-off path is slow: DESIGN.md
+    3.2).  The calibration leaves the block computed, records both timings, and either choice gives the same bits."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the choice exists in the bf16x3 arithmetic (where the two forms are bit-identical)")
+    from tools.probes.sweep_check import block
+    monkeypatch.setattr(ops, "SWEEP_AUTO", True)
+    monkeypatch.setattr(ops, "SWEEP_AUTO_STATE", {"choice": None, "sweep_us": None, "layers_us": None})
+    run = block(8, 128, 128, seed=77, grad_shape=True, with_r2=True)          # 131 072 pixels: a full-size block
+    rb, ro, _ = run("layers")
+    gb, go, _ = run("sweep")                                                    # calibrates, then runs in the chosen form
+    st = ops.SWEEP_AUTO_STATE
+    assert st["choice"] in ("sweep", "layers") and st["sweep_us"] > 0 and st["layers_us"] > 0, st
+    assert (st["choice"] == "layers") == (st["sweep_us"] > 1.10 * st["layers_us"]), st
+    assert torch.equal(gb, rb) and torch.equal(go, ro)
+    for forced in ("layers", "sweep"):
+        ops.SWEEP_AUTO_STATE["choice"] = forced
+        gb, go, _ = run("sweep")
+        assert torch.equal(gb, rb) and torch.equal(go, ro), forced
+    print("dense-block form on this box:", st)
+    assert ops.chain_error_flag() == 0
+
+
 def test_dense_block_sweeps_next_to_other_queues(mma_mode):
     """One-launch dense blocks while OTHER hardware queues oversubscribe the chip -- what a data-parallel run's RCCL kernels or a
     feeder's kernels do to them: two streams each running dense-block sweeps over their own buffers (2 x 256 workgroups that want a

@@ -428,6 +428,45 @@ def _sweep_image(lib, descs, n, stages, dev):
     return ent[0]
 
 
+# Per-box choice between the one-launch dense block and five per-layer launches in TNR_MMA_BF16X3 (bit-identical results either way).
+# The sweep hands tiles over between workgroups through system-coherent stores / loads and agent-scope progress words: fabric traffic
+# that never touches L2.  On two of ~25 boxes met in round 5 that path was slow -- the sweep alone ran 1.6 x slower (935-941 vs 587-606 us
+# per launch at batch 16), every other kernel at its usual rate -- while the per-layer path (plain loads and stores,
+# 686 us on a normal box) does not use it.  So the first full-size dense block of a process is timed both ways (3 launches each, once,
+# ~10 ms) and the per-layer path is taken for the rest of the process if the sweep is more than 10 % SLOWER than it.  TNR_SWEEP_AUTO=0: off.
+SWEEP_AUTO = os.environ.get("TNR_SWEEP_AUTO", "1") != "0"
+SWEEP_AUTO_STATE = {"choice": None, "sweep_us": None, "layers_us": None}     # choice: None (not calibrated yet) | "sweep" | "layers"
+
+
+def _calibrate_dense_block(stages):
+    """Time the one-launch form and the per-layer form of `stages` on the current stream (re-executing a dense block is idempotent: its
+    inputs -- block input, residuals, masks -- are not written by it) and record the choice."""
+    global PROFILE
+    prof, PROFILE = PROFILE, None
+    SWEEP_AUTO_STATE["choice"] = "sweep"                # (the timed calls below go through conv_chain itself)
+    try:
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return 1e3 * a.elapsed_time(b) / 3.0
+
+        def layers():
+            for st in stages:
+                conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+
+        t_sweep, t_layers = timed(lambda: conv_chain(stages)), timed(layers)
+        t_sweep = min(t_sweep, timed(lambda: conv_chain(stages)))          # (the clock may still be ramping at a process's first launches)
+        SWEEP_AUTO_STATE.update(sweep_us=round(t_sweep, 1), layers_us=round(t_layers, 1), choice="layers" if t_sweep > 1.10 * t_layers else "sweep")
+    finally:
+        PROFILE = prof
+
+
 def conv_chain(stages):
     """Dependent 3x3 convolutions over one pixel grid in one launch (tnr_conv_chain).  stages: dicts with the
     arguments of conv() (x, wp, y, bias, act, ..., mask) plus fresh_from: first input channel produced by the
@@ -445,6 +484,13 @@ def conv_chain(stages):
     # stay one launch -- opt-in (TNR_DP_OVERLAP_G=1, models/sr_model.py) until a multi-GPU run has exercised it.
     crowded = COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES
     sweep_ok = CONV_SWEEP and n == 5 and ((MMA == hip.MMA_BF16X3 and CHAIN_X3) or (MMA == hip.MMA_BF16 and AMP_SWEEP))
+    auto = SWEEP_AUTO and CONV_CHAIN and eligible and sweep_ok and MMA == hip.MMA_BF16X3 and stages[0]["x"].buf.is_cuda
+    if auto and SWEEP_AUTO_STATE["choice"] is None and not crowded and stages[0]["x"].pixels >= 131072:
+        _calibrate_dense_block(stages)               # (once per process, on the first full-size block; leaves the block computed)
+    if auto and SWEEP_AUTO_STATE["choice"] == "layers":
+        for st in stages:
+            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+        return
     if not CONV_CHAIN or not eligible or (crowded and not (sweep_ok and SWEEP_DISPENSED)):
         if crowded and CONV_CHAIN and eligible:
             COUNTERS["per_layer_next_to_collectives"] += 1
