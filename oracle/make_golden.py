@@ -43,6 +43,9 @@ CASES = {
     # ESRGAN+ GaussianNoise ON (the reference's default, defaults.py:59): the reference's own module, with its draw taken from the
     # engine's counter-based field (ref_harness._substitute_gaussian_draw) -- pins where the noise sits and how its gradient flows
     "esrgan_nb2_crop64_gauss": dict(yaml=dict(nb=2, batch=2, crop=64, d_nf=16, gaussian=True), steps=3, seed=91, noise_seed=4242),
+    # BASELINE.json configs[1]'s BATCH (16) through the real reference at reduced size: BatchNorm statistics over 16 images, the
+    # relativistic means over 16 logits, 16 LR images = several tiles per launch; two steps (the second sees the updated D)
+    "esrgan_nb2_crop128_b16": dict(yaml=dict(nb=2, batch=16, crop=128, d_nf=16), steps=2, seed=111),
     # BASELINE.json configs[3]'s networks at full depth: RRDBNet-23 + UNetDiscriminator (discriminators.py:686-779), 128 -> ... crop 128
     "esrgan_nb23_unet_crop128_b2": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64, d_type="unet"), steps=1, seed=95),
 }

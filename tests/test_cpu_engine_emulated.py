@@ -57,7 +57,7 @@ def test_vgg_schedule():
 
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb2_crop64_k10",
-                                  "esrgan_nb1_unet", "esrgan_nb2_crop64_gauss"])
+                                  "esrgan_nb1_unet", "esrgan_nb2_crop64_gauss", "esrgan_nb2_crop128_b16"])
 def test_step_vs_reference_golden(case, tmp_path):
     TS.test_step_matches_reference_golden(case, tmp_path)
 

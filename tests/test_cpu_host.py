@@ -39,7 +39,8 @@ def test_no_device_fails_loudly():
 
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
-                                  "esrgan_nb2_crop64_k10", "esrgan_nb23_crop512_b2", "esrgan_nb23_crop512_b4", "esrgan_nb1_unet"])
+                                  "esrgan_nb2_crop64_k10", "esrgan_nb23_crop512_b2", "esrgan_nb23_crop512_b4", "esrgan_nb1_unet",
+                                  "esrgan_nb2_crop128_b16"])
 def test_options_and_state_dict_contract(case, tmp_path):
     """options.parse expands to the dicts the REAL reference produced (stored in the fixtures) and the
     engine's networks carry exactly the reference's state_dict keys and shapes."""

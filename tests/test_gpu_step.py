@@ -68,7 +68,8 @@ def check_logs(log, ref_log, tol=2e-4, d_tol=None):
                                   "esrgan_nb23_crop512_b4",      # the same at batch 4: BN + relativistic means over 4 images
                                   "esrgan_nb1_unet",             # network_D: unet (Real-ESRGAN's U-Net discriminator)
                                   "esrgan_nb23_unet_crop128_b2",  # BASELINE configs[3]'s networks at full depth: RRDBNet-23 + UNetDiscriminator
-                                  "esrgan_nb2_crop64_gauss"])    # gaussian: true (ESRGAN+ noise, the reference's default), 3 steps
+                                  "esrgan_nb2_crop64_gauss",     # gaussian: true (ESRGAN+ noise, the reference's default), 3 steps
+                                  "esrgan_nb2_crop128_b16"])     # BASELINE configs[1]'s BATCH (16) through the real reference at reduced size, 2 steps
 def test_step_matches_reference_golden(case, tmp_path):
     fx = FX.load(case)
     T = CASE_TOL.get(case, DEFAULT_TOL)

@@ -15,7 +15,8 @@ CASES = ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrga
          "esrgan_nb23_crop512_b2",       # BASELINE configs[1] resolution, batch 2 through Discriminator_VGG(512)
          "esrgan_nb1_unet",              # network_D: unet (UNetDiscriminator)
          "esrgan_nb23_unet_crop128_b2",  # RRDBNet-23 + UNetDiscriminator (BASELINE configs[3]'s networks)
-         "esrgan_nb2_crop64_gauss"]      # gaussian: true -- the reference's GaussianNoise on the engine's field
+         "esrgan_nb2_crop64_gauss",      # gaussian: true -- the reference's GaussianNoise on the engine's field
+         "esrgan_nb2_crop128_b16"]       # BASELINE configs[1]'s batch (16) through the real reference at reduced size, 2 steps
 LOG_RTOL = 2e-5
 STATE_MEAN = 0.01     # mean |dp| in units of lr*steps (the largest possible Adam displacement)
 STATE_WORST = 0.6     # a noise-gradient element may flip sign once: bounded, not tight
@@ -67,7 +68,8 @@ def test_oracle_matches_reference(case):
 
 
 @pytest.mark.parametrize("case,chunk", [("esrgan_nb2_crop64_gauss", 1),     # three steps, noise fields sliced per chunk
-                                        ("esrgan_nb23_crop512_b4", 2)])     # batch 4 as 2 chunks of 2
+                                        ("esrgan_nb23_crop512_b4", 2),      # batch 4 as 2 chunks of 2
+                                        ("esrgan_nb2_crop128_b16", 2)])     # the headline's batch 16 as 8 chunks of 2 (the GPU test's chunking), 2 steps
 def test_chunked_oracle_matches_reference(case, chunk):
     """OracleSRStep.step_chunked (the form that fits BASELINE configs[1]'s batch 16 into host memory: the chain rule cut at
     fake_H, generator backward chunk by chunk) against the REAL reference's goldens, with the bounds of
