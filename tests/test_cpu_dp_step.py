@@ -119,17 +119,23 @@ def test_eight_rank_step_equals_single_process(tmp_path, monkeypatch):
     test_two_rank_step_equals_single_process(tmp_path, monkeypatch, "gaussian", world=8)
 
 
-@pytest.mark.parametrize("variant", ["plain", "gaussian", "accumulate"])
+@pytest.mark.parametrize("variant", ["plain", "gaussian", "accumulate", "overlap_g"])
 def test_two_rank_step_equals_single_process(tmp_path, monkeypatch, variant, world=2):
-    """gaussian: with the ESRGAN+ noise on (the reference's default) -- every rank must draw the field of its own samples of the
+    """overlap_g: TNR_DP_OVERLAP_G=1 -- the generator's gradient buckets leave from inside its backward (opt-in since round 5; the
+    default, which every other variant runs, sends them at its optimizer step).
+    gaussian: with the ESRGAN+ noise on (the reference's default) -- every rank must draw the field of its own samples of the
     GLOBAL batch (`noise_pix0`), or the two halves of fake_H would not be the single process's.
     accumulate: virtual_batch_size = 2 x batch_size -- gradients accumulate locally over two calls and are exchanged once, before
     the optimizer step (the buckets do not leave from inside backward then); four calls = two optimizer steps."""
     gaussian, accumulate = variant == "gaussian", variant == "accumulate"
+    if variant == "overlap_g":
+        monkeypatch.setenv("TNR_DP_OVERLAP_G", "1")          # (the environment reaches the spawned ranks)
+    else:
+        monkeypatch.delenv("TNR_DP_OVERLAP_G", raising=False)
     steps = 2 * STEPS if accumulate else STEPS
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + (os.getpid() % 2000) + {"plain": 0, "gaussian": 7, "accumulate": 13}[variant]
+    port = 31000 + (os.getpid() % 2000) + {"plain": 0, "gaussian": 7, "accumulate": 13, "overlap_g": 19}[variant]
     procs = [ctx.Process(target=_worker, args=(r, world, port + world, str(tmp_path), q, "sr", gaussian, accumulate)) for r in range(world)]
     for p in procs:
         p.start()
