@@ -162,12 +162,13 @@ class DeviceFeeder:
         import queue
         import threading
         hip.load()                          # the library handle is created on THIS thread, before the worker can race for it
+        it = iter(self.loader)              # ... and so is the loader's iterator (a DataLoader starts its worker processes and installs
+                                            # its signal handling here: that belongs to the consumer's thread, not to ours)
         todo, done = queue.Queue(), queue.Queue()
         STOP = object()
 
         def work():
             torch.cuda.set_device(self.device)
-            it = iter(self.loader)
             try:
                 while True:
                     slot = todo.get()
