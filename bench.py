@@ -314,6 +314,78 @@ def pmc_mfma_busy(family, mode):
         return None
 
 
+def driver_visible_variants(args, model, data, device, rank, barrier, step):
+    """variant_amp / variant_feed_paired / variant_config4 of the default line: {value, ms_per_step, steps, warmup, dominant}."""
+    from trainner_amd import ops
+    from trainner_amd.data.feeder import DeviceFeeder
+    n_feed = 2 + args.steps + 1
+
+    def measure(mdl, next_batch, amp):
+        nonlocal step
+        for _ in range(2):
+            step += 1
+            mdl.feed_data(next_batch())
+            mdl.optimize_parameters(step)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step += 1
+            mdl.feed_data(next_batch())
+            mdl.optimize_parameters(step)
+        barrier()
+        dtv = time.perf_counter() - t0
+        prof = ops.ConvProfile()
+        ops.PROFILE = prof
+        step += 1
+        mdl.feed_data(next_batch())
+        mdl.optimize_parameters(step)
+        ops.PROFILE = None
+        summ = {k: v for k, v in prof.summary().items() if k not in ("conv_thin", "wgrad_thin") and v["ms"] > 0 and v["flops"] > 0}
+        if ops.chain_error_flag():
+            raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
+        dom = None
+        if summ:
+            fam = max(summ, key=lambda f: summ[f]["ms"])
+            tf = summ[fam]["flops"] / (summ[fam]["ms"] * 1e-3) / 1e12
+            peak = PEAK_BF16_MFMA_TFLOPS if amp else PEAK_BF16X3_TFLOPS
+            dom = {"family": fam, "ms_per_step": round(summ[fam]["ms"], 3), "launches_per_step": summ[fam]["launches"],
+                   "tflops": round(tf, 2), "peak": round(peak, 1), "frac": round(tf / peak, 4)}
+        return {"value": round(args.batch * args.steps / dtv, 3), "unit": "HR img/s", "ms_per_step": round(1e3 * dtv / args.steps, 2),
+                "steps": args.steps, "warmup": 2, "dominant": dom}
+
+    out = {}
+    # (1) use_amp: the same model with the AMP region on (bf16 matrix-core operands, fp32 accumulate and storage)
+    model.opt["use_amp"] = True
+    model.setup_amp()
+    v = measure(model, lambda: data, True)
+    v.update(dtype="bf16", what="`use_amp: true` (options/sr/train_sr.yml:6): same model, same batch, AMP region on")
+    out["variant_amp"] = v
+    model.opt["use_amp"] = False
+    model.setup_amp()
+    # (2) the input pipeline in the loop: uint8 host batches -> pinned H2D -> device np2tensor / flip / rot (DeviceFeeder)
+    feeder = DeviceFeeder(HostBatches(n_feed, args.batch, args.crop, 1000 + rank, True), device=device)
+    it = feeder.iterate()
+    v = measure(model, lambda: next(it), False)
+    v.update(dtype="f32 (bf16x3)", what="--feed paired: uint8 LR + HR host windows through the double-buffered DeviceFeeder",
+             h2d_bytes_per_step=feeder.bytes_uploaded // n_feed)
+    out["variant_feed_paired"] = v
+    feeder.close()
+    # (3) BASELINE configs[3] on one GPU: RRDBNet-23 + UNetDiscriminator, LR synthesised by the GPU degradation pipeline
+    from trainner_amd.dataops.degradations import RealESRGANDegradation
+    del model
+    torch.cuda.empty_cache()
+    m4 = make_model(args.batch, args.crop, rank, 1, "unet", False)
+    feeder = DeviceFeeder(HostBatches(n_feed, args.batch, args.crop, 1000 + rank, False), device=device,
+                          degrade=RealESRGANDegradation(scale=4, seed=rank))
+    it = feeder.iterate()
+    v = measure(m4, lambda: next(it), False)
+    v.update(dtype="f32 (bf16x3)", what="--netd unet --feed resrgan (BASELINE configs[3] at 1 GPU): U-Net discriminator, HR windows only, "
+                                        "Real-ESRGAN degradations on the GPU")
+    out["variant_config4"] = v
+    feeder.close()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
@@ -354,6 +426,9 @@ def main():
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check on CPU (gloo + tests/emul_backend.py, tiny shapes); the JSON line is marked invalid")
     args = ap.parse_args()
+    # dmabuf IPC (RCCL across processes on this driver).  Set HERE, not only in self_launch(): the driver's scaling run starts the ranks
+    # itself (`python -m torch.distributed.run ... bench.py --gpus N`) and never passes through self_launch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -437,7 +512,13 @@ def main():
                 "g_overlapped_with_backward": bool(ops.g_buckets_leave_in_backward()),
                 "dense_blocks_one_launch_next_to_collectives": ops.COUNTERS["one_launch_next_to_collectives"],
                 "dense_blocks_per_layer_next_to_collectives": ops.COUNTERS["per_layer_next_to_collectives"]}
+    per_rank_ms = [round(1e3 * dt / args.steps, 2)]
     if world > 1:
+        # every rank's own wall time of the timed region (a straggler shows here; `value` uses the MAX, as the contract says)
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allt, mine)
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 2) for x in allt]
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -554,6 +635,14 @@ def main():
                    "ms_per_step": round(1e3 * dtv / args.steps, 2), "steps": args.steps, "warmup": 2,
                    "dtype": "f32" if other == "f32" else "f32 (bf16x3)"}
 
+    # further variants the default 1-GPU line carries, each measured in this process AFTER the headline region
+    # (2 warm-up + `steps` timed steps + 1 instrumented step for its dominant kernel family): `use_amp`, the input pipeline in the loop,
+    # and BASELINE configs[3] on one GPU (U-Net discriminator + LR synthesised by the GPU degradation pipeline)
+    extra = {}
+    if world == 1 and not args.amp and not args.no_variant and not args.no_roofline and feeder is None and not dry \
+            and args.netd == "discriminator_vgg" and args.mma == "bf16x3":
+        extra = driver_visible_variants(args, model, data, device, rank, barrier, step)
+
     if rank == 0:
         imgs = args.batch * world * args.steps
         memo_any = bool(getattr(getattr(model, "netD", None), "memoize", False))
@@ -572,7 +661,10 @@ def main():
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none",
                        # per-box choice between the one-launch dense block and five per-layer launches (bit-identical; ops.SWEEP_AUTO)
+                       # chosen ONCE at model set-up on a scratch block of this shape and agreed on by all ranks (all-reduce MAX); `per_rank`
+                       # (N > 1) = every rank's own measurement, so a split vote or a slow box is visible in this one line
                        "dense_block_form": dict(ops.SWEEP_AUTO_STATE),
+                       "per_rank_ms_per_step": per_rank_ms,
                        "gradient_exchange": comm},
             # executed work: with the discriminator's repeated forwards memoized (engine.HipNet.memoize: the D-stage forwards over
             # the real / generated batch reuse the generator stage's -- same inputs, same weights, bit-identical results) two of
@@ -582,6 +674,9 @@ def main():
             "d_forward_memoized": memo_any,
             "roofline": roof,
             (variant_key or "variant_f32_mfma"): variant,
+            "variant_amp": extra.get("variant_amp"),
+            "variant_feed_paired": extra.get("variant_feed_paired"),
+            "variant_config4": extra.get("variant_config4"),
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
         if feeder is not None:

@@ -180,6 +180,12 @@ typedef struct tnr_dense_pack_item {
 } tnr_dense_pack_item;
 
 const char *tnr_last_error(void);
+/* ABI version = TNR_ABI_VERSION of the header the library was built from.  It moves whenever a descriptor struct changes size or
+ * layout: a caller built against another header would pass a shorter struct and the library would read fields from adjacent memory.
+ * Consumers compare it with THEIR header's TNR_ABI_VERSION before the first call (trainner_amd/hip.py does).
+ *   1: rounds 1-4.   2: tnr_wgrad_desc gained dw2 / cout_split / cin_total2 / db2, TNR_WGRAD_GROUP_MAX 8 -> 12 (round 5; the number
+ *      itself was bumped in round 6).                                                                                   */
+#define TNR_ABI_VERSION 2
 int tnr_version(void);
 
 /* --- convolution family ---------------------------------------------------------------------- */

@@ -32,7 +32,7 @@ def vgg_state(seed):
 
 
 def initial_states(fx):
-    g = initial_state(fx["g_keys"], fx["seeds"]["G"])
+    g = initial_state(fx["g_keys"], fx["seeds"]["G"], **({"gain": fx["spec"]["g_gain"]} if "g_gain" in fx["spec"] else {}))
     d = initial_state(fx["d_keys"], fx["seeds"]["D"]) if fx["d_keys"] else None
     f = vgg_state(fx["seeds"]["F"]) if fx["spec"]["yaml"].get("feature", True) else None
     return g, d, f

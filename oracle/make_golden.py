@@ -48,6 +48,12 @@ CASES = {
     "esrgan_nb2_crop128_b16": dict(yaml=dict(nb=2, batch=16, crop=128, d_nf=16), steps=2, seed=111),
     # BASELINE.json configs[3]'s networks at full depth: RRDBNet-23 + UNetDiscriminator (discriminators.py:686-779), 128 -> ... crop 128
     "esrgan_nb23_unet_crop128_b2": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64, d_type="unet"), steps=1, seed=95),
+    # SURVEY.md 8(d) parity metric K = 10 at the headline DEPTH: ten consecutive G+D steps of RRDBNet-23 + Discriminator_VGG(128, nf 64)
+    # + VGG19 at batch 2 -- a ten-step trajectory of the 23-block trunk through the real reference (round 6, VERDICT r5 item 6 i)
+    # G filled at gain 0.1 -- the scale the reference itself initialises RRDBNet with (kaiming x 0.1, networks.py:61-75,102-119): at the
+    # other cases' gain 0.5 a 23-block trunk amplifies rounding noise so much over ten sign-like Adam steps that two fp32 CPU
+    # implementations of the same math part ways by 2 % of the image (measured: this restatement vs the reference)
+    "esrgan_nb23_crop128_b2_k10": dict(yaml=dict(nb=23, batch=2, crop=128, d_nf=64), steps=10, seed=131, g_gain=0.1),
 }
 
 G_SEED, D_SEED, F_SEED = 101, 202, 77
@@ -67,7 +73,7 @@ def probe_state(sd):
 def run_case(name, spec):
     yml = R.esrgan_yaml(name="golden_" + name, **spec["yaml"])
     opt, model = R.build_reference_model(yml, seed=0, noise_seed=spec.get("noise_seed"))
-    detrand.fill_state_dict_(model.netG.state_dict(), G_SEED)
+    detrand.fill_state_dict_(model.netG.state_dict(), G_SEED, **({"gain": spec["g_gain"]} if "g_gain" in spec else {}))
     has_d = bool(getattr(model, "cri_gan", False))
     if has_d:
         detrand.fill_state_dict_(model.netD.state_dict(), D_SEED)

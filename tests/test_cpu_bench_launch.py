@@ -25,6 +25,22 @@ def test_bench_self_launches_two_ranks():
     for k in ("metric", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "variant_f32_mfma"):
         assert k in j, k
     assert j["variant_f32_mfma"] is None and j["dtype"] == "f32 (bf16x3)" and j["config"]["mma"].startswith("fp32 arithmetic on the bf16 matrix core")
+    for k in ("variant_amp", "variant_feed_paired", "variant_config4"):      # 1-GPU-only measurements: present, null here
+        assert k in j and j[k] is None, k
+    check_first_multi_gpu_run_keys(j, 2)
+
+
+def check_first_multi_gpu_run_keys(j, world):
+    """What a first real N-GPU run must show in its ONE line: the IPC mode RCCL starts with, every rank's own step
+    time (a straggler), every rank's dense-block form record and the form all ranks agreed on (a split vote)."""
+    c = j["config"]
+    assert c["hsa_enable_ipc_mode_legacy"] == "0"                    # defaulted in bench.main() itself, not only by self_launch
+    assert len(c["per_rank_ms_per_step"]) == world and all(t > 0 for t in c["per_rank_ms_per_step"])
+    assert max(c["per_rank_ms_per_step"]) == j["ms_per_step"]
+    form = c["dense_block_form"]
+    assert [r["rank"] for r in form["per_rank"]] == list(range(world))
+    assert all(set(r) >= {"choice", "sweep_us", "layers_us"} for r in form["per_rank"])
+    assert form["choice"] is None                                    # nothing to time on the CPU stand-in: the default form
 
 
 def test_bench_under_the_drivers_eight_rank_launch():
@@ -45,3 +61,4 @@ def test_bench_under_the_drivers_eight_rank_launch():
     assert j["config"]["global_batch"] == 16 and j["scaling"] == "weak" and j["steps"] == 1 and j["warmup"] == 1
     assert j["value"] is None and j["invalid"] == "dry run"
     assert all(v == v for v in j["losses"].values())
+    check_first_multi_gpu_run_keys(j, 8)

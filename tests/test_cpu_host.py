@@ -23,7 +23,7 @@ def test_library_exports_match_header():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tnr_version() >= 1
+    assert lib.tnr_version() == hip.ABI_VERSION == 2          # (header TNR_ABI_VERSION; a mismatch raises in hip.load)
 
 
 def test_no_device_fails_loudly():
@@ -40,7 +40,7 @@ def test_no_device_fails_loudly():
 
 @pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrgan_nb23_crop128",
                                   "esrgan_nb2_crop64_k10", "esrgan_nb23_crop512_b2", "esrgan_nb23_crop512_b4", "esrgan_nb1_unet",
-                                  "esrgan_nb2_crop128_b16"])
+                                  "esrgan_nb2_crop128_b16", "esrgan_nb23_crop128_b2_k10"])
 def test_options_and_state_dict_contract(case, tmp_path):
     """options.parse expands to the dicts the REAL reference produced (stored in the fixtures) and the
     engine's networks carry exactly the reference's state_dict keys and shapes."""
@@ -200,6 +200,26 @@ def test_fused_adam_state_layout_matches_torch_adam():
     opt.load_state_dict(sd)                                            # moments are re-homed into flat buffers
     p0 = opt.param_groups[0]["params"][0]
     assert opt.state[p0]["exp_avg"].shape == p0.shape
+
+
+def test_fused_adam_resumes_a_checkpoint_with_lagging_step_counts(monkeypatch):
+    """A torch.optim.Adam checkpoint may carry different `step` values inside one group (a parameter that was frozen for a while
+    lags): FusedAdam resumes it with the most advanced count and a warning; TNR_STRICT_OPTIM_STATE=1 makes it an error."""
+    from trainner_amd.models.modules.architectures.SRResNet_arch import SRResNet
+    from trainner_amd.models.optimizers import FusedAdam
+    net = SRResNet(3, 3, 32, 1)
+    net.flat_params()
+    opt = FusedAdam(list(net.parameters()), lr=1e-4)
+    for g in opt.param_groups:
+        opt._ensure_state(g)
+    sd = opt.state_dict()
+    for i, st in sd["state"].items():
+        st["step"] = torch.tensor(7.0 if i else 3.0)                  # parameter 0 lags
+    opt.load_state_dict(sd)
+    assert opt._t[0] == 7
+    monkeypatch.setenv("TNR_STRICT_OPTIM_STATE", "1")
+    with pytest.raises(ValueError):
+        opt.load_state_dict(sd)
 
 
 def test_psnr_definition():

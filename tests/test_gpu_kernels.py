@@ -303,9 +303,11 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
 
 
 def test_dense_block_form_is_chosen_per_box(mma_mode, monkeypatch):
-    """ops.SWEEP_AUTO: the first full-size dense block of a process is timed as one launch and as five per-layer launches and the
-    per-layer path is taken only where the sweep is more than 10 % slower (boxes whose coherent hand-off path is slow: DESIGN.md
-    3.2).  The calibration leaves the block computed, records both timings, and either choice gives the same bits."""
+    """ops.SWEEP_AUTO: a dense block of the training shape is timed ONCE, explicitly (ops.calibrate_dense_block_form -- the models call
+    it from their constructor on scratch buffers, never from inside a forward), as one launch and as five per-layer launches, and the
+    per-layer path is taken only where the sweep is more than 10 % slower (boxes whose coherent hand-off path is slow: DESIGN.md 3.2).
+    The calibration records both timings, either choice gives the same bits, an uncalibrated process runs the sweep, and a block whose
+    output aliases one of its inputs is refused (re-executing it would not be idempotent)."""
     ops = _ops()
     from trainner_amd import hip
     if ops.MMA != hip.MMA_BF16X3:
@@ -314,18 +316,41 @@ def test_dense_block_form_is_chosen_per_box(mma_mode, monkeypatch):
     monkeypatch.setattr(ops, "SWEEP_AUTO", True)
     monkeypatch.setattr(ops, "SWEEP_AUTO_STATE", {"choice": None, "sweep_us": None, "layers_us": None})
     run = block(8, 128, 128, seed=77, grad_shape=True, with_r2=True)          # 131 072 pixels: a full-size block
-    rb, ro, _ = run("layers")
-    gb, go, _ = run("sweep")                                                    # calibrates, then runs in the chosen form
-    st = ops.SWEEP_AUTO_STATE
+    rb, ro, stages = run("layers")
+    rb, ro = rb.clone(), ro.clone()
+    gb, go, _ = run("sweep")                                                    # NOT calibrated: the sweep, no timing inside the call
+    assert ops.SWEEP_AUTO_STATE["choice"] is None and ops.SWEEP_AUTO_STATE["sweep_us"] is None
+    assert torch.equal(gb, rb) and torch.equal(go, ro)
+    st = ops.calibrate_dense_block_form(stages)
     assert st["choice"] in ("sweep", "layers") and st["sweep_us"] > 0 and st["layers_us"] > 0, st
     assert (st["choice"] == "layers") == (st["sweep_us"] > 1.10 * st["layers_us"]), st
-    assert torch.equal(gb, rb) and torch.equal(go, ro)
     for forced in ("layers", "sweep"):
         ops.SWEEP_AUTO_STATE["choice"] = forced
         gb, go, _ = run("sweep")
         assert torch.equal(gb, rb) and torch.equal(go, ro), forced
     print("dense-block form on this box:", st)
+    bad = [dict(s) for s in stages]
+    bad[-1]["y"] = ops.View(bad[0]["x"].buf, 0, bad[-1]["y"].C)                # the block's output over its own input channels
+    with pytest.raises(AssertionError):
+        ops.calibrate_dense_block_form(bad)
     assert ops.chain_error_flag() == 0
+
+
+def test_model_constructor_calibrates_the_dense_block_form(mma_mode, monkeypatch, tmp_path):
+    """SRModel.__init__ -> calibrate_engine: the choice exists before the first step, measured on the TRAINING shape (batch x crop / scale)."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("bf16x3 only")
+    from oracle import ref_harness
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    monkeypatch.setattr(ops, "SWEEP_AUTO", True)
+    monkeypatch.setattr(ops, "SWEEP_AUTO_STATE", {"choice": None, "sweep_us": None, "layers_us": None})
+    opt = options.parse(ref_harness.esrgan_yaml(name="calib", out_root=str(tmp_path), gpu_ids="[0]", nb=1, batch=2, crop=128, d_nf=16), is_train=True)
+    create_model(opt, verbose=False)
+    st = ops.SWEEP_AUTO_STATE
+    assert st["choice"] in ("sweep", "layers") and st["sweep_us"] > 0 and st["layers_us"] > 0, st
 
 
 def test_dense_block_sweeps_next_to_other_queues(mma_mode):

@@ -16,10 +16,14 @@ CASES = ["cfg1_srresnet", "esrgan_nb1_crop64", "esrgan_nb1_pixelshuffle", "esrga
          "esrgan_nb1_unet",              # network_D: unet (UNetDiscriminator)
          "esrgan_nb23_unet_crop128_b2",  # RRDBNet-23 + UNetDiscriminator (BASELINE configs[3]'s networks)
          "esrgan_nb2_crop64_gauss",      # gaussian: true -- the reference's GaussianNoise on the engine's field
+         "esrgan_nb23_crop128_b2_k10",   # K = 10 at the headline DEPTH: RRDBNet-23 + D_VGG(128, nf 64) + VGG19, batch 2 (round 6)
          "esrgan_nb2_crop128_b16"]       # BASELINE configs[1]'s batch (16) through the real reference at reduced size, 2 steps
 LOG_RTOL = 2e-5
 STATE_MEAN = 0.01     # mean |dp| in units of lr*steps (the largest possible Adam displacement)
 STATE_WORST = 0.6     # a noise-gradient element may flip sign once: bounded, not tight
+# fake_H after the LAST step, max |d| in units of max(1, |ref|max).  Ten steps of the 23-block trunk: measured drift of this restatement
+# against the reference 1.8e-4 (both fp32 torch-CPU; logs <= 1.5e-4, PSNR identical to 1e-9 dB) -- the other cases stay at 1e-4
+FAKE_MAX = {"esrgan_nb23_crop128_b2_k10": 4e-4}
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -55,7 +59,7 @@ def test_oracle_matches_reference(case):
                     assert e_s < 2e-3 and e_n < 2e-3, (case, "D grad", k, e_s, e_n)
     ref = fx["fake_H"]
     diff = (orc.fake_H.detach() - ref).abs()
-    assert diff.max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), diff.max().item()
+    assert diff.max().item() <= FAKE_MAX.get(case, 1e-4) * max(1.0, ref.abs().max().item()), diff.max().item()
     lr_steps = 1e-4 * fx["spec"]["steps"]
     worst, mean, k = FX.state_error(orc.g_state(), fx["g_state"], lr_steps=lr_steps)
     assert mean < STATE_MEAN and worst < STATE_WORST, ("G state", k, worst, mean)

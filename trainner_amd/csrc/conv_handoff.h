@@ -52,7 +52,12 @@ struct ChainWait {
                 // fired within milliseconds in 2 runs of 5 -- a wave that is context-saved and restored meanwhile does not see a
                 // continuous clock -- and a spurious timeout is worse than none: the tile reads unpublished data and the latch stops
                 // the run.  A poll count only advances while the wave runs.
+                // Round 6: the poll count alone can still run out falsely -- when the PRODUCER workgroup is the one that is
+                // context-saved for a long time, the consumer polls at full rate meanwhile -- so a fault needs BOTH bounds: 2^22 polls AND
+                // >= 2^28 ticks of the constant-rate 100 MHz counter (s_memrealtime: continuous across a context save, unlike s_memtime;
+                // 2.7 s of wall time, whatever the shader clock).  Minimum wall time before a fault is declared: 2.7 s.
                 unsigned polls = 0;
+                const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #ifdef TNR_HANDOFF_CLOCK_BOUND     /* (probe build: the clock-based bound of rounds 2-4, kept to show the test next to other queues catches it) */
                 const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -62,7 +67,8 @@ struct ChainWait {
 #ifdef TNR_HANDOFF_CLOCK_BOUND
                     if (__builtin_amdgcn_s_memtime() - t0 > (4ull << 30)) {
 #else
-                    if (++polls > (1u << 22)) {                               // seconds: report instead of hanging the GPU
+                    // (the real-time counter is read once per 1024 polls beyond the count bound)
+                    if (++polls > (1u << 22) && (polls & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() - rt0 > (1ull << 28)) {
 #endif
                         *err = 1u;
                         break;

@@ -29,7 +29,7 @@ extern "C" int tnr_set_fault_word(uint32_t *dev_word) {
     g_fault_word = dev_word;
     return TNR_OK;
 }
-extern "C" int tnr_version(void) { return 1; }
+extern "C" int tnr_version(void) { return TNR_ABI_VERSION; }
 
 extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, int32_t kind, int32_t *KoutP,
                              int32_t *KinP, int64_t *n_out) {

@@ -91,6 +91,11 @@ class DPGroup:
             return
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
+    def all_reduce_max(self, t):
+        """Element-wise MAX over the ranks, in place, on the current stream (the fault latch: one int32 word)."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+
     def mean_scalar(self, t):
         """Global-batch mean of a per-rank mean (equal shards): what nn.DataParallel's gather-then-loss reports."""
         if not self.active:
@@ -213,5 +218,6 @@ def init_from_env():
         if use_cuda:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: this driver's only mode (RCCL / tensor sharing across processes)
         dist.init_process_group(backend="nccl" if use_cuda else "gloo")
     return DPGroup()

@@ -170,6 +170,9 @@ def library_path():
     return os.environ.get("TNR_HIP_LIB") or _build.LIB
 
 
+ABI_VERSION = 2          # include/trainner_hip.h TNR_ABI_VERSION: the descriptor layouts below are those of this version
+
+
 def load(build_if_missing=False):
     """dlopen the in-tree library and type every export.  Raises if it is absent."""
     global _lib
@@ -188,6 +191,9 @@ def load(build_if_missing=False):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.tnr_version() != ABI_VERSION:
+        raise HipEngineError("%s speaks ABI version %d, this binding expects %d (include/trainner_hip.h TNR_ABI_VERSION): rebuild with "
+                             "`python -m trainner_amd.build --force`" % (path, lib.tnr_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -128,7 +128,9 @@ class BaseModel:
         """Host-side read of the fault latch (ops.fault_word) at points that synchronise anyway (log read-out, checkpoint).  A tile
         hand-off wait of a one-launch dense block that timed out computed with unpublished neighbour tiles: the latch is sticky and
         every Adam launch runs behind it ON THE DEVICE (tnr_adam_step_guarded), so no optimiser step is applied from the faulted
-        launch on -- the weights here are those of the last healthy step -- and the run stops at this check."""
+        launch on -- the weights here are those of the last healthy step -- and the run stops at this check.  Data-parallel ranks
+        share the latch (MAX-reduced with every gradient exchange, _sync_gradients): all of them stop at the same step.  Only the
+        weights and Adam's moments are protected; BatchNorm running statistics and the step counters of the faulted step have moved."""
         if ops.chain_error_flag():
             raise hip.HipEngineError("a tile hand-off wait inside a one-launch dense block timed out (another tenant on the GPU kept "
                                      "the workgroups from being resident?): no optimiser step has been applied since; restart with "
@@ -433,6 +435,14 @@ class BaseModel:
         if timed:                                   # bench.py: the EXPOSED part of the exchange = how long the compute stream sits
             e0 = torch.cuda.Event(enable_timing=True)      # between the last backward kernel and the first optimiser kernel
             e0.record(torch.cuda.current_stream(self.device))
+        # the fault latch is agreed on with the gradients: a rank whose dense-block launch faulted would skip its Adam step
+        # alone, the replicas would diverge and its peers would block in the next all-reduce while it raises.  MAX over the ranks on
+        # the compute stream, in front of the guarded Adam launches: from the faulted step on NO rank applies an update and every
+        # rank's own check_engine_errors() raises.  (What the latch protects is the WEIGHTS and Adam's moments; BatchNorm running
+        # statistics, schedulers and FusedAdam's host-side step counter of the faulted step have already advanced -- the run stops
+        # at the next host check, it is not resumable from memory.)
+        if ops._FAULT is not None and ops._FAULT.device.type == self.device.type:
+            self.dp.all_reduce_max(ops._FAULT)
         for net in self._opt_nets[opt_flag]:
             holder = net.flat_params()
             sched = getattr(net, "_bucket_schedule", None)

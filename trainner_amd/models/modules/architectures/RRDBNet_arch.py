@@ -173,6 +173,26 @@ class RRDBNet(HipNet):
             saved = dict(lr=lr, bufs=bufs, trunk=trunk, y0=y0, stages=stages, hr_in=cur, h0=h0, shape=(N, h, w), noise=nz)
         return out, saved
 
+    def calibrate_dense_block_form(self, N, h, w, dp=None):
+        """ops.calibrate_dense_block_form on a SCRATCH dense block of the training shape (N x h x w LR pixels): the first block's weights,
+        random activations in a 192-channel buffer of its own, the output in a second buffer -- nothing the network keeps is touched.
+        Called once by the model's constructor (every data-parallel rank at the same point)."""
+        dev = next(self.parameters()).device
+        if not self.nb or dev.type != "cuda":
+            return ops.calibrate_dense_block_form(None, dp)
+        nf, gc = self.nf, self.gc
+        self._prepare(torch.empty(1, self.in_nc, 8, 8, device=dev))      # the packed layouts of the current weights (what a forward does first)
+        buf, res = new_act(N, h, w, nf + 4 * gc, dev), new_act(N, h, w, nf, dev)
+        out = new_act(N, h, w, nf, dev)
+        buf.normal_(0.0, 0.5)
+        res.normal_(0.0, 0.5)
+        convs, st = self._ops["rdb"][0], []
+        for k in range(4):
+            cin = nf + gc * k
+            st.append(convs[k].fwd_stage(View(buf, 0, cin), View(buf, cin, gc), fresh_from=(cin - gc if k else None), act=self.act, slope=self.slope))
+        st.append(convs[4].fwd_stage(View(buf), View(out), fresh_from=nf + 3 * gc, alpha=0.2, r1=View(buf, 0, nf), r2=View(res), alpha2=0.2))
+        return ops.calibrate_dense_block_form(st, dp)
+
     def _draw_noise(self, nrdb, hw):
         if not (self.training and self.noise_sigma != 0.0):
             return None

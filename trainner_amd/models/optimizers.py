@@ -9,6 +9,7 @@ written by either engine resume in the other (base_model.py:454-500).
 """
 import logging
 import math
+import os
 
 import torch
 
@@ -112,9 +113,17 @@ class FusedAdam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             steps = {int(float(self.state[p]["step"])) for p in group["params"] if p in self.state and "step" in self.state[p]}
             if len(steps) > 1:
-                raise ValueError("FusedAdam: the parameters of one group carry different step counts %s" % sorted(steps))
+                # a torch.optim.Adam checkpoint may legitimately hold this: a parameter whose grad was None for some steps (frozen
+                # or unfrozen mid-run) lags the others.  FusedAdam keeps ONE counter per group (its bias correction is a launch
+                # argument): resume from the most advanced one -- what the bulk of the parameters had -- and say so.
+                # TNR_STRICT_OPTIM_STATE=1 turns this into an error.
+                msg = "FusedAdam: the parameters of group %d carry different step counts %s; resuming with step %d for all of them" % (
+                    gi, sorted(steps), max(steps))
+                if os.environ.get("TNR_STRICT_OPTIM_STATE") == "1":
+                    raise ValueError(msg)
+                logger.warning(msg)
             if steps:
-                self._t[gi] = steps.pop()
+                self._t[gi] = max(steps)
             self._ensure_state(group)
 
 

@@ -61,7 +61,19 @@ class SRModel(BaseModel):
             self.setup_gradclip(opt_G_nets)
         if self.is_train:
             self.sync_replicas()
+            self.calibrate_engine()
         self.print_network(verbose=False)
+
+    def calibrate_engine(self):
+        """Per-box kernel-form choices that rest on a timing, made ONCE here on scratch buffers of the training shape (this rank's
+        shard of `batch_size` x crop_size / scale) and agreed on by all data-parallel ranks -- never inside a forward (ops.SWEEP_AUTO)."""
+        from .. import ops
+        if not hasattr(self.netG, "calibrate_dense_block_form") or not ops.SWEEP_AUTO or getattr(self, "amp", False):
+            return            # (`use_amp` steps run the bf16-operand forms: no choice to make)
+        ds = self.opt["datasets"]["train"]
+        per = max(1, int(ds["batch_size"]) // max(1, self.dp.world_size))
+        lr_size = max(8, int(ds.get("crop_size") or 128) // int(self.opt.get("scale") or 4))
+        self.netG.calibrate_dense_block_form(per, lr_size, lr_size, self.dp)
 
     def feed_data(self, data, need_HR=True):
         self.var_L = self._shard(data["LR"]).to(self.device, non_blocking=True)

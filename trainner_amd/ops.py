@@ -432,18 +432,34 @@ def _sweep_image(lib, descs, n, stages, dev):
 # The sweep hands tiles over between workgroups through system-coherent stores / loads and agent-scope progress words: fabric traffic
 # that never touches L2.  On two of ~25 boxes met in round 5 that path was slow -- the sweep alone ran 1.6 x slower (935-941 vs 587-606 us
 # per launch at batch 16), every other kernel at its usual rate -- while the per-layer path (plain loads and stores,
-# 686 us on a normal box) does not use it.  So the first full-size dense block of a process is timed both ways (3 launches each, once,
-# ~10 ms) and the per-layer path is taken for the rest of the process if the sweep is more than 10 % SLOWER than it.  TNR_SWEEP_AUTO=0: off.
+# 686 us on a normal box) does not use it.  The choice is made EXPLICITLY, once, when a training model is set up
+# (`calibrate_dense_block_form`, called by SRModel with a scratch block of the TRAINING shape -- never from inside a forward, whose first
+# full-size call could be a validation or tiled-inference shape): both forms are timed (3 launches each, ~10 ms) and the per-layer path
+# is taken if the sweep is more than 10 % SLOWER than it.  Data-parallel ranks agree on ONE form (all-reduce MAX: if any rank's sweep is
+# slow every rank runs per-layer launches -- a rank that kept the slow sweep would be the step's straggler) and every rank's own
+# measurement is kept in SWEEP_AUTO_STATE["per_rank"] (bench.py prints it).  Not calibrated (choice None): the sweep.  TNR_SWEEP_AUTO=0: off.
 SWEEP_AUTO = os.environ.get("TNR_SWEEP_AUTO", "1") != "0"
-SWEEP_AUTO_STATE = {"choice": None, "sweep_us": None, "layers_us": None}     # choice: None (not calibrated yet) | "sweep" | "layers"
+SWEEP_AUTO_STATE = {"choice": None, "sweep_us": None, "layers_us": None}     # choice: None (not calibrated) | "sweep" | "layers"
+
+
+def _stage_views(st):
+    return [st[k] for k in ("x", "y", "r1", "r2", "mask") if st.get(k) is not None]
 
 
 def _calibrate_dense_block(stages):
-    """Time the one-launch form and the per-layer form of `stages` on the current stream (re-executing a dense block is idempotent: its
-    inputs -- block input, residuals, masks -- are not written by it) and record the choice."""
+    """Time the one-launch form and the per-layer form of `stages` on the current stream and record this process's own choice.  The block
+    is executed several times, which is only idempotent when no stage writes what another launch of the block reads: the LAST stage's
+    output must not share a buffer with any input (the four inner stages write channel groups of the dense buffer that the block itself
+    produces) -- asserted, not assumed."""
     global PROFILE
+    out = stages[-1]["y"]
+    for st in stages:
+        for v in _stage_views(st):
+            if v is not out and v.buf.data_ptr() == out.buf.data_ptr():
+                lo, hi = max(v.coff, out.coff), min(v.coff + v.C, out.coff + out.C)
+                assert hi <= lo, "calibration re-executes the block: its output must not alias an input (channels [%d, %d))" % (lo, hi)
     prof, PROFILE = PROFILE, None
-    SWEEP_AUTO_STATE["choice"] = "sweep"                # (the timed calls below go through conv_chain itself)
+    prev = SWEEP_AUTO_STATE["choice"]
     try:
         def timed(fn):
             fn()
@@ -460,11 +476,52 @@ def _calibrate_dense_block(stages):
             for st in stages:
                 conv(**{k: v for k, v in st.items() if k != "fresh_from"})
 
+        SWEEP_AUTO_STATE["choice"] = "sweep"                # (the timed calls below go through conv_chain itself)
         t_sweep, t_layers = timed(lambda: conv_chain(stages)), timed(layers)
         t_sweep = min(t_sweep, timed(lambda: conv_chain(stages)))          # (the clock may still be ramping at a process's first launches)
-        SWEEP_AUTO_STATE.update(sweep_us=round(t_sweep, 1), layers_us=round(t_layers, 1), choice="layers" if t_sweep > 1.10 * t_layers else "sweep")
+        prev = "layers" if t_sweep > 1.10 * t_layers else "sweep"
+        SWEEP_AUTO_STATE.update(sweep_us=round(t_sweep, 1), layers_us=round(t_layers, 1))
     finally:
+        SWEEP_AUTO_STATE["choice"] = prev
         PROFILE = prof
+
+
+def dense_block_form_applies(stages):
+    return (SWEEP_AUTO and CONV_CHAIN and CONV_SWEEP and CHAIN_X3 and len(stages) == 5 and FP32_MMA == hip.MMA_BF16X3 and
+            stages[0]["x"].buf.is_cuda and
+            all(st.get("mode", CONV_3x3) == CONV_3x3 and st["y"].C % 32 == 0 and st["wp"].KoutP == st["y"].C for st in stages))
+
+
+def calibrate_dense_block_form(stages, dp=None):
+    """The explicit per-box calibration (see above).  stages: a dense block over SCRATCH buffers of the training shape (None: nothing to
+    time here -- a CPU stand-in run -- but the ranks still exchange their records).  dp: the
+    data-parallel group -- every rank must call this at the same point (two small collectives).  Returns SWEEP_AUTO_STATE."""
+    applies = bool(stages) and dense_block_form_applies(stages)
+    if applies:
+        prev, globals()["MMA"] = MMA, FP32_MMA               # (the fp32 arithmetic of the step, also when called inside an amp region)
+        try:
+            _calibrate_dense_block(stages)
+        finally:
+            globals()["MMA"] = prev
+    SWEEP_AUTO_STATE["own_choice"] = SWEEP_AUTO_STATE["choice"]
+    if dp is not None and dp.active:
+        import torch.distributed as dist
+        dev = stages[0]["x"].buf.device if (stages and stages[0]["x"].buf.is_cuda and dist.get_backend(dp.group) == "nccl") else torch.device("cpu")
+        mine = torch.tensor([1.0 if SWEEP_AUTO_STATE["choice"] == "layers" else 0.0, float(SWEEP_AUTO_STATE["sweep_us"] or 0.0),
+                             float(SWEEP_AUTO_STATE["layers_us"] or 0.0), 1.0 if applies else 0.0], dtype=torch.float32, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(dp.world_size)]
+        dist.all_gather(allr, mine, group=dp.group)
+        rows = [t.cpu().tolist() for t in allr]
+        SWEEP_AUTO_STATE["per_rank"] = [{"rank": r, "choice": (("layers" if v[0] else "sweep") if v[3] else None),
+                                         "sweep_us": round(v[1], 1) or None, "layers_us": round(v[2], 1) or None} for r, v in enumerate(rows)]
+        if any(v[3] for v in rows):
+            SWEEP_AUTO_STATE["choice"] = "layers" if any(v[0] and v[3] for v in rows) else "sweep"       # all-reduce MAX, by hand
+    if SWEEP_AUTO_STATE["choice"] is not None:
+        import logging
+        logging.getLogger("base").info("dense-block form: %s (this rank: sweep %s us, per-layer %s us%s)", SWEEP_AUTO_STATE["choice"],
+                                       SWEEP_AUTO_STATE["sweep_us"], SWEEP_AUTO_STATE["layers_us"],
+                                       "; ranks: %s" % SWEEP_AUTO_STATE["per_rank"] if "per_rank" in SWEEP_AUTO_STATE else "")
+    return SWEEP_AUTO_STATE
 
 
 def conv_chain(stages):
@@ -485,9 +542,7 @@ def conv_chain(stages):
     crowded = COLLECTIVES_IN_FLIGHT and not CHAIN_WITH_COLLECTIVES
     sweep_ok = CONV_SWEEP and n == 5 and ((MMA == hip.MMA_BF16X3 and CHAIN_X3) or (MMA == hip.MMA_BF16 and AMP_SWEEP))
     auto = SWEEP_AUTO and CONV_CHAIN and eligible and sweep_ok and MMA == hip.MMA_BF16X3 and stages[0]["x"].buf.is_cuda
-    if auto and SWEEP_AUTO_STATE["choice"] is None and not crowded and stages[0]["x"].pixels >= 131072:
-        _calibrate_dense_block(stages)               # (once per process, on the first full-size block; leaves the block computed)
-    if auto and SWEEP_AUTO_STATE["choice"] == "layers":
+    if auto and SWEEP_AUTO_STATE["choice"] == "layers":      # (calibrate_dense_block_form chose it at model set-up: never timed here)
         for st in stages:
             conv(**{k: v for k, v in st.items() if k != "fresh_from"})
         return
