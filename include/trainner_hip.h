@@ -129,6 +129,11 @@ typedef struct tnr_conv_desc {
      * of splitting and staging the slab through LDS per workgroup and chunk.  NULL: the launch stages `wp` itself.  Same results
      * bit for bit either way.                                                                                                    */
     const void *wq; int64_t wq_bytes;
+    /* which stream `wq` is: 0 = the tap-major one above (tnr_conv_wq_pack), 1 = the Winograd F(2x2, 3x3) transform-domain stream
+     * (tnr_conv_wino_pack): the launch then runs as 16 transform-domain GEMMs per 2 x 2 output patch -- 2.25 x fewer matrix-core
+     * instructions for the same convolution; the transforms cost a few extra fp32 roundings per element (error vs fp64 held to 3 x
+     * the fp32 matrix core's in the tests, against 1.5 x for the direct forms) and the results are NOT bit-identical to them.      */
+    int32_t wq_form;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -184,8 +189,8 @@ const char *tnr_last_error(void);
  * layout: a caller built against another header would pass a shorter struct and the library would read fields from adjacent memory.
  * Consumers compare it with THEIR header's TNR_ABI_VERSION before the first call (trainner_amd/hip.py does).
  *   1: rounds 1-4.   2: tnr_wgrad_desc gained dw2 / cout_split / cin_total2 / db2, TNR_WGRAD_GROUP_MAX 8 -> 12 (round 5; the number
- *      itself was bumped in round 6).                                                                                   */
-#define TNR_ABI_VERSION 2
+ *      itself was bumped in round 6).   3: tnr_conv_desc gained wq_form (round 6).                                      */
+#define TNR_ABI_VERSION 3
 int tnr_version(void);
 
 /* --- convolution family ---------------------------------------------------------------------- */
@@ -205,6 +210,11 @@ int64_t tnr_conv_workspace_bytes(const tnr_conv_desc *d);   /* 0 when the launch
 /* size of / build the pre-split weight stream of a launch (tnr_conv_desc.wq); 0: the launch cannot use one */
 int64_t tnr_conv_wq_bytes(const tnr_conv_desc *d);
 int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t image_bytes, void *stream);
+/* the same for the Winograd F(2x2, 3x3) form (tnr_conv_desc.wq with wq_form = 1): U = G g G^T of every (cout, cin) filter, computed in
+ * fp64 from the packed fp32 weights, rounded once to fp32 and split into three bf16 planes in MFMA operand order.  64-cout blocks,
+ * Cin % 16 == 0, TNR_MMA_BF16X3, stride 1, zero or reflection padding (nn.Conv2d k3 s1 p1, block.py:214-256; ResNet_arch.py:118-146). */
+int64_t tnr_conv_wino_bytes(const tnr_conv_desc *d);
+int tnr_conv_wino_pack(const tnr_conv_desc *d, void *image, int64_t image_bytes, void *stream);
 /* out[(n*Ho + oy)*Wo + ox][(ky*kw + kx)*C + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c] (0 outside):
  * the patch matrix of a k x k convolution as an NHWC "image" of Ho*Wo*N pixels with kh*kw*C channels, for
  * TNR_CONV_1x1 with TNR_PACK_COL_* weights.  C % 4 == 0.                                                */

@@ -92,8 +92,8 @@ def _mm(t):
 
 
 def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, alpha=1.0, r1=None, r1_ch=None,
-         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False, noise=None):
-    xin = _mm(_nchw(x))
+         beta1=1.0, r2=None, alpha2=1.0, mask=None, m_lo=0, m_hi=None, m_slope=0.2, reflect=False, noise=None, wino=None):
+    xin = _mm(_nchw(x))      # (wino: a kernel-form choice of the real library; the contract's arithmetic is the same convolution)
     w = None if wp.kind == ops.PACK_DENSE_DGRAD else _mm(wp.w.detach())
     if wp.kind == ops.PACK_DENSE_DGRAD:
         out = _dense_dgrad(xin, wp, y.C)

@@ -23,7 +23,7 @@ def test_library_exports_match_header():
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.tnr_version() == hip.ABI_VERSION == 2          # (header TNR_ABI_VERSION; a mismatch raises in hip.load)
+    assert lib.tnr_version() == hip.ABI_VERSION == 3          # (header TNR_ABI_VERSION; a mismatch raises in hip.load)
 
 
 def test_no_device_fails_loudly():

@@ -11,12 +11,21 @@ from trainner_amd import build as B  # noqa: E402
 
 
 def main(name, *defs):
+    # --only a.hip,b.hip : recompile just these sources with the flags and link them with the SHIPPED build's other objects
+    only = None
+    defs = list(defs)
+    if "--only" in defs:
+        k = defs.index("--only")
+        only = defs[k + 1].split(",")
+        del defs[k:k + 2]
     out_dir = os.path.join(B.LIBDIR, "variants")
     obj_dir = os.path.join(out_dir, "obj_" + name)
     os.makedirs(obj_dir, exist_ok=True)
     cc = B._hipcc()
 
     def one(src):
+        if only is not None and src not in only:
+            return os.path.join(B.LIBDIR, "obj", src.replace(".hip", ".o"))
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         r = subprocess.run([cc, *B.FLAGS, *defs, "-c", os.path.join(B.CSRC, src), "-o", obj], capture_output=True, text=True)
         if r.returncode:

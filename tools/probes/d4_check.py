@@ -28,14 +28,15 @@ def layer(N, H, W, Cin, Cout, seed, epi="plain", dgrad=False):
           "reflect": dict(bias=b, act=ops.ACT_RELU, reflect=True)}[epi]
 
     def run(d4):
+        """d4: True / False = the direct weight-stream kernel / the staged-weights kernels; "wino" = the Winograd form (csrc/conv_wino.hip)."""
         y = torch.full((N, H, W, Cout + 96), 3.0, device=dev)
-        ops.X3_D4 = d4
-        ops.conv(ops.View(x, 16, Cin), p.get(i), ops.View(y, 64, Cout), **kw)
+        ops.X3_D4 = d4 is not False
+        ops.conv(ops.View(x, 16, Cin), p.get(i), ops.View(y, 64, Cout), wino=(d4 == "wino"), **kw)
         ops.X3_D4 = True
         torch.cuda.synchronize()
         return y
 
-    return run, p, lambda d4: (setattr(ops, "X3_D4", d4), ops.conv(ops.View(x, 16, Cin), p.get(i), ops.View(torch.empty((N, H, W, Cout), device=dev)), **kw))
+    return run, p, lambda d4: (setattr(ops, "X3_D4", d4), ops.conv(ops.View(x, 16, Cin), p.get(i), ops.View(torch.empty((N, H, W, Cout), device=dev)), wino=False, **kw))
 
 
 def main():

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtrainner_hip.so")
-SOURCES = ["conv_tile.hip", "conv_chain.hip", "conv_sweep.hip", "conv_thin.hip", "wgrad_tile.hip", "wgrad_thin.hip", "pack_api.hip", "elementwise.hip", "norm_loss_optim.hip", "metrics.hip", "feed.hip", "degrade.hip", "dp_api.hip", "gconv.hip"]
+SOURCES = ["conv_tile.hip", "conv_chain.hip", "conv_sweep.hip", "conv_wino.hip", "conv_thin.hip", "wgrad_tile.hip", "wgrad_thin.hip", "pack_api.hip", "elementwise.hip", "norm_loss_optim.hip", "metrics.hip", "feed.hip", "degrade.hip", "dp_api.hip", "gconv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

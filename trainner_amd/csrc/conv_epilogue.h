@@ -7,10 +7,12 @@ namespace {
 
 // Epilogue of a tile (the quad-transpose epilogue of conv_body.h as a function: same arithmetic, same order): `acc` holds the MFMA
 // results of wave `wave` (M-tile mi = pixels (wave * MT + mi) * 32 .. + 31 of the TW-wide tile at (ty0, tx0), channel block cb).
-template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true>
-__device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
-                                                  const int tx0, const int par, const int wave, const int li, const int half,
-                                                  const __amdgpu_buffer_rsrc_t y_rs) {
+// PixFn: (mi, row 0 .. 31 of that M-tile) -> (tile row, tile column) of the pixel that accumulator row holds.  The default is the row-major
+// walk of a TW-wide tile; the Winograd kernel (conv_wino.hip) maps rows to the pixels of its 2 x 2 output patches instead.
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true, class PixFn>
+__device__ __forceinline__ void conv_epilogue_dpp_map(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
+                                                      const int tx0, const int par, const int li, const int half,
+                                                      const __amdgpu_buffer_rsrc_t y_rs, PixFn &&pixfn) {
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
     constexpr int NC = NT * 32;
     const int py = par >> 1, px = par & 1;
@@ -90,8 +92,8 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
     f32x4 q1[SETS][NT], q2[SETS][NT], qm[SETS][NT];
     auto prep = [&](int u, int set) {
         const int mi = u >> 2, q = u & 3;
-        const int p = (wave * MT + mi) * 32 + 8 * q + 4 * half + qb;
-        const int rr = p / TW, cc = p - rr * TW;
+        int rr, cc;
+        pixfn(mi, 8 * q + 4 * half + qb, rr, cc);
         const int sy = ty0 + rr, sx = tx0 + cc;
         ok[set] = sy < a.th_space && sx < a.tw_space;
         const int oy = DG2 ? 2 * sy + py : sy;
@@ -167,6 +169,18 @@ __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[M
         if (u + AHEAD < UNITS) prep(u + AHEAD, (u + AHEAD) % SETS);
         finish(u, u % SETS);
     }
+}
+
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true>
+__device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
+                                                  const int tx0, const int par, const int wave, const int li, const int half,
+                                                  const __amdgpu_buffer_rsrc_t y_rs) {
+    conv_epilogue_dpp_map<MODE, TW, NT, MT, COH, DEPTH, NOISE>(a, acc, cb, n, ty0, tx0, par, li, half, y_rs,
+                                                                [&](int mi, int row, int &rr, int &cc) __attribute__((always_inline)) {
+                                                                    const int p = (wave * MT + mi) * 32 + row;
+                                                                    rr = p / TW;
+                                                                    cc = p - rr * TW;
+                                                                });
 }
 
 }  // namespace

@@ -153,6 +153,7 @@ int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
 }  // namespace
 
 int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream);      // conv_sweep.hip (1: not for that kernel)
+int tnr_launch_conv3x3_wino(const tnr_conv_desc *d, void *stream);    // conv_wino.hip (1: not for that kernel)
 
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
@@ -240,6 +241,12 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
         tiles *= ksplit;
     }
     int rc;
+    if (d->wq != nullptr && d->wq_form == 1) {     // transform-domain weight stream: the Winograd F(2x2, 3x3) kernel (conv_wino.hip) or nothing
+        TNR_REQUIRE(k.ksplit == 1, "conv: a Winograd weight stream cannot be combined with a split-K workspace");
+        rc = tnr_launch_conv3x3_wino(d, (void *)s);
+        TNR_REQUIRE(rc != 1, "conv: wq_form = 1 but the launch does not qualify for the Winograd kernel (tnr_conv_wino_bytes() == 0)");
+        return rc;
+    }
     if (d->wq != nullptr && k.ksplit == 1) {       // pre-split weight stream: the direct four-wave kernel (conv_sweep.hip), when the launch qualifies
         static const bool d4 = [] { const char *e = std::getenv("TNR_X3_D4"); return e == nullptr || e[0] != '0'; }();
         if (d4) {

@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("m", CView), ("m_lo", c_i), ("m_hi", c_i), ("m_slope", c_f),
         ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i), ("pad_mode", c_i),
         ("noise_sigma", c_f), ("noise_pos", c_i), ("noise_key0", C.c_uint32), ("noise_key1", C.c_uint32), ("noise_pix0", C.c_uint32),
-        ("wq", c_p), ("wq_bytes", c_l),
+        ("wq", c_p), ("wq_bytes", c_l), ("wq_form", c_i),
     ]
 
 
@@ -76,6 +76,8 @@ _SIGS = {
     "tnr_conv_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
     "tnr_conv_wq_bytes": (c_l, [C.POINTER(ConvDesc)]),
     "tnr_conv_wq_pack": (c_i, [C.POINTER(ConvDesc), c_p, c_l, c_p]),
+    "tnr_conv_wino_bytes": (c_l, [C.POINTER(ConvDesc)]),
+    "tnr_conv_wino_pack": (c_i, [C.POINTER(ConvDesc), c_p, c_l, c_p]),
     "tnr_gauss_mult": (c_i, [CView, CView, c_l, c_i, c_f, C.c_uint32, C.c_uint32, C.c_uint32, c_p]),
     "tnr_im2col": (c_i, [CView, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "tnr_conv_chain_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
@@ -170,7 +172,7 @@ def library_path():
     return os.environ.get("TNR_HIP_LIB") or _build.LIB
 
 
-ABI_VERSION = 2          # include/trainner_hip.h TNR_ABI_VERSION: the descriptor layouts below are those of this version
+ABI_VERSION = 3          # include/trainner_hip.h TNR_ABI_VERSION: the descriptor layouts below are those of this version
 
 
 def load(build_if_missing=False):

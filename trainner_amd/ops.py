@@ -341,7 +341,42 @@ def _wq_image(lib, d, wp, dev):
     return ent[0]
 
 
-def conv(x, wp, y, mode=CONV_3x3, **epi):
+# TNR_MMA=bf16x3: 64-cout 3x3 layers in the Winograd F(2x2, 3x3) form (csrc/conv_wino.hip): 2.25 x fewer matrix-core instructions for the
+# same convolution, a few more fp32 roundings per element (error vs fp64 <= 3 x the fp32 matrix core's in the tests; NOT bit-identical
+# to the direct kernels).  Where: layers with >= 128 input channels -- the transform + operand split of an input chunk is vector-ALU work
+# per PIXEL that only 64 output channels per workgroup amortise (registers: 16 transform positions x 2 x 2 accumulator tiles), so the
+# kernel is bound by it, not by the matrix core: x 1.17 (128 ch) / 1.26 (256) / 1.27-1.35 (512) over the direct weight-stream kernel,
+# x 0.99-1.07 on the 64-channel layers, which stay direct (profiles/r09m_wino_check.txt; analysis DESIGN.md 3.9).  TNR_WINO=0: off.
+WINO = os.environ.get("TNR_WINO", "1") != "0"
+WINO_MIN_CIN = int(os.environ.get("TNR_WINO_MIN_CIN", "128"))
+WINO_MIN_PIXELS = int(os.environ.get("TNR_WINO_MIN_PIXELS", "4096"))
+
+
+def _wino_image(lib, d, wp, dev):
+    """The transform-domain weight stream of a launch (tnr_conv_desc.wq with wq_form = 1; None: the launch cannot run in the Winograd
+    form).  Cached and refreshed like _wq_image: per owning packer and its generation, or per (weights, stream) for one-off packs."""
+    need = lib.tnr_conv_wino_bytes(C.byref(d))
+    if need <= 0:
+        return None
+    owner = wp.owner
+    cache, gen = (_wq_oneoff, None) if owner is None else (owner.__dict__.setdefault("_wq_images", {}), owner.gen)
+    key = ("wino", wp.t.data_ptr()) if owner is not None else ("wino", wp.t.data_ptr(), hip.stream())
+    ent = cache.get(key)
+    if owner is None and ent is not None:
+        cache[key] = cache.pop(key)
+    if ent is None or ent[0].numel() * 4 < need:
+        ent = cache[key] = [torch.empty(need // 4, dtype=torch.float32, device=dev), None]
+        if owner is None:
+            while len(cache) > 64:
+                cache.pop(next(iter(cache)))
+    if gen is None or ent[1] != gen:
+        hip.check(lib.tnr_conv_wino_pack(C.byref(d), ent[0].data_ptr(), need, hip.stream()), "conv_wino_pack")
+        ent[1] = gen
+    return ent[0]
+
+
+def conv(x, wp, y, mode=CONV_3x3, wino=None, **epi):
+    """wino: None = the process policy (WINO and the layer's size), True / False = force / forbid the Winograd form for this launch."""
     d = ConvDesc()
     _conv_desc(d, x, wp, y, mode, **epi)
     if y.pixels <= 16384 and wp.KinP >= 512:      # candidates for split-K (tnr_conv_workspace_bytes decides)
@@ -349,7 +384,14 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
         if need > 0:
             ws = WS.get("splitk@%x" % hip.stream(), need, x.buf.device)
             d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
-    if X3_D4 and mode == CONV_3x3 and d.mma in (hip.MMA_BF16X3, hip.MMA_BF16) and not d.ws and y.C % 64 == 0:
+    use_wino = (WINO and x.C >= WINO_MIN_CIN and y.pixels >= WINO_MIN_PIXELS) if wino is None else wino
+    if use_wino and mode == CONV_3x3 and d.mma == hip.MMA_BF16X3 and not d.ws and y.C % 64 == 0:
+        img = _wino_image(hip.load(), d, wp, x.buf.device)
+        if img is not None:
+            d.wq, d.wq_bytes, d.wq_form = img.data_ptr(), img.numel() * 4, 1
+        else:
+            assert wino is not True, "this launch cannot run in the Winograd form"
+    if not d.wq and X3_D4 and mode == CONV_3x3 and d.mma in (hip.MMA_BF16X3, hip.MMA_BF16) and not d.ws and y.C % 64 == 0:
         img = _wq_image(hip.load(), d, wp, x.buf.device)
         if img is not None:
             d.wq, d.wq_bytes = img.data_ptr(), img.numel() * 4
@@ -362,6 +404,8 @@ def conv(x, wp, y, mode=CONV_3x3, **epi):
     opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
            DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1", CONV_3x3_C4: "conv_tile_3x3_c4"}[mode]
+    if d.wq_form == 1:
+        fam = "conv_wino_3x3"          # (algorithmic FLOP of the convolution it computes: 9 taps)
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
 
 
