@@ -134,6 +134,13 @@ typedef struct tnr_conv_desc {
      * instructions for the same convolution; the transforms cost a few extra fp32 roundings per element (error vs fp64 held to 3 x
      * the fp32 matrix core's in the tests, against 1.5 x for the direct forms) and the results are NOT bit-identical to them.      */
     int32_t wq_form;
+    /* nn.PixelShuffle(2) behind the convolution (block.pixelshuffle_block, block.py:374-387: conv nf -> 4 nf, shuffle, act) folded into
+     * the STORE: 0 = off; 2 = y is the SHUFFLED tensor [N, 2 Ho, 2 Wo, Cout / 4] and conv output channel 4 c + 2 dy + dx of pixel (oy, ox)
+     * is written to channel c of pixel (2 oy + dy, 2 ox + dx) -- the [N, Ho, Wo, Cout] intermediate and the depth-to-space pass never
+     * exist.  The epilogue (bias, act, alpha) is applied as usual (an elementwise activation commutes with the shuffle); residuals, mask
+     * and noise are not supported.  Needs the pre-split weight stream (wq, wq_form = 0, built with this field set: the stream's cout
+     * order follows the sub-pixel) and Cout % 256 == 0; anything else is refused -- the caller then runs tnr_depth_to_space itself.  */
+    int32_t shuffle;
 } tnr_conv_desc;
 
 /* Weight-gradient of one convolution: dW[co][ci][ky][kx] = beta*dW + alpha * sum_pixels g * x
@@ -189,7 +196,7 @@ const char *tnr_last_error(void);
  * layout: a caller built against another header would pass a shorter struct and the library would read fields from adjacent memory.
  * Consumers compare it with THEIR header's TNR_ABI_VERSION before the first call (trainner_amd/hip.py does).
  *   1: rounds 1-4.   2: tnr_wgrad_desc gained dw2 / cout_split / cin_total2 / db2, TNR_WGRAD_GROUP_MAX 8 -> 12 (round 5; the number
- *      itself was bumped in round 6).   3: tnr_conv_desc gained wq_form (round 6).                                      */
+ *      itself was bumped in round 6).   3: tnr_conv_desc gained wq_form and shuffle (round 6).                                      */
 #define TNR_ABI_VERSION 3
 int tnr_version(void);
 

@@ -478,9 +478,47 @@ def test_conv3x3_winograd_form_agrees_with_direct_kernel(case):
     assert float((half - run(True)).abs().max()) <= 3e-6 * sc and not torch.equal(half, got)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64), (1, 40, 72, 64), (2, 24, 40, 128), (3, 9, 33, 64)])
+@pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
+def test_pixel_shuffle_folded_into_the_conv_store(shape, act, monkeypatch):
+    """block.pixelshuffle_block (block.py:374-387: conv nf -> 4 nf, nn.PixelShuffle(2), act) as ONE launch (tnr_conv_desc.shuffle: the
+    weight stream ordered by sub-pixel, every 64-cout block stored as 256-byte rows of the shuffled tensor) against the two-pass form
+    -- the same convolution kernel followed by tnr_depth_to_space -- bit for bit; ragged tiles, nf 64 and 128, the three epilogue
+    activations, also with bf16 operands (`use_amp`).  The fp32-matrix-core arithmetic has no such kernel: ops.conv_shuffle2 says so."""
+    ops = _ops()
+    from trainner_amd import hip
+    N, H, W, nf = shape
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5 + H)
+    w = ((torch.rand(4 * nf, nf, 3, 3, generator=g) - 0.5) * 0.2).to(dev)
+    b = (torch.rand(4 * nf, generator=g) - 0.5).to(dev)
+    x = (torch.rand(N, H, W, nf, generator=g) * 2 - 1).to(dev)
+    p = ops.WeightPacker(dev)
+    i = p.add(w, ops.PACK_FWD)
+    p.run()
+    kw = dict(bias=b, **{"relu": dict(act=ops.ACT_RELU), "lrelu": dict(act=ops.ACT_LRELU, slope=0.2), "none": {}}[act])
+    modes = [ops.MMA] + ([hip.MMA_BF16] if ops.MMA == hip.MMA_BF16X3 else [])
+    for mma in modes:
+        monkeypatch.setattr(ops, "MMA", mma)
+        t = torch.zeros(N, H, W, 4 * nf, device=dev)
+        ref = torch.zeros(N, 2 * H, 2 * W, nf, device=dev)
+        ops.conv(ops.View(x), p.get(i), ops.View(t), wino=False, **kw)
+        ops.depth_to_space(ops.View(t), ops.View(ref))
+        want = torch.nn.functional.pixel_shuffle(t.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert torch.equal(ref, want)                                  # (tnr_depth_to_space is nn.PixelShuffle(2))
+        got = torch.full((N, 2 * H, 2 * W, nf + 8), 7.0, device=dev)   # a channel window of a wider buffer
+        done = ops.conv_shuffle2(ops.View(x), p.get(i), ops.View(got, 4, nf), **kw)
+        if mma == hip.MMA_F32:
+            assert done is False
+            continue
+        assert done is True
+        assert torch.equal(got[..., 4:4 + nf], ref), float((got[..., 4:4 + nf] - ref).abs().max())
+        assert float(got[..., :4].min()) == 7.0 and float(got[..., 4 + nf:].min()) == 7.0
+
+
 def test_winograd_policy(monkeypatch):
-    """ops.conv picks the Winograd form by itself only where it wins (>= 128 input channels, enough pixels: ops.WINO*), never for the
-    64-channel layers, never in the fp32-matrix-core arithmetic or under `use_amp`, and TNR_WINO=0 turns it off."""
+    """ops.conv picks the Winograd form by itself only where it wins (>= ops.WINO_MIN_CIN input channels, enough pixels), never in the
+    fp32-matrix-core arithmetic or under `use_amp`, never for the per-layer form of a dense block, and TNR_WINO=0 turns it off."""
     ops = _ops()
     from trainner_amd import hip
     if ops.MMA != hip.MMA_BF16X3:
@@ -500,6 +538,7 @@ def test_winograd_policy(monkeypatch):
         return list(prof.summary())[0]
 
     monkeypatch.setattr(ops, "WINO", True)
+    monkeypatch.setattr(ops, "WINO_MIN_CIN", 128)
     assert probe(128, 64) == "conv_wino_3x3" and probe(64, 64) == "conv_tile_3x3" and probe(256, 32) == "conv_tile_3x3"
     assert probe(64, 64, wino=True) == "conv_wino_3x3" and probe(128, 64, wino=False) == "conv_tile_3x3"
     monkeypatch.setattr(ops, "WINO", False)

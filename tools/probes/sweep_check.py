@@ -53,7 +53,7 @@ def block(N, H, W, seed, grad_shape, with_r2=True, noise=None):
         st = make(buf, out)
         if how == "layers":
             for d in st:
-                ops.conv(**{k: v for k, v in d.items() if k != "fresh_from"})
+                ops.conv(wino=False, **{k: v for k, v in d.items() if k != "fresh_from"})      # (the direct kernels: what the sweep is bit-identical to)
         else:
             ops.CONV_SWEEP = how == "sweep"
             ops.conv_chain(st)

@@ -78,6 +78,16 @@ __device__ __forceinline__ void tnr_split4_bf16x3_pk(const f32x4 v, tnr_f32x2 (&
     out[1] = tnr_f32x2{__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1)};
     out[2] = tnr_f32x2{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1)};
 }
+// one level of that split for four channels: the packed bf16 pair-of-pairs `pk` (channel order 0 1 2 3) and the residual x - float(pk)
+__device__ __forceinline__ void tnr_pk_level(const f32x4 x, tnr_bf16x4 &pk, f32x4 &res) {
+    const tnr_f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
+    const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, tnr_bf16x2));
+    const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, tnr_bf16x2));
+    pk = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1)});
+    const f32x4 back = {__builtin_bit_cast(float, p0 << 16), __builtin_bit_cast(float, p0 & 0xffff0000u),
+                        __builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    res = x - back;
+}
 #ifndef TNR_X3_REFILL
 #define TNR_X3_REFILL 1     /* TNR_MMA_BF16X3: 1 = the input tile is split when it is written to LDS, 0 = at every fragment read */
 #endif

@@ -9,7 +9,9 @@ namespace {
 // results of wave `wave` (M-tile mi = pixels (wave * MT + mi) * 32 .. + 31 of the TW-wide tile at (ty0, tx0), channel block cb).
 // PixFn: (mi, row 0 .. 31 of that M-tile) -> (tile row, tile column) of the pixel that accumulator row holds.  The default is the row-major
 // walk of a TW-wide tile; the Winograd kernel (conv_wino.hip) maps rows to the pixels of its 2 x 2 output patches instead.
-template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true, class PixFn>
+// BIAS_STEP: distance between the bias entries of consecutive stored channels (4 when the store folds a pixel shuffle: stored channel c
+// of sub-pixel s is conv channel 4 c + s; `a.bias` then points at entry s).
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true, int BIAS_STEP = 1, class PixFn>
 __device__ __forceinline__ void conv_epilogue_dpp_map(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
                                                       const int tx0, const int par, const int li, const int half,
                                                       const __amdgpu_buffer_rsrc_t y_rs, PixFn &&pixfn) {
@@ -51,7 +53,11 @@ __device__ __forceinline__ void conv_epilogue_dpp_map(const ConvK a, f32x16 (&ac
     TNR_STAMP(7);
     // Everything below is written branch-light (uniform switches hoisted, lane conditions as selects): a per-element
     // activation switch and per-unit residual / mask / partial-store branches once cost ~1000 cycles per float4 unit.
+#ifdef TNR_ABL_NOMASK          /* (ablation build, results invalid: the upper bound of what a 1-bit activation mask could save -- no mask tensor read at all) */
+    const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = false;
+#else
     const bool has_r1 = a.r1 != nullptr, has_r2 = a.r2 != nullptr, has_m = a.m != nullptr;     // wave-uniform
+#endif
     const bool has_noise = NOISE && a.noise_pos != 0;     // wave-uniform (NOISE = false: an instance for stages that never carry the ESRGAN+ noise)
     const bool all_full = (a.Cout & 3) == 0;                                                  // wave-uniform
     const float ns = a.act == TNR_ACT_LRELU ? a.slope : (a.act == TNR_ACT_RELU ? 0.f : 1.f);  // act(v) = max(v,0) + ns*min(v,0)
@@ -67,7 +73,11 @@ __device__ __forceinline__ void conv_epilogue_dpp_map(const ConvK a, f32x16 (&ac
         co_ok[nn] = co < a.Cout;
         bv[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias != nullptr && co_ok[nn]) {
-            if (co + 4 <= a.Cout) {
+            if constexpr (BIAS_STEP != 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (co + k < a.Cout) bv[nn][k] = a.bias[(co + k) * BIAS_STEP];
+            } else if (co + 4 <= a.Cout) {
                 bv[nn] = *reinterpret_cast<const f32x4 *>(a.bias + co);
             } else {
 #pragma unroll
@@ -171,11 +181,11 @@ __device__ __forceinline__ void conv_epilogue_dpp_map(const ConvK a, f32x16 (&ac
     }
 }
 
-template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true>
+template <int MODE, int TW, int NT, int MT, bool COH, int DEPTH = 1, bool NOISE = true, int BIAS_STEP = 1>
 __device__ __forceinline__ void conv_epilogue_dpp(const ConvK a, f32x16 (&acc)[MT][NT], const int cb, const int n, const int ty0,
                                                   const int tx0, const int par, const int wave, const int li, const int half,
                                                   const __amdgpu_buffer_rsrc_t y_rs) {
-    conv_epilogue_dpp_map<MODE, TW, NT, MT, COH, DEPTH, NOISE>(a, acc, cb, n, ty0, tx0, par, li, half, y_rs,
+    conv_epilogue_dpp_map<MODE, TW, NT, MT, COH, DEPTH, NOISE, BIAS_STEP>(a, acc, cb, n, ty0, tx0, par, li, half, y_rs,
                                                                 [&](int mi, int row, int &rr, int &cc) __attribute__((always_inline)) {
                                                                     const int p = (wave * MT + mi) * 32 + row;
                                                                     rr = p / TW;

@@ -711,6 +711,27 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         f32x4 ir;
         auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {
             constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
+#ifdef S4_ABL_NOSPLIT       /* (ablation build, results invalid: the upper bound of what PRE-SPLIT block buffers could save -- no operand split in the stager, the three LDS stores stay) */
+            if constexpr (k >= 2) {
+                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
+                *reinterpret_cast<tnr_f32x2 *>(dst) = tnr_f32x2{rin[it][k - 2], rin[it][3]};
+            }
+#elif defined(S4_PK_SPLIT)  /* the same split with ONE packed conversion per channel pair and level (tnr_split4_bf16x3_pk's form, conv_body.h): 22 instead of 30 vector instructions per item, bit-identical */
+            if constexpr (k == 0) {
+                tnr_pk_level(rin[it], ih, ir);
+            } else if constexpr (k == 1) {
+                const f32x4 r1 = ir;
+                tnr_pk_level(r1, im, ir);
+            } else {
+                if constexpr (k == 2) {
+                    const tnr_f32x2 a = {ir[0], ir[1]}, b = {ir[2], ir[3]};
+                    il = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a, tnr_bf16x2)),
+                                                                __builtin_bit_cast(float, __builtin_convertvector(b, tnr_bf16x2))});
+                }
+                float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
+                *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
+            }
+#else
             if constexpr (k == 0) {
                 ih = __builtin_convertvector(rin[it], tnr_bf16x4);
                 ir = rin[it] - __builtin_convertvector(ih, f32x4);
@@ -722,6 +743,7 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                 float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
                 *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
             }
+#endif
         };
         auto a_store_item = [&](auto ic, int buf) __attribute__((always_inline)) {
             sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, buf); });
@@ -998,6 +1020,7 @@ struct D4K {
 struct D4PackK {
     const float *wp;
     int KinP, KoutP, nck, ncb, units;
+    int shuffle;                       // 2: the stream's cout r' = sub * (Cout / 4) + c holds conv channel 4 c + sub (tnr_conv_desc.shuffle)
     float *out;
 };
 
@@ -1008,7 +1031,12 @@ __global__ void __launch_bounds__(256) d4_pack_kernel(const D4PackK a) {
     const int per_cb = a.nck * 18;
     const int cb = unit / per_cb, rem = unit - cb * per_cb;
     const int ck = rem / 18, tj = rem - ck * 18, tap = tj >> 1, j = tj & 1;
-    const float *src = a.wp + ((size_t)tap * a.KoutP + cb * 64 + j * 32 + r) * a.KinP + 16 * ck + 8 * h;
+    int co = cb * 64 + j * 32 + r;
+    if (a.shuffle == 2) {
+        const int nfc = a.KoutP >> 2;
+        co = (co % nfc) * 4 + co / nfc;
+    }
+    const float *src = a.wp + ((size_t)tap * a.KoutP + co) * a.KinP + 16 * ck + 8 * h;
     const f32x4 q0 = *reinterpret_cast<const f32x4 *>(src), q1 = *reinterpret_cast<const f32x4 *>(src + 4);
     tnr_bf16x8 pl[3];
     tnr_split_bf16x3(q0, q1, pl);
@@ -1017,7 +1045,7 @@ __global__ void __launch_bounds__(256) d4_pack_kernel(const D4PackK a) {
     for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + k * 256) = pl[k];
 }
 
-template <int OCC, bool AMP = false>
+template <int OCC, bool AMP = false, bool PS = false>
 __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_a = smem;
@@ -1147,11 +1175,27 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
             t[m][1] = acc[m][1];
         }
         // (two workgroups per CU: the other one's MFMAs cover this epilogue's load latency -- one unit of look-ahead keeps it in 256 registers)
-        conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 2, false, (OCC == 1 ? 8 : 1)>(a, t, cb, n, ty0, tx0, 0, wave, li, half, y_rs);
+        if constexpr (PS) {
+            // nn.PixelShuffle(2) folded into the store (tnr_conv_desc.shuffle): the stream's 64-cout block cb holds the channels
+            // c of ONE sub-pixel (dy, dx) = cb / (blocks per sub-pixel): 256-byte rows of the shuffled tensor, written where they belong
+            ConvK ap = a;
+            const int nfb = c.ncb >> 2, sub = cb / nfb;
+            ap.Cout = a.Cout >> 2;
+            ap.Ho = 2 * a.Ho;
+            ap.Wo = 2 * a.Wo;
+            ap.bias = a.bias != nullptr ? a.bias + sub : nullptr;
+            conv_epilogue_dpp<TNR_DGRAD_4x4_S2, SW_TW, 2, 2, false, (OCC == 1 ? 8 : 1), false, 4>(ap, t, cb - sub * nfb, n, ty0, tx0, sub, wave, li, half, y_rs);
+        } else {
+            conv_epilogue_dpp<TNR_CONV_3x3, SW_TW, 2, 2, false, (OCC == 1 ? 8 : 1)>(a, t, cb, n, ty0, tx0, 0, wave, li, half, y_rs);
+        }
     }
 }
 
 bool d4_ok(const tnr_conv_desc *d) {
+    if (d->shuffle != 0 && !(d->shuffle == 2 && (d->Cout % 256) == 0 && d->r1.ptr == nullptr && d->r2.ptr == nullptr && d->m.ptr == nullptr &&
+                             d->noise_pos == 0 && d->pad_mode == 0 && (d->y.ctot % 4) == 0 &&
+                             (int64_t)d->N * d->H * d->W * 4 * d->y.ctot < (1LL << 30)))
+        return false;
     return d->mode == TNR_CONV_3x3 && (d->mma == TNR_MMA_BF16X3 || d->mma == TNR_MMA_BF16) && (d->pad_mode == 0 || (d->pad_mode == 1 && d->H >= 2 && d->W >= 2)) &&
            (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
            d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && d->Ho == d->H && d->Wo == d->W && d->W >= 32 && d->H >= 8 &&
@@ -1331,6 +1375,7 @@ extern "C" int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t ima
     D4PackK a;
     a.wp = d->wp; a.KinP = d->KinP; a.KoutP = d->KoutP; a.nck = d->Cin / 16; a.ncb = d->Cout / 64;
     a.units = a.ncb * a.nck * 18;
+    a.shuffle = d->shuffle;
     TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_wq_pack: image buffer too small");
     a.out = static_cast<float *>(image);
     hipLaunchKernelGGL(d4_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
@@ -1347,7 +1392,9 @@ int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_d4_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
             cus = 0;
             tnr_set_error("conv3x3_d4: cannot set up the kernel");
             return TNR_ELAUNCH;
@@ -1378,6 +1425,13 @@ int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream) {
     k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = c.ncb;
     const int slots = cus * (occ == 1 ? 1 : 2);
     const int grid = c.tiles < slots ? c.tiles : slots;
+    if (d->shuffle == 2) {
+        // the buffer the store addresses is the shuffled one: [N, 2 Ho, 2 Wo, Cout / 4] (same element count)
+        const unsigned g2 = (unsigned)(c.tiles < 2 * cus ? c.tiles : 2 * cus);
+        if (d->mma == TNR_MMA_BF16) hipLaunchKernelGGL((conv3x3_d4_kernel<2, true, true>), dim3(g2), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+        else hipLaunchKernelGGL((conv3x3_d4_kernel<2, false, true>), dim3(g2), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+        return tnr_check_launch("conv3x3_d4 (pixel-shuffle store)");
+    }
     if (d->mma == TNR_MMA_BF16) hipLaunchKernelGGL((conv3x3_d4_kernel<2, true>), dim3((unsigned)(c.tiles < 2 * cus ? c.tiles : 2 * cus)), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     else if (occ == 1) hipLaunchKernelGGL(conv3x3_d4_kernel<1>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
     else hipLaunchKernelGGL(conv3x3_d4_kernel<2>, dim3((unsigned)grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);

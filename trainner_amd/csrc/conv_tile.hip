@@ -249,11 +249,12 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     }
     if (d->wq != nullptr && k.ksplit == 1) {       // pre-split weight stream: the direct four-wave kernel (conv_sweep.hip), when the launch qualifies
         static const bool d4 = [] { const char *e = std::getenv("TNR_X3_D4"); return e == nullptr || e[0] != '0'; }();
-        if (d4) {
+        if (d4 || d->shuffle != 0) {
             rc = tnr_launch_conv3x3_d4(d, (void *)s);
             if (rc <= 0) return rc;
         }
     }
+    TNR_REQUIRE(d->shuffle == 0, "conv: a pixel-shuffle store (shuffle = %d) exists in the weight-stream kernel only (tnr_conv_wq_bytes() == 0 for this launch)", d->shuffle);
     {   // TNR_MMA_BF16X3, 64-cout 3x3 layers: the 8-wave kernel with both operands pre-split in LDS (conv_x3w8.h; TNR_X3_W8=0: off)
         static const bool w8 = [] { const char *e = std::getenv("TNR_X3_W8"); return e == nullptr || e[0] != '0'; }();
         if (w8 && d->mode == TNR_CONV_3x3 && nt == 2 && tw == 32 && sh >= 16 && conv3x3_x3w8_ok(k)) return launch_conv3x3_x3w8(k, s);

@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
                 for (int r = 0; r < 16; ++r) acc[j][m][r] = 0.f;
 
         // weight fragments of one multiply phase: the four units (j = 0 .. 3) of this wave's (nt, i) at one chunk -- units 0 and 1 requested at
-        // the top of the transform phase in front of it, units 2 and 3 at the top of the multiply phase itself (24 MFMAs = 768 cycles ahead of
-        // their first use; holding all four through the transform phase does not fit the registers)
+        // the end of the transform phase in front of it, units 2 and 3 at the top of the multiply phase itself (24 MFMAs = 768 cycles ahead of
+        // their first use)
         // (a unit feeds 12 MFMAs: both M-tiles; per CU and chunk 96 KB of weights
         // through the vector memory path, what the direct kernel moves -- the first version gave a wave one M-tile and four units more
         // and was bound by that path: 128 B / cycle / CU needed at the matrix core's rate)
@@ -344,14 +344,20 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
 #ifndef WN_X_NORAW
             if (ck >= 1 && ck + 1 < c.nck) raw_store((ck + 1) & 1);      // (at the END of the phase instead: 8 % slower, profiles/r09l_wino_raw_store_late.txt)
 #endif
-#ifndef WN_X_NOB
+#if !defined(WN_X_NOB) && defined(WN_B_EARLY)
             b_fetch(ck, std::integral_constant<int, 0>{});
-#else
+#elif defined(WN_X_NOB)
             if (ck == 0) { b_fetch(0, std::integral_constant<int, 0>{}); b_fetch(0, std::integral_constant<int, 2>{}); }
 #endif
             { WN_T(ts); WN_ADD(8, ts); }
 #ifndef WN_X_NOT
             transform(ck & 1);
+#endif
+#if !defined(WN_X_NOB) && !defined(WN_B_EARLY)
+            // units 0 and 1 go out at the END of the transform (units 2 and 3 at the top of the multiply phase): requested at its top they
+            // cost the transform 24 registers it schedules better without -- x 1.03-1.07 on every shape (profiles/r09o_wino_blate_ab.txt), and the
+            // multiply phase, which has slack next to the transform, opens on the L2 latency instead
+            b_fetch(ck, std::integral_constant<int, 0>{});
 #endif
             WN_T(t1);
             __syncthreads();

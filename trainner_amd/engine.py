@@ -62,6 +62,12 @@ class ConvOp:
             return
         ops.conv(x, self.packer.get(self.i_f), y, mode=self.mode_f, bias=self.mod.bias, **epi)
 
+    def fwd_shuffle2(self, x, y, **epi):
+        """This layer + nn.PixelShuffle(2) in one launch, y = the shuffled tensor (ops.conv_shuffle2); False: not available here."""
+        if self.mode_f != ops.CONV_3x3 or self.mod.out_channels != 4 * y.C:
+            return False
+        return ops.conv_shuffle2(x, self.packer.get(self.i_f), y, bias=self.mod.bias, **epi)
+
     def fwd_stage(self, x, y, fresh_from=None, **epi):
         """Stage descriptor of this layer's forward for ops.conv_chain."""
         return dict(x=x, wp=self.packer.get(self.i_f), y=y, mode=self.mode_f, bias=self.mod.bias, fresh_from=fresh_from, **epi)

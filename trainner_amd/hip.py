@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("m", CView), ("m_lo", c_i), ("m_hi", c_i), ("m_slope", c_f),
         ("ws", c_p), ("ws_bytes", c_l), ("mma", c_i), ("pad_mode", c_i),
         ("noise_sigma", c_f), ("noise_pos", c_i), ("noise_key0", C.c_uint32), ("noise_key1", C.c_uint32), ("noise_pix0", C.c_uint32),
-        ("wq", c_p), ("wq_bytes", c_l), ("wq_form", c_i),
+        ("wq", c_p), ("wq_bytes", c_l), ("wq_form", c_i), ("shuffle", c_i),
     ]
 
 

@@ -156,10 +156,12 @@ class RRDBNet(HipNet):
                 u.fwd(cur, nxt, act=act, slope=sl)
                 stages.append((cur, nxt, None))
             else:
-                t = View(new_act(N, cur.H, cur.W, 4 * nf, dev))
-                u.fwd(cur, t, act=act, slope=sl)                  # activation commutes with the shuffle
                 nxt = View(new_act(N, H2, W2, nf, dev))
-                ops.depth_to_space(t, nxt)
+                t = None
+                if not u.fwd_shuffle2(cur, nxt, act=act, slope=sl):      # the shuffle folded into the convolution's store where the kernel offers it
+                    t = View(new_act(N, cur.H, cur.W, 4 * nf, dev))
+                    u.fwd(cur, t, act=act, slope=sl)              # activation commutes with the shuffle
+                    ops.depth_to_space(t, nxt)
                 stages.append((cur, nxt, t))
             cur = nxt
         h0 = View(new_act(N, cur.H, cur.W, nf, dev))

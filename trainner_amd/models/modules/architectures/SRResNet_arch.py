@@ -78,10 +78,11 @@ class SRResNet(HipNet):
         o["lr"].fwd(t, y0, r1=fea)
         cur, stages = y0, []
         for u in o["up"]:
-            tt = View(new_act(N, cur.H, cur.W, 4 * nf, dev))
-            u.fwd(cur, tt, act=act, slope=sl)
             nxt = View(new_act(N, cur.H * 2, cur.W * 2, nf, dev))
-            ops.depth_to_space(tt, nxt)
+            if not u.fwd_shuffle2(cur, nxt, act=act, slope=sl):          # the shuffle folded into the convolution's store where the kernel offers it
+                tt = View(new_act(N, cur.H, cur.W, 4 * nf, dev))
+                u.fwd(cur, tt, act=act, slope=sl)
+                ops.depth_to_space(tt, nxt)
             stages.append((cur, nxt))
             cur = nxt
         h0 = View(new_act(N, cur.H, cur.W, nf, dev))

@@ -316,9 +316,10 @@ X3_D4 = os.environ.get("TNR_X3_D4", "1") != "0"      # TNR_MMA=bf16x3: 64-cout 3
 _wq_oneoff = {}
 
 
-def _wq_image(lib, d, wp, dev):
+def _wq_image(lib, d, wp, dev, tag=None):
     """The pre-split weight stream of a launch (tnr_conv_desc.wq; None: the launch cannot use one).  Kept on the packer that owns the
-    packed weights and rebuilt (one small launch) when that packer has run since -- once per optimiser step, once ever for the VGG."""
+    packed weights and rebuilt (one small launch) when that packer has run since -- once per optimiser step, once ever for the VGG.
+    tag: a second stream of the same weights in another order (the pixel-shuffle store's) is cached under its own key."""
     need = lib.tnr_conv_wq_bytes(C.byref(d))
     if need <= 0:
         return None
@@ -327,6 +328,8 @@ def _wq_image(lib, d, wp, dev):
     # one-off packs (no owning packer): an image per (packed weights, stream) -- it is re-packed on every call on the CURRENT stream,
     # so two streams must not share one -- and at most 64 of them (least recently used out: the addresses change as tensors come and go)
     key = wp.t.data_ptr() if owner is not None else (wp.t.data_ptr(), hip.stream())
+    if tag is not None:
+        key = (tag, key)
     ent = cache.get(key)
     if owner is None and ent is not None:
         cache[key] = cache.pop(key)          # most recently used last
@@ -343,12 +346,13 @@ def _wq_image(lib, d, wp, dev):
 
 # TNR_MMA=bf16x3: 64-cout 3x3 layers in the Winograd F(2x2, 3x3) form (csrc/conv_wino.hip): 2.25 x fewer matrix-core instructions for the
 # same convolution, a few more fp32 roundings per element (error vs fp64 <= 3 x the fp32 matrix core's in the tests; NOT bit-identical
-# to the direct kernels).  Where: layers with >= 128 input channels -- the transform + operand split of an input chunk is vector-ALU work
-# per PIXEL that only 64 output channels per workgroup amortise (registers: 16 transform positions x 2 x 2 accumulator tiles), so the
-# kernel is bound by it, not by the matrix core: x 1.17 (128 ch) / 1.26 (256) / 1.27-1.35 (512) over the direct weight-stream kernel,
-# x 0.99-1.07 on the 64-channel layers, which stay direct (profiles/r09m_wino_check.txt; analysis DESIGN.md 3.9).  TNR_WINO=0: off.
+# to the direct kernels).  The transform + operand split of an input chunk is vector-ALU work per PIXEL that only 64 output channels per
+# workgroup amortise (registers: 16 transform positions x 2 x 2 accumulator tiles), so the kernel is bound by it, not by the matrix
+# core: x 1.19 (128 ch) / 1.26 (256) / 1.23-1.31 (512) over the direct weight-stream kernel, x 1.04-1.11 on the 64-channel layers
+# (profiles/r09o_wino_blate_ab.txt; analysis DESIGN.md 3.9).  Dense blocks never use it (their per-layer fallback must stay
+# bit-identical to the one-launch forms).  TNR_WINO=0: off.
 WINO = os.environ.get("TNR_WINO", "1") != "0"
-WINO_MIN_CIN = int(os.environ.get("TNR_WINO_MIN_CIN", "128"))
+WINO_MIN_CIN = int(os.environ.get("TNR_WINO_MIN_CIN", "64"))
 WINO_MIN_PIXELS = int(os.environ.get("TNR_WINO_MIN_PIXELS", "4096"))
 
 
@@ -373,6 +377,33 @@ def _wino_image(lib, d, wp, dev):
         hip.check(lib.tnr_conv_wino_pack(C.byref(d), ent[0].data_ptr(), need, hip.stream()), "conv_wino_pack")
         ent[1] = gen
     return ent[0]
+
+
+SHUFFLE_FOLD = os.environ.get("TNR_SHUFFLE_FOLD", "1") != "0"      # nn.PixelShuffle(2) folded into the convolution's store (A/B switch)
+
+
+def conv_shuffle2(x, wp, y, **epi):
+    """conv (nf -> 4 nf, 3x3) + nn.PixelShuffle(2) + the epilogue's activation in ONE launch (block.pixelshuffle_block, block.py:374-387):
+    y is the SHUFFLED tensor [N, 2 H, 2 W, nf]; the [N, H, W, 4 nf] intermediate and the depth-to-space pass do not exist
+    (tnr_conv_desc.shuffle).  Returns False when the launch cannot run that way (fp32-matrix-core arithmetic, shapes the weight-stream
+    kernel does not take): the caller then runs conv + depth_to_space."""
+    if not (SHUFFLE_FOLD and X3_D4 and MMA in (hip.MMA_BF16X3, hip.MMA_BF16) and x.buf.is_cuda):
+        return False
+    assert y.H == 2 * x.H and y.W == 2 * x.W and wp.KoutP == 4 * y.C
+    lib = hip.load()
+    d = ConvDesc()
+    _conv_desc(d, x, wp, y, CONV_3x3, **epi)
+    d.Ho, d.Wo, d.Cout, d.shuffle = x.H, x.W, 4 * y.C, 2
+    d.m_hi = 0
+    img = _wq_image(lib, d, wp, x.buf.device, tag="shuffle2")
+    if img is None:
+        return False
+    d.wq, d.wq_bytes = img.data_ptr(), img.numel() * 4
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward (pixel-shuffle store)")
+    if PROFILE is not None:
+        PROFILE.end("conv_tile_3x3", 2.0 * x.pixels * 9 * x.C * 4 * y.C, t0, (x.C, 4 * y.C, x.H, wp.kind))
+    return True
 
 
 def conv(x, wp, y, mode=CONV_3x3, wino=None, **epi):
@@ -518,7 +549,7 @@ def _calibrate_dense_block(stages):
 
         def layers():
             for st in stages:
-                conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+                conv(wino=False, **{k: v for k, v in st.items() if k != "fresh_from"})      # (the direct kernels: bit-identical to the one-launch forms)
 
         SWEEP_AUTO_STATE["choice"] = "sweep"                # (the timed calls below go through conv_chain itself)
         t_sweep, t_layers = timed(lambda: conv_chain(stages)), timed(layers)
@@ -588,13 +619,13 @@ def conv_chain(stages):
     auto = SWEEP_AUTO and CONV_CHAIN and eligible and sweep_ok and MMA == hip.MMA_BF16X3 and stages[0]["x"].buf.is_cuda
     if auto and SWEEP_AUTO_STATE["choice"] == "layers":      # (calibrate_dense_block_form chose it at model set-up: never timed here)
         for st in stages:
-            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+            conv(wino=False, **{k: v for k, v in st.items() if k != "fresh_from"})      # (the direct kernels: bit-identical to the one-launch forms)
         return
     if not CONV_CHAIN or not eligible or (crowded and not (sweep_ok and SWEEP_DISPENSED)):
         if crowded and CONV_CHAIN and eligible:
             COUNTERS["per_layer_next_to_collectives"] += 1
         for st in stages:
-            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+            conv(wino=False, **{k: v for k, v in st.items() if k != "fresh_from"})      # (the direct kernels: bit-identical to the one-launch forms)
         return
     lib = hip.load()
     descs = (ConvDesc * n)()
@@ -627,7 +658,7 @@ def conv_chain(stages):
     if crowded and image is None:                      # (a 5-stage block the sweep does not cover: shapes, tiles per image)
         COUNTERS["per_layer_next_to_collectives"] += 1
         for st in stages:
-            conv(**{k: v for k, v in st.items() if k != "fresh_from"})
+            conv(wino=False, **{k: v for k, v in st.items() if k != "fresh_from"})      # (the direct kernels: bit-identical to the one-launch forms)
         return
     if COLLECTIVES_IN_FLIGHT:
         COUNTERS["one_launch_next_to_collectives"] += 1
