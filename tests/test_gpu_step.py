@@ -111,6 +111,27 @@ def test_step_matches_reference_golden(case, tmp_path):
         assert e < T["bn"], ("D running stats", k, e)
 
 
+@pytest.mark.parametrize("case", ["cfg1_srresnet", "esrgan_nb1_pixelshuffle"])
+def test_pixelshuffle_generators_run_without_a_depth_to_space_pass(case, tmp_path, monkeypatch, mma_mode):
+    """in the split arithmetic the pixel-shuffle upsamplers (SRResNet; RRDBNet with upsample_mode: pixelshuffle) store
+    the shuffled tensor straight from the convolution (tnr_conv_desc.shuffle) -- no tnr_depth_to_space launch in the forward -- and the
+    reference's goldens are met unchanged; the fp32-matrix-core arithmetic keeps the two-pass form."""
+    from trainner_amd import hip, ops
+    calls = []
+    real = ops.depth_to_space
+    monkeypatch.setattr(ops, "depth_to_space", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    test_step_matches_reference_golden(case, tmp_path)
+    fx = FX.load(case)
+    steps, lr_side = fx["spec"]["steps"], fx["spec"]["yaml"]["crop"] // 4
+    if ops.MMA == hip.MMA_BF16X3:
+        # (the weight-stream kernel's tile is 32 pixels wide: an upsampling stage on a narrower image keeps the two-pass form --
+        #  esrgan_nb1_pixelshuffle's first stage works on 16 x 16, its second on 32 x 32)
+        narrow = sum(1 for k in range(2) if lr_side * 2 ** k < 32)
+        assert len(calls) == narrow * steps, (len(calls), narrow, steps)
+    else:
+        assert len(calls) == 2 * steps
+
+
 @pytest.mark.parametrize("case", ["esrgan_nb1_crop64", "esrgan_nb23_crop128", "esrgan_nb23_crop512_b2", "esrgan_nb23_crop128_b2_k10"])
 def test_step_matches_reference_golden_bf16x3(case, tmp_path, monkeypatch):
     """TNR_MMA=bf16x3 (per-layer convolutions on the bf16 matrix core with exactly split fp32 operands, include/trainner_hip.h

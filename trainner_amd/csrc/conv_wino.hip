@@ -244,17 +244,47 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
                 ea[q] = H == 0 ? r[q][0] - r[q][2] : r[q][1] - r[q][0];
                 eb[q] = H == 0 ? r[q][1] + r[q][2] : r[q][0] - r[q][2];
             }
+            auto colstep = [&](const f32x4 (&e)[4], int j) __attribute__((always_inline)) {
+                return j == 0 ? e[0] - e[2] : (j == 1 ? e[1] + e[2] : (j == 2 ? e[2] - e[1] : e[1] - e[3]));
+            };
+            auto store3 = [&](int xl, const tnr_bf16x4 &h, const tnr_bf16x4 &m, const tnr_bf16x4 &l) __attribute__((always_inline)) {
+                float *d = s_vh + v_dst0 + xl * XL_STRIDE;
+                *reinterpret_cast<tnr_f32x2 *>(d) = __builtin_bit_cast(tnr_f32x2, h);
+                *reinterpret_cast<tnr_f32x2 *>(d + 8) = __builtin_bit_cast(tnr_f32x2, m);
+                *reinterpret_cast<tnr_f32x2 *>(d + 16) = __builtin_bit_cast(tnr_f32x2, l);
+            };
+            // two transform positions at a time, level by level: the split is a chain of seven dependent steps per value, and one position
+            // (four channels) alone leaves the vector ALU waiting on itself
             auto emit = [&](const f32x4 (&e)[4], int xl0) __attribute__((always_inline)) {
+#ifdef WN_EMIT1
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = j == 0 ? e[0] - e[2] : (j == 1 ? e[1] + e[2] : (j == 2 ? e[2] - e[1] : e[1] - e[3]));
                     tnr_f32x2 pc[3];
-                    tnr_split4_bf16x3_pk(v, pc);
+                    tnr_split4_bf16x3_pk(colstep(e, j), pc);
                     float *d = s_vh + v_dst0 + (xl0 + j) * XL_STRIDE;
                     *reinterpret_cast<tnr_f32x2 *>(d) = pc[0];
                     *reinterpret_cast<tnr_f32x2 *>(d + 8) = pc[1];
                     *reinterpret_cast<tnr_f32x2 *>(d + 16) = pc[2];
                 }
+#else
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x4 va = colstep(e, j), vb = colstep(e, j + 1);
+                    tnr_bf16x4 ha, hb, ma, mb;
+                    f32x4 ra, rb, qa, qb;
+                    tnr_pk_level(va, ha, ra);
+                    tnr_pk_level(vb, hb, rb);
+                    tnr_pk_level(ra, ma, qa);
+                    tnr_pk_level(rb, mb, qb);
+                    const tnr_f32x2 a0 = {qa[0], qa[1]}, a1 = {qa[2], qa[3]}, b0 = {qb[0], qb[1]}, b1 = {qb[2], qb[3]};
+                    const tnr_bf16x4 la = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a0, tnr_bf16x2)),
+                                                                                 __builtin_bit_cast(float, __builtin_convertvector(a1, tnr_bf16x2))});
+                    const tnr_bf16x4 lb = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(b0, tnr_bf16x2)),
+                                                                                 __builtin_bit_cast(float, __builtin_convertvector(b1, tnr_bf16x2))});
+                    store3(xl0 + j, ha, ma, la);
+                    store3(xl0 + j + 1, hb, mb, lb);
+                }
+#endif
             };
 #ifdef WN_TIMELINE
             __builtin_amdgcn_sched_barrier(0);
