@@ -478,6 +478,33 @@ def test_conv3x3_winograd_form_agrees_with_direct_kernel(case):
     assert float((half - run(True)).abs().max()) <= 3e-6 * sc and not torch.equal(half, got)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, False, "plain"), (1, 40, 72, 128, 128, False, "plain"), (3, 17, 33, 64, 128, False, "none"),
+                                  (2, 32, 32, 512, 512, False, "plain"), (2, 32, 32, 64, 64, True, "mask"), (1, 40, 72, 128, 128, True, "mask"),
+                                  (3, 17, 33, 128, 64, True, "none"), (2, 32, 32, 512, 512, True, "mask"), (1, 8, 32, 32, 64, True, "plain")])
+def test_four_tap_weight_stream_kernel_equals_staged_weights(case, monkeypatch):
+    """conv_s2_d4_kernel (csrc/conv_sweep.hip: the discriminators' 4x4 stride-2 convolution, discriminators.py:24-34, as 2 x 2 taps over the
+    parity planes, and its data-gradient per output parity class, with the weights as a pre-split stream) against conv_tile_kernel
+    (ops.S2_D4 = False), bit for bit in the split arithmetic: ragged tiles, channel windows of wider buffers, bias / mask epilogues,
+    64 .. 512 channels; with bf16 operands (`use_amp`) the two agree to 2e-5 of the scale (another order of the products inside an MFMA)."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the weight stream is the split arithmetic's (three bf16 planes)")
+    from tools.probes.s2_check import layer
+    N, Ho, Wo, Cin, Cout, dg, epi = case
+    for mma in (hip.MMA_BF16X3, hip.MMA_BF16):
+        monkeypatch.setattr(ops, "MMA", mma)
+        run, _, _ = layer(N, Ho, Wo, Cin, Cout, 60, dg, epi)
+        ref = run(False)
+        got = run(True)
+        if mma == hip.MMA_BF16X3:
+            assert torch.equal(got, ref) and torch.equal(run(True), ref)
+        else:
+            assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        yc = Cin if dg else Cout
+        assert float(got[..., :64].min()) == 3.0 and float(got[..., 64 + yc:].min()) == 3.0
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32, 64), (1, 40, 72, 64), (2, 24, 40, 128), (3, 9, 33, 64)])
 @pytest.mark.parametrize("act", ["relu", "lrelu", "none"])
 def test_pixel_shuffle_folded_into_the_conv_store(shape, act, monkeypatch):

@@ -1191,6 +1191,253 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
     }
 }
 
+// =====================================================================================================================================
+// The four-tap convolutions of the discriminators on the same machinery ("s2"; TNR_MMA_BF16X3 / TNR_MMA_BF16, Cout % 64 == 0, Cin % 16 == 0):
+//   TNR_CONV_4x4_S2   k4 s2 p1 (discriminators.py:24-34) as 2 x 2 taps over the four parity planes of the input: chunk = (parity plane pp,
+//                     16 channels), halo tile 9 x 33 positions of that plane;
+//   TNR_DGRAD_4x4_S2  its data-gradient, one output parity class (py, px) per tile: 2 x 2 taps at positions (1 + py - ty, 1 + px - tx)
+//                     of the 10 x 34 halo tile of the incoming gradient, stored to pixels (2 y + py, 2 x + px).
+// conv_tile_kernel splits and stages a 4 x 64 x 16 weight slab through LDS per workgroup and chunk between two barriers; here the weights
+// are a pre-split stream (tnr_conv_wq_pack: units of one tap x one 32-cout N-tile x 16 channels in register order) read straight from L2
+// into a four-deep register ring, the input tile is double-buffered and its split + store rides behind the MFMAs: one barrier per chunk.
+// Chunk, tap and product order are conv_tile_body's: bit-identical results.
+constexpr int S2_TAPS = 4, S2_NU = S2_TAPS * 2, S2_RING = 4;
+struct S2K {
+    ConvK a;
+    const float *wq;                   // forward: [cb][pp][chunk][tap][N-tile] units; gradient: [par][cb][chunk][tap][N-tile]
+    int wq_bytes;
+    int nck;                           // 16-channel chunks per parity plane (forward) / of the gradient's channels
+    int tiles_x, tiles_y, ncb, tiles;
+};
+struct S2PackK {
+    const float *wp;
+    int KinP, KoutP, nck, ncb, units, dgrad;
+    float *out;
+};
+
+__global__ void __launch_bounds__(256) s2_pack_kernel(const S2PackK a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int unit = g >> 6, r = (g >> 1) & 31, h = g & 1;
+    if (unit >= a.units) return;
+    const int j = unit & 1, tap = (unit >> 1) & 3;
+    int rest = unit >> 3;
+    const float *src;
+    if (a.dgrad) {       // [par][cb][ck]: packed slab [par][tap][KoutP][KinP]
+        const int ck = rest % a.nck;
+        rest /= a.nck;
+        const int cb = rest % a.ncb, par = rest / a.ncb;
+        src = a.wp + (((size_t)par * 4 + tap) * a.KoutP + cb * 64 + j * 32 + r) * a.KinP + 16 * ck + 8 * h;
+    } else {             // [cb][pp][ck]: packed slab [tap][KoutP][4 KinP], parity plane pp = columns pp KinP ..
+        const int ck = rest % a.nck;
+        rest /= a.nck;
+        const int pp = rest & 3, cb = rest >> 2;
+        src = a.wp + ((size_t)tap * a.KoutP + cb * 64 + j * 32 + r) * (4 * a.KinP) + pp * a.KinP + 16 * ck + 8 * h;
+    }
+    const f32x4 q0 = *reinterpret_cast<const f32x4 *>(src), q1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    tnr_bf16x8 pl[3];
+    tnr_split_bf16x3(q0, q1, pl);
+    float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + (h * 32 + r) * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + k * 256) = pl[k];
+}
+
+// one input chunk: 4 taps x 2 N-tiles = 8 units of 12 MFMAs; tap t of M-tile m reads its fragment rows at LDS offset aaddr[m][t] (floats:
+// row and slot swizzle of the SHIFTED row); everything else as in sweep4_chunk<.., DIRECT = true> with a four-deep fragment ring
+// (8 units = two turns of it)
+template <bool AMP, class Item, class BFetch>
+__device__ __forceinline__ void tap4_chunk(f32x16 (&acc)[2][2], const float *sa, const int (&aaddr)[2][4], Item &&item_step,
+                                           tnr_bf16x8 (&fbr)[S2_RING][3], BFetch &&b_fetch) {
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};      // the six kept partial products, smallest first
+    tnr_bf16x8 fa[2][2][3];
+    auto read_a = [&](auto tc, int m, int sp) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        fa[t & 1][m][sp] = *reinterpret_cast<const tnr_bf16x8 *>(sa + aaddr[m][t] + 8 * sp);
+    };
+#pragma unroll
+    for (int k = 0; k < (AMP ? 2 : 6); ++k) read_a(std::integral_constant<int, 0>{}, AMP ? k : k / 3, AMP ? 0 : k % 3);
+    sw_static_for<0, S2_NU>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value, t = u >> 1, jj = u & 1;
+        constexpr bool NEXT_TAP = jj == 1 && t + 1 < S2_TAPS;
+        constexpr int ITEM = u - (S2_NU - 6);           // the chunk's last six units carry the next chunk's (up to) six items
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AMP) {
+            sw_static_for<0, 2>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                acc[m][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][0], fbr[u % S2_RING][0], acc[m][jj], 0, 0, 0);
+                if constexpr (m == 0) b_fetch(std::integral_constant<int, (u + 3) % S2_RING>{}, 0);
+                if constexpr (NEXT_TAP) read_a(std::integral_constant<int, (t + 1 < S2_TAPS ? t + 1 : t)>{}, m, 0);
+                if constexpr (m == 1 && ITEM >= 0) item_step(std::integral_constant<int, (ITEM >= 0 ? ITEM : 0)>{}, std::integral_constant<int, -1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            sw_static_for<0, 12>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, p = i / 2, m = i % 2;
+                acc[m][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t & 1][m][TA[p]], fbr[u % S2_RING][TB[p]], acc[m][jj], 0, 0, 0);
+                if constexpr (i < 3) b_fetch(std::integral_constant<int, (u + 3) % S2_RING>{}, i);       // unit g + 3 into the slot unit g - 1 left
+                if constexpr (NEXT_TAP && i >= 3 && i < 9) read_a(std::integral_constant<int, (t + 1 < S2_TAPS ? t + 1 : t)>{}, (i - 3) / 3, (i - 3) % 3);
+                if constexpr (ITEM >= 0 && i >= 4 && i < 9) item_step(std::integral_constant<int, (ITEM >= 0 ? ITEM : 0)>{}, std::integral_constant<int, (i >= 4 && i < 9 ? i - 4 : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    });
+}
+
+template <int MODE, bool AMP>
+__global__ void __launch_bounds__(256, 2) conv_s2_d4_kernel(const S2K c) {
+    constexpr bool DG = MODE == TNR_DGRAD_4x4_S2;
+    constexpr int HT = DG ? SW_HT : SW_TH + 1, WT = DG ? SW_WT : SW_TW + 1, ROWS = HT * WT;      // halo tile of the gradient / of one parity plane
+    constexpr int A_IT = (ROWS * 4 + 255) / 256;                                                 // 6 / 5 staging items per thread and chunk
+    static_assert(A_IT <= 6 && A_IT * 256 <= SW_A_ALLOC_ROWS * 4, "staging plan");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_a = smem;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    const ConvK &a = c.a;
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.wq), 0, c.wq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+    const int nchunks = DG ? c.nck : 4 * c.nck;
+
+    for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+        // (cb -- and the gradient's parity class -- innermost: the workgroups of a pixel tile run side by side and share its input in L2)
+        int rest = tile;
+        const int cb = rest % c.ncb;
+        rest /= c.ncb;
+        int par = 0;
+        if constexpr (DG) {
+            par = rest & 3;
+            rest >>= 2;
+        }
+        const int tx = rest % c.tiles_x;
+        rest /= c.tiles_x;
+        const int ty = rest % c.tiles_y, n = rest / c.tiles_y;
+        const int ty0 = ty * SW_TH, tx0 = tx * SW_TW;
+        const int py = par >> 1, px = par & 1;
+        // tap t = (t >> 1, t & 1) sits at position (pos_y, pos_x) of the halo tile; fragment rows of this wave's two M-tiles (tile rows
+        // 2 w, 2 w + 1): row (2 w + m + pos_y) WT + li + pos_x, slot swizzle of THAT row
+        int aaddr[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pos_y = DG ? 1 + py - (t >> 1) : (t >> 1), pos_x = DG ? 1 + px - (t & 1) : (t & 1);
+                const int pp = (2 * wave + m + pos_y) * WT + li + pos_x;
+                aaddr[m][t] = pp * SW_ROW + 4 * (half ^ ((pp >> TNR_X3_SWZ) & 1));
+            }
+        int in_off[A_IT], a_dst[A_IT];
+        auto plan = [&](int pp) __attribute__((always_inline)) {        // forward: the parity plane pp of the input; gradient: pp = 0
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int i = tid + it * 256, row = i >> 2, q = i & 3;
+                const int hr = row / WT, hc = row - hr * WT;
+                const int Y = DG ? ty0 + hr - 1 : 2 * (ty0 + hr) - 1 + (pp >> 1), X = DG ? tx0 + hc - 1 : 2 * (tx0 + hc) - 1 + (pp & 1);
+                const bool in = (row < ROWS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                in_off[it] = in ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+                a_dst[it] = row * SW_ROW + 4 * ((q >> 1) ^ ((row >> TNR_X3_SWZ) & 1)) + 2 * (q & 1);
+            }
+        };
+        plan(0);
+        f32x4 rin[A_IT];
+        auto a_load = [&](int ch, bool valid) __attribute__((always_inline)) {     // on every path (past-the-end addresses read zeros)
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const unsigned bo = (valid && in_off[it] >= 0) ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;
+                rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
+            }
+        };
+        tnr_bf16x4 ih, im, il;
+        f32x4 ir;
+        auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {      // (conv_sweep4_kernel: five steps per item; k = -1: a whole bf16-operand item)
+            constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
+            if constexpr (it < A_IT) {
+                if constexpr (k < 0) {
+                    const tnr_bf16x4 hh = __builtin_convertvector(rin[it], tnr_bf16x4);
+                    *reinterpret_cast<tnr_f32x2 *>(s_a + buf * SW_A_FLOATS + a_dst[it]) = __builtin_bit_cast(tnr_f32x2, hh);
+                } else if constexpr (k == 0) {
+                    ih = __builtin_convertvector(rin[it], tnr_bf16x4);
+                    ir = rin[it] - __builtin_convertvector(ih, f32x4);
+                } else if constexpr (k == 1) {
+                    im = __builtin_convertvector(ir, tnr_bf16x4);
+                    ir = ir - __builtin_convertvector(im, f32x4);
+                } else {
+                    if constexpr (k == 2) il = __builtin_convertvector(ir, tnr_bf16x4);
+                    float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
+                    *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
+                }
+            }
+        };
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+        a_load(0, true);
+        __syncthreads();                 // the previous tile's last fragments are consumed
+        tnr_bf16x8 fbr[S2_RING][3];
+        int bq = (DG ? (par * c.ncb + cb) * c.nck : cb * 4 * c.nck) * S2_NU;        // this tile's part of the stream
+        auto b_fetch = [&](auto rc, int sp) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            if constexpr (AMP) {
+                fbr[r][0] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, bq * 3072, 0));
+                ++bq;
+            } else {
+                fbr[r][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (bq * 3 + sp) * 1024, 0));
+                if (sp == 2) ++bq;
+            }
+        };
+        sw_static_for<0, 3>([&](auto rc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int sp = 0; sp < (AMP ? 1 : 3); ++sp) b_fetch(rc, sp);
+        });
+        sw_static_for<0, 6>([&](auto ic) __attribute__((always_inline)) {
+            if constexpr (AMP) item_step_buf(ic, std::integral_constant<int, -1>{}, 0);
+            else sw_static_for<0, 5>([&](auto kc) __attribute__((always_inline)) { item_step_buf(ic, kc, 0); });
+        });
+        bool has_next = false;
+        int e = 0;
+        auto item_step = [&](auto ic, auto kc) __attribute__((always_inline)) {
+            if (has_next) item_step_buf(ic, kc, (e + 1) & 1);
+        };
+#pragma unroll 1
+        for (int ck = 0; ck < nchunks; ++ck) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the chunk's input tile is in LDS; the other buffer is consumed
+            has_next = ck + 1 < nchunks;
+            int ch_next = 16 * (ck + 1);
+            if constexpr (!DG) {                     // forward: chunk = (parity plane, 16 channels); a new plane has its own addresses
+                const int nx = ck + 1, ppn = nx / c.nck;
+                ch_next = 16 * (nx - ppn * c.nck);
+                if (has_next && ppn != ck / c.nck) plan(ppn);
+            }
+            a_load(ch_next, has_next);
+            tap4_chunk<AMP>(acc, s_a + (e & 1) * SW_A_FLOATS, aaddr, item_step, fbr, b_fetch);
+            ++e;
+        }
+        f32x16 t2[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            t2[m][0] = acc[m][0];
+            t2[m][1] = acc[m][1];
+        }
+        conv_epilogue_dpp<MODE, SW_TW, 2, 2, false, 1>(a, t2, cb, n, ty0, tx0, par, wave, li, half, y_rs);
+    }
+}
+
+bool s2_ok(const tnr_conv_desc *d) {
+    if (d->mode != TNR_CONV_4x4_S2 && d->mode != TNR_DGRAD_4x4_S2) return false;
+    const bool dg = d->mode == TNR_DGRAD_4x4_S2;
+    const int tw = dg ? d->W : d->Wo, th = dg ? d->H : d->Ho;            // the tile space
+    return (d->mma == TNR_MMA_BF16X3 || d->mma == TNR_MMA_BF16) && d->pad_mode == 0 && d->shuffle == 0 && (d->Cout % 64) == 0 && d->KoutP == d->Cout &&
+           d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && tw >= 32 && th >= 8 &&
+           (dg ? (d->Ho == 2 * d->H && d->Wo == 2 * d->W) : (d->H == 2 * d->Ho && d->W == 2 * d->Wo)) &&
+           (int64_t)d->N * d->H * d->W * d->x.ctot < (1LL << 30) && (int64_t)d->N * d->Ho * d->Wo * d->y.ctot < (1LL << 30) &&
+           (int64_t)(d->Cout / 64) * (d->Cin / 16) * 4 * S2_NU * SW_UNIT_FLOATS * (int64_t)sizeof(float) < (1LL << 31);
+}
+
 bool d4_ok(const tnr_conv_desc *d) {
     if (d->shuffle != 0 && !(d->shuffle == 2 && (d->Cout % 256) == 0 && d->r1.ptr == nullptr && d->r2.ptr == nullptr && d->m.ptr == nullptr &&
                              d->noise_pos == 0 && d->pad_mode == 0 && (d->y.ctot % 4) == 0 &&
@@ -1366,11 +1613,22 @@ extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void
 }
 
 extern "C" int64_t tnr_conv_wq_bytes(const tnr_conv_desc *d) {
+    if (d != nullptr && s2_ok(d)) return (int64_t)(d->Cout / 64) * (d->Cin / 16) * 4 * S2_NU * SW_UNIT_FLOATS * (int64_t)sizeof(float);
     if (d == nullptr || !d4_ok(d)) return 0;
     return (int64_t)(d->Cout / 64) * (d->Cin / 16) * 18 * SW_UNIT_FLOATS * (int64_t)sizeof(float);
 }
 
 extern "C" int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t image_bytes, void *stream) {
+    if (d != nullptr && image != nullptr && d->wp != nullptr && s2_ok(d)) {      // the four-tap forms: 4 (parity planes | parity classes) x chunks x 4 taps x 2 N-tiles
+        S2PackK a;
+        a.wp = d->wp; a.KinP = d->KinP; a.KoutP = d->KoutP; a.nck = d->Cin / 16; a.ncb = d->Cout / 64;
+        a.dgrad = d->mode == TNR_DGRAD_4x4_S2;
+        a.units = a.ncb * 4 * a.nck * S2_NU;
+        TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_wq_pack: image buffer too small");
+        a.out = static_cast<float *>(image);
+        hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
+        return tnr_check_launch("conv_wq_pack (four-tap form)");
+    }
     TNR_REQUIRE(d != nullptr && image != nullptr && d->wp != nullptr && d4_ok(d), "conv_wq_pack: the launch cannot use a pre-split weight stream");
     D4PackK a;
     a.wp = d->wp; a.KinP = d->KinP; a.KoutP = d->KoutP; a.nck = d->Cin / 16; a.ncb = d->Cout / 64;
@@ -1380,6 +1638,58 @@ extern "C" int tnr_conv_wq_pack(const tnr_conv_desc *d, void *image, int64_t ima
     a.out = static_cast<float *>(image);
     hipLaunchKernelGGL(d4_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return tnr_check_launch("conv_wq_pack");
+}
+
+// the four-tap forms (4x4 stride 2 forward, its data-gradient) with a pre-split weight stream; 1: not for this kernel
+int tnr_launch_conv_s2_d4(const tnr_conv_desc *d, void *stream) {
+    if (!s2_ok(d) || d->wq == nullptr || d->wq_bytes < tnr_conv_wq_bytes(d) || d->noise_pos != 0) return 1;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2_d4_kernel<TNR_CONV_4x4_S2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2_d4_kernel<TNR_CONV_4x4_S2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2_d4_kernel<TNR_DGRAD_4x4_S2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_s2_d4_kernel<TNR_DGRAD_4x4_S2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S4D_LDS_BYTES) != hipSuccess || cus < 1) {
+            cus = 0;
+            tnr_set_error("conv_s2_d4: cannot set up the kernel");
+            return TNR_ELAUNCH;
+        }
+    }
+    const bool dg = d->mode == TNR_DGRAD_4x4_S2;
+    S2K c;
+    ConvK &k = c.a;
+    k.x = d->x.ptr; k.x_ct = d->x.ctot; k.x_co = d->x.coff;
+    k.N = d->N; k.H = d->H; k.W = d->W; k.Cin = d->Cin;
+    k.wp = d->wp; k.KinP = d->KinP; k.KoutP = d->KoutP;
+    k.y = d->y.ptr; k.y_ct = d->y.ctot; k.y_co = d->y.coff; k.Ho = d->Ho; k.Wo = d->Wo; k.Cout = d->Cout;
+    k.bias = d->bias; k.act = d->act; k.slope = d->slope; k.alpha = d->alpha;
+    k.r1 = d->r1.ptr; k.r1_ct = d->r1.ctot; k.r1_co = d->r1.coff; k.r1_ch = d->r1_ch; k.beta1 = d->beta1;
+    k.r2 = d->r2.ptr; k.r2_ct = d->r2.ctot; k.r2_co = d->r2.coff; k.alpha2 = d->alpha2;
+    k.m = d->m.ptr; k.m_ct = d->m.ctot; k.m_co = d->m.coff; k.m_lo = d->m_lo; k.m_hi = d->m_hi; k.m_slope = d->m_slope;
+    k.noise_pos = 0; k.noise_sigma = 0.f; k.noise_k0 = 0; k.noise_k1 = 0; k.noise_pix0 = 0;
+    k.th_space = dg ? d->H : d->Ho; k.tw_space = dg ? d->W : d->Wo;
+    k.ksplit = 1; k.split_stride = 0; k.bf = d->mma; k.reflect = 0;
+    c.wq = static_cast<const float *>(d->wq);
+    c.wq_bytes = (int)tnr_conv_wq_bytes(d);
+    c.nck = d->Cin / 16;
+    c.tiles_x = tnr_cdiv(k.tw_space, SW_TW);
+    c.tiles_y = tnr_cdiv(k.th_space, SW_TH);
+    c.ncb = d->Cout / 64;
+    const int64_t tiles = (int64_t)c.tiles_x * c.tiles_y * c.ncb * d->N * (dg ? 4 : 1);
+    if (tiles >= (1LL << 31)) return 1;
+    c.tiles = (int)tiles;
+    k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = c.ncb;
+    const unsigned grid = (unsigned)(c.tiles < 2 * cus ? c.tiles : 2 * cus);
+    const bool amp = d->mma == TNR_MMA_BF16;
+    if (dg) {
+        if (amp) hipLaunchKernelGGL((conv_s2_d4_kernel<TNR_DGRAD_4x4_S2, true>), dim3(grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+        else hipLaunchKernelGGL((conv_s2_d4_kernel<TNR_DGRAD_4x4_S2, false>), dim3(grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    } else {
+        if (amp) hipLaunchKernelGGL((conv_s2_d4_kernel<TNR_CONV_4x4_S2, true>), dim3(grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+        else hipLaunchKernelGGL((conv_s2_d4_kernel<TNR_CONV_4x4_S2, false>), dim3(grid), dim3(256), S4D_LDS_BYTES, (hipStream_t)stream, c);
+    }
+    return tnr_check_launch("conv_s2_d4");
 }
 
 // called by tnr_conv_forward (conv_tile.hip) for a launch that carries a pre-split weight stream; 1: not for this kernel

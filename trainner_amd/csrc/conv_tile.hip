@@ -154,6 +154,7 @@ int conv_ksplit(const tnr_conv_desc *d, int64_t tiles) {
 
 int tnr_launch_conv3x3_d4(const tnr_conv_desc *d, void *stream);      // conv_sweep.hip (1: not for that kernel)
 int tnr_launch_conv3x3_wino(const tnr_conv_desc *d, void *stream);    // conv_wino.hip (1: not for that kernel)
+int tnr_launch_conv_s2_d4(const tnr_conv_desc *d, void *stream);      // conv_sweep.hip: the four-tap forms (1: not for that kernel)
 
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
@@ -250,7 +251,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     if (d->wq != nullptr && k.ksplit == 1) {       // pre-split weight stream: the direct four-wave kernel (conv_sweep.hip), when the launch qualifies
         static const bool d4 = [] { const char *e = std::getenv("TNR_X3_D4"); return e == nullptr || e[0] != '0'; }();
         if (d4 || d->shuffle != 0) {
-            rc = tnr_launch_conv3x3_d4(d, (void *)s);
+            rc = (d->mode == TNR_CONV_4x4_S2 || d->mode == TNR_DGRAD_4x4_S2) ? tnr_launch_conv_s2_d4(d, (void *)s) : tnr_launch_conv3x3_d4(d, (void *)s);
             if (rc <= 0) return rc;
         }
     }

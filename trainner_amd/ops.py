@@ -312,6 +312,7 @@ IMAGE_C4 = os.environ.get("TNR_IMAGE_C4", "1") != "0"       # taps-in-K kernel f
 SMALL_GEMM = os.environ.get("TNR_SMALL_GEMM", "1") != "0"   # im2col + split-K GEMM for <= 4096-pixel layers (A/B switch)
 
 
+S2_D4 = os.environ.get("TNR_S2_D4", "1") != "0"      # the four-tap layers (4x4 stride 2 and its data-gradient) on the weight-stream machinery too (A/B switch)
 X3_D4 = os.environ.get("TNR_X3_D4", "1") != "0"      # TNR_MMA=bf16x3: 64-cout 3x3 layers take their weights as a pre-split stream (A/B switch)
 _wq_oneoff = {}
 
@@ -422,7 +423,8 @@ def conv(x, wp, y, mode=CONV_3x3, wino=None, **epi):
             d.wq, d.wq_bytes, d.wq_form = img.data_ptr(), img.numel() * 4, 1
         else:
             assert wino is not True, "this launch cannot run in the Winograd form"
-    if not d.wq and X3_D4 and mode == CONV_3x3 and d.mma in (hip.MMA_BF16X3, hip.MMA_BF16) and not d.ws and y.C % 64 == 0:
+    if not d.wq and X3_D4 and (mode == CONV_3x3 or (S2_D4 and mode in (CONV_4x4_S2, DGRAD_4x4_S2))) and d.mma in (hip.MMA_BF16X3, hip.MMA_BF16) \
+            and not d.ws and y.C % 64 == 0:
         img = _wq_image(hip.load(), d, wp, x.buf.device)
         if img is not None:
             d.wq, d.wq_bytes = img.data_ptr(), img.numel() * 4
