@@ -266,6 +266,23 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
                     *reinterpret_cast<tnr_f32x2 *>(d + 8) = pc[1];
                     *reinterpret_cast<tnr_f32x2 *>(d + 16) = pc[2];
                 }
+#elif defined(WN_EMIT4)     /* (probe: all four positions of a transform row level by level) */
+                f32x4 v[4], r[4], q[4];
+                tnr_bf16x4 h[4], m[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = colstep(e, j);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tnr_pk_level(v[j], h[j], r[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tnr_pk_level(r[j], m[j], q[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const tnr_f32x2 a0 = {q[j][0], q[j][1]}, a1 = {q[j][2], q[j][3]};
+                    l[j] = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a0, tnr_bf16x2)),
+                                                                   __builtin_bit_cast(float, __builtin_convertvector(a1, tnr_bf16x2))});
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) store3(xl0 + j, h[j], m[j], l[j]);
 #else
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
