@@ -6,8 +6,8 @@ FAMILIES = {
     "conv_tile_3x3": ("conv_tile_kernel<0,", "conv3x3_x3w8_kernel", "conv3x3_d4_kernel"),
     "conv_wino_3x3": ("conv3x3_wino_kernel",),          # the Winograd F(2x2, 3x3) form of the >= 128-channel 3x3 layers (csrc/conv_wino.hip)
     "conv_tile_3x3_up2": ("conv_tile_kernel<1,",),
-    "conv_tile_4x4s2": ("conv_tile_kernel<2,",),
-    "conv_tile_dgrad4x4s2": ("conv_tile_kernel<3,",),
+    "conv_tile_4x4s2": ("conv_tile_kernel<2,", "conv_s2_d4_kernel<2,"),
+    "conv_tile_dgrad4x4s2": ("conv_tile_kernel<3,", "conv_s2_d4_kernel<3,"),
     "conv_tile_1x1": ("conv_tile_kernel<4,",),
     "conv_tile_3x3_c4": ("conv_tile_kernel<5,",),
     "wgrad_tile": ("wgrad_tile_kernel",),

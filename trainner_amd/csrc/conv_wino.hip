@@ -370,7 +370,9 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
 #endif
         };
 
-        // ---- prologue: raw patches of chunks 0 and 1 (each half stages its share)
+        // ---- prologue: raw patches of chunks 0 and 1 (each half stages its share).  (Requesting the NEXT tile's two patches in front of the
+        // inverse transform and storing them behind its exchange -- no global-memory latency between tiles -- was 2-7 % SLOWER on every
+        // shape: 24 more live registers through the epilogue and one more barrier; profiles/r10d_wino_tile_pipelining_ab.txt)
         __syncthreads();                 // the previous tile's exchange / fragments are consumed
         raw_load(0, true);
         raw_store(0);
