@@ -252,6 +252,14 @@ int tnr_conv_chain(const tnr_conv_desc *stages, const int32_t *fresh_from, int32
  * i.e. one ws per stream).  Results are bit-identical to tnr_conv_chain / five tnr_conv_forward calls in TNR_MMA_BF16X3.    */
 int64_t tnr_conv_sweep_image_bytes(const tnr_conv_desc *stages, int32_t n);
 int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, void *stream);
+/* the images of MANY blocks in one launch: tnr_conv_sweep_pack_item validates a block like tnr_conv_sweep_pack and fills one HOST entry
+ * (opaque but for `units`); the caller keeps the entries of all its blocks in a DEVICE array and rebuilds every image with one
+ * tnr_conv_sweep_pack_batch(items_dev, n, max over the entries' units) whenever the packed weights changed (once per optimiser step:
+ * 2 launches -- forward and gradient-mirror blocks -- instead of 2 x 69 for RRDBNet-23).  An entry stays valid while the stages'
+ * packed-weight pointers and the image pointer do.                                                                                  */
+typedef struct tnr_sweep_pack_item { int32_t units; int32_t reserved; uint64_t opaque[15]; } tnr_sweep_pack_item;
+int tnr_conv_sweep_pack_item(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, tnr_sweep_pack_item *item);
+int tnr_conv_sweep_pack_batch(const tnr_sweep_pack_item *items_dev, int32_t n, int32_t max_units, void *stream);
 int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void *image, uint32_t *ws, int64_t ws_bytes, uint32_t epoch,
                    void *stream);
 /* 3x3 s1 p1 convolution with Cout <= 4 on the vector ALUs (one thread = one pixel x 4 outputs): G's last conv

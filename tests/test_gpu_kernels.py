@@ -302,6 +302,37 @@ def test_dense_block_sweep_equals_per_layer_launches(shape, grad_shape, mma_mode
     assert ops.chain_error_flag() == 0
 
 
+def test_sweep_images_rebuilt_in_one_launch(mma_mode, monkeypatch):
+    """tnr_conv_sweep_pack_batch (ops.SWEEP_PACK_BATCH: every dense block's sweep image of a packer rebuilt in one launch after the weights
+    changed) gives the images the per-block tnr_conv_sweep_pack builds, bit for bit -- two blocks, three weight updates."""
+    ops = _ops()
+    from trainner_amd import hip
+    if ops.MMA != hip.MMA_BF16X3:
+        pytest.skip("the sweep kernel is the dense block of the bf16x3 arithmetic")
+    from tools.probes.sweep_check import block
+    outs = {}
+    for batch in (False, True):
+        monkeypatch.setattr(ops, "SWEEP_PACK_BATCH", batch)
+        runs = [block(2, 24, 40, seed=13 + i, grad_shape=bool(i), with_r2=True) for i in range(2)]
+        res = []
+        for step in range(3):
+            for run in runs:
+                gb, go, st = run("sweep")
+                res.append((gb.clone(), go.clone()))
+                packer = st[0]["wp"].owner
+            for run in runs:                       # an "optimiser step": scale the weights, re-pack (the batch rebuilds every image)
+                _, _, st = run("layers")
+                p = st[0]["wp"].owner
+                for j in p.jobs:
+                    j[0].mul_(0.9)
+                p.run()
+        outs[batch] = res
+        if batch:
+            assert "_sweep_batch" in packer.__dict__ and len(packer.__dict__["_sweep_batch"]["items"]) == 1
+    for (a, b), (c, d) in zip(outs[False], outs[True]):
+        assert torch.equal(a, c) and torch.equal(b, d)
+
+
 def test_dense_block_form_is_chosen_per_box(mma_mode, monkeypatch):
     """ops.SWEEP_AUTO: a dense block of the training shape is timed ONCE, explicitly (ops.calibrate_dense_block_form -- the models call
     it from their constructor on scratch buffers, never from inside a forward), as one launch and as five per-layer launches, and the

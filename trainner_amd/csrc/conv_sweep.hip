@@ -35,6 +35,7 @@
 // Arithmetic (split, kept partial products and their order, channel and tap order, epilogue) is that of conv_tile_body<.., BF = 2>:
 // results are bit-identical to five tnr_conv_forward launches in TNR_MMA_BF16X3.
 #include <stddef.h>
+#include <string.h>
 #include <type_traits>
 #include <utility>
 #include "conv_body.h"
@@ -121,8 +122,7 @@ struct SweepPackK {
     float *out;
 };
 
-__global__ void __launch_bounds__(256) sweep_pack_kernel(const SweepPackK a) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void sweep_pack_one(const SweepPackK &a, const int g) {
     const int unit = g >> 6, r = (g >> 1) & 31, sp = g & 1;
     if (unit >= a.units) return;
     int p = 0, u0 = 0;
@@ -152,6 +152,14 @@ __global__ void __launch_bounds__(256) sweep_pack_kernel(const SweepPackK a) {
     float *dst = a.out + (size_t)unit * SW_UNIT_FLOATS + r * SW_ROW + 4 * sp;
 #pragma unroll
     for (int k = 0; k < 3; ++k) *reinterpret_cast<tnr_bf16x8 *>(dst + 8 * k) = pl[k];
+}
+
+__global__ void __launch_bounds__(256) sweep_pack_kernel(const SweepPackK a) { sweep_pack_one(a, blockIdx.x * 256 + threadIdx.x); }
+
+// the same for MANY blocks in one launch (tnr_conv_sweep_pack_batch): blockIdx.y = entry of a device table of the kernel arguments above
+__global__ void __launch_bounds__(256) sweep_pack_batch_strided_kernel(const tnr_sweep_pack_item *items) {
+    const SweepPackK a = *reinterpret_cast<const SweepPackK *>(items[blockIdx.y].opaque);
+    sweep_pack_one(a, blockIdx.x * 256 + threadIdx.x);
 }
 
 // The N-tiles [J0, J0 + NJ) x T taps of one ring slot: (tap, N-tile) units in stream order, 6 MFMAs each.
@@ -1555,6 +1563,36 @@ extern "C" int tnr_conv_sweep_pack(const tnr_conv_desc *stages, int32_t n, void 
     a.out = static_cast<float *>(image);
     hipLaunchKernelGGL(sweep_pack_kernel, dim3((unsigned)tnr_cdiv(a.units * 64, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return tnr_check_launch("conv_sweep_pack");
+}
+
+static_assert(sizeof(SweepPackK) <= sizeof(((tnr_sweep_pack_item *)nullptr)->opaque), "tnr_sweep_pack_item holds the pack kernel's arguments");
+
+extern "C" int tnr_conv_sweep_pack_item(const tnr_conv_desc *stages, int32_t n, void *image, int64_t image_bytes, tnr_sweep_pack_item *item) {
+    const char *why = "";
+    TNR_REQUIRE(stages != nullptr && image != nullptr && item != nullptr && sweep_pattern(stages, n, &why),
+                "conv_sweep_pack_item: not a sweepable dense block (%s)", why);
+    SweepPackK a;
+    a.nck0 = stages[0].Cin / 16;
+    a.units = sw_total_units(a.nck0);
+    a.direct = sweep_form() == 5;
+    TNR_REQUIRE((int64_t)a.units * SW_UNIT_FLOATS * (int64_t)sizeof(float) <= image_bytes, "conv_sweep_pack_item: image buffer too small");
+    for (int i = 0; i < SW_NSTAGE; ++i) {
+        a.wp[i] = stages[i].wp;
+        a.KinP[i] = stages[i].KinP;
+        a.KoutP[i] = stages[i].KoutP;
+    }
+    a.out = static_cast<float *>(image);
+    memset(item, 0, sizeof(*item));
+    memcpy(item->opaque, &a, sizeof(a));
+    item->units = a.units;
+    return TNR_OK;
+}
+
+extern "C" int tnr_conv_sweep_pack_batch(const tnr_sweep_pack_item *items_dev, int32_t n, int32_t max_units, void *stream) {
+    TNR_REQUIRE(items_dev != nullptr && n >= 1 && n <= 65535 && max_units >= 1, "conv_sweep_pack_batch: bad arguments");
+    static_assert(sizeof(tnr_sweep_pack_item) % 8 == 0, "table stride");
+    hipLaunchKernelGGL(sweep_pack_batch_strided_kernel, dim3((unsigned)tnr_cdiv(max_units * 64, 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, items_dev);
+    return tnr_check_launch("conv_sweep_pack_batch");
 }
 
 extern "C" int tnr_conv_sweep(const tnr_conv_desc *stages, int32_t n, const void *image, uint32_t *ws, int64_t ws_bytes, uint32_t epoch,

@@ -55,6 +55,10 @@ class WgradDesc(C.Structure):
     ]
 
 
+class SweepPackItem(C.Structure):      # tnr_sweep_pack_item
+    _fields_ = [("units", c_i), ("reserved", c_i), ("opaque", C.c_uint64 * 15)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", c_p), ("wp", c_p), ("Cout", c_i), ("Cin", c_i), ("kh", c_i), ("kw", c_i),
                 ("kind", c_i), ("KoutP", c_i), ("KinP", c_i), ("n_out", c_l)]
@@ -83,6 +87,8 @@ _SIGS = {
     "tnr_conv_chain_workspace_bytes": (c_l, [C.POINTER(ConvDesc)]),
     "tnr_conv_chain": (c_i, [C.POINTER(ConvDesc), C.POINTER(C.c_int32), c_i, c_p, c_l, C.c_uint32, c_p]),
     "tnr_conv_sweep_image_bytes": (c_l, [C.POINTER(ConvDesc), c_i]),
+    "tnr_conv_sweep_pack_item": (c_i, [C.POINTER(ConvDesc), c_i, c_p, c_l, C.POINTER(SweepPackItem)]),
+    "tnr_conv_sweep_pack_batch": (c_i, [c_p, c_i, c_i, c_p]),
     "tnr_conv_sweep_pack": (c_i, [C.POINTER(ConvDesc), c_i, c_p, c_l, c_p]),
     "tnr_conv_sweep": (c_i, [C.POINTER(ConvDesc), c_i, c_p, c_p, c_l, C.c_uint32, c_p]),
     "tnr_conv_thin_pack_floats": (c_l, [c_i]),

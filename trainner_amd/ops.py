@@ -116,6 +116,7 @@ class WeightPacker:
 
     def _finalize(self):
         self.__dict__.pop("_sweep_images", None)       # derived layouts of the old slabs
+        self.__dict__.pop("_sweep_batch", None)
         self.__dict__.pop("_wq_images", None)
         total = sum(round_up(j[4], 64) for j in self.jobs)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
@@ -145,6 +146,7 @@ class WeightPacker:
         hip.check(hip.load().tnr_pack_weights(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
                   "pack_weights")
         self.gen += 1
+        _repack_sweep_images(self)
 
 
 class DensePacker:
@@ -174,6 +176,7 @@ class DensePacker:
 
     def _finalize(self):
         self.__dict__.pop("_sweep_images", None)
+        self.__dict__.pop("_sweep_batch", None)
         total = sum(round_up(j[7], 64) for j in self.jobs)
         self.flat = torch.empty(total, dtype=torch.float32, device=self.device)
         items = (DensePackItem * len(self.jobs))()
@@ -204,6 +207,7 @@ class DensePacker:
         hip.check(hip.load().tnr_pack_dense_dgrad(self.table.data_ptr(), len(self.jobs), self.max_out, hip.stream()),
                   "pack_dense_dgrad")
         self.gen += 1
+        _repack_sweep_images(self)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -473,6 +477,27 @@ def g_buckets_leave_in_backward():
     return want == "1" or (want == "auto" and dense_blocks_overlap_collectives())
 
 
+# every dense block's sweep image rebuilt in ONE launch per packer run (tnr_conv_sweep_pack_batch: 2 launches per optimiser step instead of 138).
+# OFF by default: measured 0.6-2.1 ms per step SLOWER than the per-block 5 us launches, which sit in launch gaps the stream pays anyway
+# (profiles/r10g_sweep_pack_batch_ab.txt); bit-identical either way.
+SWEEP_PACK_BATCH = os.environ.get("TNR_SWEEP_PACK_BATCH", "0") != "0"
+
+
+def _repack_sweep_images(owner):
+    """After `owner` (a WeightPacker / DensePacker) re-packed its weights: rebuild the sweep images of ALL its dense blocks in one launch
+    (tnr_conv_sweep_pack_batch) instead of one small launch per block at its first use -- 2 launches per optimiser step instead of
+    2 x 69 for RRDBNet-23.  The batch is the set of images _sweep_image has built for this owner so far."""
+    b = owner.__dict__.get("_sweep_batch")
+    if not b or not SWEEP_PACK_BATCH:
+        return
+    if b["table"] is None:
+        raw = b"".join(bytes(it) for it in b["items"])
+        b["table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(b["ents"][0][0].device)
+    hip.check(hip.load().tnr_conv_sweep_pack_batch(b["table"].data_ptr(), len(b["items"]), b["max_units"], hip.stream()), "conv_sweep_pack_batch")
+    for ent in b["ents"]:
+        ent[1] = owner.gen
+
+
 _chain_epoch = {}
 _sweep_images = {}              # sweep images of one-off packs (no owning packer): (packed-weight pointers) -> [image, None]
 
@@ -501,6 +526,15 @@ def _sweep_image(lib, descs, n, stages, dev):
                 cache.pop(next(iter(cache)))
     if gen is None or ent[1] != gen:
         hip.check(lib.tnr_conv_sweep_pack(descs, n, ent[0].data_ptr(), need, hip.stream()), "conv_sweep_pack")
+        if owner is not None and SWEEP_PACK_BATCH and ent[1] is None:
+            # first build of this block's image: from the owner's next run() on it is rebuilt with all the others in one launch
+            item = hip.SweepPackItem()
+            hip.check(lib.tnr_conv_sweep_pack_item(descs, n, ent[0].data_ptr(), need, C.byref(item)), "conv_sweep_pack_item")
+            b = owner.__dict__.setdefault("_sweep_batch", {"items": [], "ents": [], "table": None, "max_units": 0})
+            b["items"].append(item)
+            b["ents"].append(ent)
+            b["table"] = None
+            b["max_units"] = max(b["max_units"], item.units)
         ent[1] = gen
     return ent[0]
 
