@@ -30,6 +30,7 @@
 // Output: a wave holds one transform row of every (patch, cout) of its N-tile; the inverse transform's column step is local, the row step
 // is one exchange through LDS among the four waves of an N-tile, after which every wave finishes one output row of one M-tile.
 #include <stddef.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 #include "conv_body.h"
@@ -483,6 +484,242 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
 #endif
 }
 
+// =====================================================================================================================================
+// The sixteen-wave form (TNR_WINO_WAVES=16; probe).  Same tile, stream, LDS image and arithmetic as conv3x3_wino_kernel -- another division
+// of the work: FOUR waves per SIMD (128 registers), two of each half, so that a transforming wave's dependent vector-ALU chains and LDS
+// round trips are covered by a second transforming wave and a multiplying wave's fragment waits by a second multiplying wave.
+//   wave w: half h = (w >> 2) & 1 (waves w, w + 4, w + 8, w + 12 share a SIMD: two of each half); role index r = (w & 3) | ((w >> 3) << 2):
+//   transform row i = 2 h + (r & 1), N-tile nt = (r >> 1) & 1, column pair jp = r >> 2 (columns j = 2 jp, 2 jp + 1), BOTH M-tiles:
+//   4 accumulator tiles (64 registers), a weight unit feeds 12 MFMAs as before.
+//   Transform: the 512 threads of a half take (patch, channel quad, row selector): ONE transform row per thread (4 positions).
+//   Inverse transform: column pairs are joined through LDS first (jp = 1 -> jp = 0), then the rows as in the eight-wave form; every wave
+//   finishes ONE (output row k, output column l, M-tile) of its N-tile.
+constexpr int W16_STAGE_IT = (WN_STAGE_ITEMS / 2 + 511) / 512;      // raw-patch items per thread of a half: 2
+
+__global__ void __launch_bounds__(1024, 4) conv3x3_wino16_kernel(const WinoK c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_v = smem;
+    float *s_raw = smem + 2 * WN_VH_FLOATS;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, half = lane >> 5;
+    const int wh = (wave >> 2) & 1, role = (wave & 3) | ((wave >> 3) << 2);
+    const int wil = role & 1, wn = (role >> 1) & 1, wjp = role >> 2;
+    const int wi = 2 * wh + wil;
+    const int tt = role * 64 + lane;                     // thread of its half (0 .. 511)
+    const ConvK &a = c.a;
+    const __amdgpu_buffer_rsrc_t x_rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)((unsigned)a.N * a.H * a.W * a.x_ct * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(c.wq), 0, c.wq_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.N * a.Ho * a.Wo * a.y_ct * 4u), 0x00020000);
+    float *s_vh = s_v + wh * WN_VH_FLOATS;
+
+    // transform plan: patch tp, channel quad tq, row selector rs (wave-uniform): this thread builds V row i_t = 2 h + rs of its patch
+    const int tp = (tt >> 2) & 63, tq = tt & 3, rs = tt >> 8;
+    const int tpy = tp >> 3, tpx = tp & 7;
+    // the two patch rows the transform row needs and the sign of the second: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+    const int it_ = 2 * wh + rs;
+    const int pa = it_ == 0 ? 0 : (it_ == 2 ? 2 : 1), pb = it_ == 0 ? 2 : (it_ == 1 ? 2 : (it_ == 2 ? 1 : 3));
+    const bool plus = it_ == 1;
+    const int raw_a = ((2 * tpy + pa) * WN_RAW_W + 2 * tpx) * WN_RAW_STRIDE + 4 * tq;
+    const int raw_b = ((2 * tpy + pb) * WN_RAW_W + 2 * tpx) * WN_RAW_STRIDE + 4 * tq;
+    static_assert(TNR_X3_SWZ < 4, "the swizzle bit must not depend on the transform position or the M-tile");
+    const int v_dst0 = (rs * 4 * WN_NP + tp) * WN_ROW + 4 * ((tq >> 1) ^ ((tp >> TNR_X3_SWZ) & 1)) + 2 * (tq & 1);
+    const int a_src0 = ((wil * 4 + 2 * wjp) * WN_NP + li) * WN_ROW + 4 * (half ^ ((li >> TNR_X3_SWZ) & 1));
+    constexpr int XL_STRIDE = WN_NP * WN_ROW;
+
+    for (int tile = blockIdx.x; tile < c.tiles; tile += gridDim.x) {
+        const int cb = tile % c.ncb;
+        int rest = tile / c.ncb;
+        const int tx = rest % c.tiles_x;
+        rest /= c.tiles_x;
+        const int ty = rest % c.tiles_y, n = rest / c.tiles_y;
+        const int ty0 = ty * WN_T, tx0 = tx * WN_T;
+        int in_off[W16_STAGE_IT], r_dst[W16_STAGE_IT];
+#pragma unroll
+        for (int it = 0; it < W16_STAGE_IT; ++it) {
+            const int il = tt + it * 512;
+            const int i = wh * (WN_STAGE_ITEMS / 2) + il, pix = i >> 2, q = i & 3;
+            const int pr = pix / WN_RAW_W, pc = pix - pr * WN_RAW_W;
+            int Y = ty0 + pr - 1, X = tx0 + pc - 1;
+            if (a.reflect) {
+                Y = Y == -1 ? 1 : (Y == a.H ? a.H - 2 : Y);
+                X = X == -1 ? 1 : (X == a.W ? a.W - 2 : X);
+            }
+            const bool mine = il < WN_STAGE_ITEMS / 2;
+            const bool in = mine & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+            in_off[it] = in ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co + q * 4) : -1;
+            r_dst[it] = mine ? pix * WN_RAW_STRIDE + 4 * q : -1;
+        }
+        f32x4 rin[W16_STAGE_IT];
+        auto raw_load = [&](int ch, bool valid) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < W16_STAGE_IT; ++it) {
+                const unsigned bo = (valid && in_off[it] >= 0) ? (unsigned)(in_off[it] + ch) * 4u : 0xfffffff0u;
+                rin[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, (int)bo, 0, 0));
+            }
+        };
+        auto raw_store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < W16_STAGE_IT; ++it)
+                if (r_dst[it] >= 0) *reinterpret_cast<f32x4 *>(s_raw + buf * WN_RAW_FLOATS + r_dst[it]) = rin[it];
+        };
+
+        f32x16 acc[2][2];                // [jj][m]
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jj][m][r] = 0.f;
+
+        tnr_bf16x8 fbr[2][3];
+        const int bq0 = (((cb * 2 + wn) * 4 + wi) * c.nck) * 4 + 2 * wjp;       // this wave's two units of a chunk: j = 2 jp, 2 jp + 1
+        auto b_fetch = [&](int ck) __attribute__((always_inline)) {
+            const int u0 = bq0 + ck * 4;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    fbr[jj][sp] = __builtin_bit_cast(tnr_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, ((u0 + jj) * 3 + sp) * 1024, 0));
+        };
+        auto transform = [&](int rb) __attribute__((always_inline)) {
+            const float *sa_ = s_raw + rb * WN_RAW_FLOATS + raw_a, *sb_ = s_raw + rb * WN_RAW_FLOATS + raw_b;
+            f32x4 e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 da = *reinterpret_cast<const f32x4 *>(sa_ + q * WN_RAW_STRIDE), db = *reinterpret_cast<const f32x4 *>(sb_ + q * WN_RAW_STRIDE);
+                e[q] = plus ? da + db : da - db;
+            }
+            auto store3 = [&](int j, const tnr_bf16x4 &h_, const tnr_bf16x4 &m_, const tnr_bf16x4 &l_) __attribute__((always_inline)) {
+                float *d = s_vh + v_dst0 + j * XL_STRIDE;
+                *reinterpret_cast<tnr_f32x2 *>(d) = __builtin_bit_cast(tnr_f32x2, h_);
+                *reinterpret_cast<tnr_f32x2 *>(d + 8) = __builtin_bit_cast(tnr_f32x2, m_);
+                *reinterpret_cast<tnr_f32x2 *>(d + 16) = __builtin_bit_cast(tnr_f32x2, l_);
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = j == 0 ? e[0] - e[2] : (j == 1 ? e[1] + e[2] : (j == 2 ? e[2] - e[1] : e[1] - e[3]));
+                tnr_bf16x4 hh, mm;
+                f32x4 r1, r2;
+                tnr_pk_level(v, hh, r1);
+                tnr_pk_level(r1, mm, r2);
+                const tnr_f32x2 a0 = {r2[0], r2[1]}, a1 = {r2[2], r2[3]};
+                const tnr_bf16x4 ll = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a0, tnr_bf16x2)),
+                                                                             __builtin_bit_cast(float, __builtin_convertvector(a1, tnr_bf16x2))});
+                store3(j, hh, mm, ll);
+            }
+        };
+        auto multiply = [&]() __attribute__((always_inline)) {
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
+            tnr_bf16x8 fa[2][3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) fa[0][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_vh + a_src0 + 8 * sp);
+            wn_static_for<0, 4>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value, jj = u >> 1, m = u & 1;
+                if constexpr (u + 1 < 4) {
+                    constexpr int j1 = (u + 1) >> 1, m1 = (u + 1) & 1;
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+                        fa[(u + 1) & 1][sp] = *reinterpret_cast<const tnr_bf16x8 *>(s_vh + a_src0 + j1 * XL_STRIDE + m1 * 32 * WN_ROW + 8 * sp);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+                    acc[jj][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[u & 1][TA[p]], fbr[jj][TB[p]], acc[jj][m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        __syncthreads();
+        raw_load(0, true);
+        raw_store(0);
+        raw_load(16, c.nck > 1);
+        if (c.nck > 1) raw_store(1);
+        __syncthreads();
+        if (wh == 1) __syncthreads();
+#pragma unroll 1
+        for (int ck = 0; ck < c.nck; ++ck) {
+            if (ck >= 1 && ck + 1 < c.nck) raw_store((ck + 1) & 1);
+            transform(ck & 1);
+            b_fetch(ck);
+            __syncthreads();
+            raw_load(16 * (ck + 2), ck + 2 < c.nck);
+            multiply();
+            __syncthreads();
+        }
+        if (wh == 0) __syncthreads();
+
+        // ---- inverse transform.  Column step over this wave's two columns: l = 0: (M0 + M1) + M2, l = 1: (M1 - M2) - M3
+        //   jp = 0 holds M0, M1: P[0] = M0 + M1, P[1] = M1;   jp = 1 holds M2, M3: P[0] = M2, P[1] = -M2 - M3   ->   R[l] = P0[l] + P1[l]
+        // (the same order of additions as the eight-wave form: (M0 + M1) + M2 and (M1 - M2) - M3 = M1 + (-M2 - M3) differs in the last bit
+        //  -- the probe's results are compared with a tolerance, not bit for bit)
+        f32x16 pr_[2][2];               // [l][m]
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (wjp == 0) {
+                pr_[0][m] = acc[0][m] + acc[1][m];
+                pr_[1][m] = acc[1][m];
+            } else {
+                pr_[0][m] = acc[0][m];
+                pr_[1][m] = -acc[0][m] - acc[1][m];
+            }
+        }
+        // step A: jp = 1 waves hand their partials to their jp = 0 partner (same h, il, nt: wave ^ 8); slot = [role & 3][h][l][m][r][lane]
+        float *xa = smem + (((wave & 3) | (wh << 2)) * 4) * (16 * 64);
+        if (wjp == 1) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xa[((l * 2 + m) * 16 + r) * 64 + lane] = pr_[l][m][r];
+        }
+        __syncthreads();
+        if (wjp == 0) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pr_[l][m][r] = l == 0 ? pr_[l][m][r] + xa[((l * 2 + m) * 16 + r) * 64 + lane]
+                                                                       : pr_[l][m][r] + xa[((l * 2 + m) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+        // step B: the jp = 0 waves now hold R[i][l][m] of their (i, nt): written to slot [i][nt] = the eight-wave form's layout
+        float *xb = smem + ((wh * 4 + wn * 2 + wil) * 4) * (16 * 64);
+        if (wjp == 0) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xb[((l * 2 + m) * 16 + r) * 64 + lane] = pr_[l][m][r];
+        }
+        __syncthreads();
+        // every wave finishes ONE (output row k, column l, M-tile m) of its N-tile: k = il, m = h, l = jp
+        f32x16 keep[1][1];
+        {
+            const int k = wil, m = wh, l = wjp;
+            auto slot = [&](int ip) __attribute__((always_inline)) {
+                return smem + (((ip >> 1) * 4 + wn * 2 + (ip & 1)) * 4 + l * 2 + m) * (16 * 64) + lane;
+            };
+            const float *p0 = slot(k), *p1 = slot(k + 1), *p2 = slot(k + 2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x0 = p0[r * 64], x1 = p1[r * 64], x2 = p2[r * 64];
+                keep[0][0][r] = k == 0 ? (x0 + x1) + x2 : (x0 - x1) - x2;
+            }
+        }
+        conv_epilogue_dpp_map<TNR_CONV_3x3, WN_T, 1, 1, false, 1>(a, keep, cb * 2 + wn, n, ty0, tx0, 0, li, half, y_rs,
+                                                                  [&](int, int row, int &rr, int &cc) __attribute__((always_inline)) {
+                                                                      const int p = 32 * wh + row;
+                                                                      rr = 2 * (p >> 3) + wil;
+                                                                      cc = 2 * (p & 7) + wjp;
+                                                                  });
+    }
+}
+
 bool wino_ok(const tnr_conv_desc *d) {
     return d->mode == TNR_CONV_3x3 && d->mma == TNR_MMA_BF16X3 && (d->pad_mode == 0 || (d->pad_mode == 1 && d->H >= 2 && d->W >= 2)) &&
            (d->Cout % 64) == 0 && d->KoutP == d->Cout && d->Cin == d->KinP && (d->Cin % 16) == 0 && d->Cin >= 32 && d->Ho == d->H &&
@@ -528,6 +765,7 @@ int tnr_launch_conv3x3_wino(const tnr_conv_desc *d, void *stream) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WN_LDS_BYTES) != hipSuccess ||
             cus < 1) {
             cus = 0;
             tnr_set_error("conv3x3_wino: cannot set up the kernel");
@@ -558,6 +796,11 @@ int tnr_launch_conv3x3_wino(const tnr_conv_desc *d, void *stream) {
     c.tiles = (int)tiles;
     k.tiles_x = c.tiles_x; k.tiles_y = c.tiles_y; k.ncb = c.ncb;
     const int grid = c.tiles < cus ? c.tiles : cus;
+    static const bool w16 = [] { const char *e = getenv("TNR_WINO_WAVES"); return e != nullptr && atoi(e) == 16; }();
+    if (w16) {
+        hipLaunchKernelGGL(conv3x3_wino16_kernel, dim3((unsigned)grid), dim3(1024), WN_LDS_BYTES, (hipStream_t)stream, c);
+        return tnr_check_launch("conv3x3_wino16");
+    }
     hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)grid), dim3(512), WN_LDS_BYTES, (hipStream_t)stream, c);
     return tnr_check_launch("conv3x3_wino");
 }
