@@ -100,7 +100,7 @@ def one(which, reps=10):
                 print("   %-28s %10.0f cycles per workgroup and launch   %8.0f per chunk" % (nm, o[k] / n, o[k] / max(o[7], 1)))
             ch = float(max(o[7], 1))      # stamps 8 .. 12 are SUMS of absolute times: differences of sums = summed intervals
             print("   inside the transform, per chunk: store raw + request weights %.0f | raw LDS reads landed %.0f | row step %.0f | first 4 positions split + stored %.0f | last 4 %.0f"
-                  % ((o[8] - (o[12] - o[0] - 0)) / ch if False else 0, (o[9] - o[8]) / ch, (o[10] - o[9]) / ch, (o[11] - o[10]) / ch, (o[12] - o[11]) / ch))
+                  % ((o[8] - o[13]) / ch, (o[9] - o[8]) / ch, (o[10] - o[9]) / ch, (o[11] - o[10]) / ch, (o[12] - o[11]) / ch))
 
 
 def main():

@@ -393,13 +393,16 @@ __global__ void __launch_bounds__(512, 2) conv3x3_wino_kernel(const WinoK c) {
             WN_T(t0);
 #ifndef WN_X_NORAW
             if (ck >= 1 && ck + 1 < c.nck) raw_store((ck + 1) & 1);      // (at the END of the phase instead: 8 % slower, profiles/r09l_wino_raw_store_late.txt)
+            // (the in-kernel timeline shows ~1.6 k cycles at this point, profiles/r10j_wino_timeline_transform_top.txt; requesting the patch two
+            //  phases ahead instead of one -- at this place, held through the transform -- made the kernel 3-6 % SLOWER, profiles/r10k: the
+            //  cycles are not load latency)
 #endif
 #if !defined(WN_X_NOB) && defined(WN_B_EARLY)
             b_fetch(ck, std::integral_constant<int, 0>{});
 #elif defined(WN_X_NOB)
             if (ck == 0) { b_fetch(0, std::integral_constant<int, 0>{}); b_fetch(0, std::integral_constant<int, 2>{}); }
 #endif
-            { WN_T(ts); WN_ADD(8, ts); }
+            { WN_T(ts); WN_ADD(8, ts); WN_ADD(13, t0); }
 #ifndef WN_X_NOT
             transform(ck & 1);
 #endif
