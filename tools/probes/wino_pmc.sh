@@ -1,3 +1,6 @@
+#!/bin/bash
+# rocprofv3 --pmc passes (SQ issue / wait / LDS / MFMA counters, three passes of 8 slots) over ten launches of conv5's shape in the Winograd kernel and in the
+# direct weight-stream kernel: gpurun -- 'bash tools/probes/wino_pmc.sh'  ->  gpurun_out/r09f_pmc_{wino,d4}.csv  (profiles/r09f_pmc_wino.csv)
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo; O=$R/gpurun_out
 for W in wino d4; do
