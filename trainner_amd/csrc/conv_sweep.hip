@@ -717,6 +717,9 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
         // (tnr_split4_bf16x3's arithmetic)
         tnr_bf16x4 ih, im, il;
         f32x4 ir;
+#ifndef S4_PK_SPLIT
+#define S4_PK_SPLIT 1
+#endif
         auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {
             constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
 #ifdef S4_ABL_NOSPLIT       /* (ablation build, results invalid: the upper bound of what PRE-SPLIT block buffers could save -- no operand split in the stager, the three LDS stores stay) */
@@ -724,7 +727,7 @@ __global__ void __launch_bounds__(256, 1) conv_sweep4_kernel(const SweepK c) {
                 float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
                 *reinterpret_cast<tnr_f32x2 *>(dst) = tnr_f32x2{rin[it][k - 2], rin[it][3]};
             }
-#elif defined(S4_PK_SPLIT)  /* the same split with ONE packed conversion per channel pair and level (tnr_split4_bf16x3_pk's form, conv_body.h): 22 instead of 30 vector instructions per item, bit-identical */
+#elif S4_PK_SPLIT           /* the same split with ONE packed conversion per channel pair and level (tnr_split4_bf16x3_pk's form, conv_body.h): 22 instead of 30 vector instructions per item, bit-identical; -0.3 % forward / -0.8 % gradient launch (profiles/r09o_sweep_upper_bounds.txt) */
             if constexpr (k == 0) {
                 tnr_pk_level(rin[it], ih, ir);
             } else if constexpr (k == 1) {
@@ -1102,13 +1105,16 @@ __global__ void __launch_bounds__(256, OCC) conv3x3_d4_kernel(const D4K c) {
         auto item_step_buf = [&](auto ic, auto kc, int buf) __attribute__((always_inline)) {      // (conv_sweep4_kernel: five steps per item)
             constexpr int it = decltype(ic)::value, k = decltype(kc)::value;
             if constexpr (k == 0) {
-                ih = __builtin_convertvector(rin[it], tnr_bf16x4);
-                ir = rin[it] - __builtin_convertvector(ih, f32x4);
+                tnr_pk_level(rin[it], ih, ir);           // (the packed-conversion form of the split: conv_sweep4_kernel's stager, bit-identical)
             } else if constexpr (k == 1) {
-                im = __builtin_convertvector(ir, tnr_bf16x4);
-                ir = ir - __builtin_convertvector(im, f32x4);
+                const f32x4 r1 = ir;
+                tnr_pk_level(r1, im, ir);
             } else {
-                if constexpr (k == 2) il = __builtin_convertvector(ir, tnr_bf16x4);
+                if constexpr (k == 2) {
+                    const tnr_f32x2 a2 = {ir[0], ir[1]}, b2 = {ir[2], ir[3]};
+                    il = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a2, tnr_bf16x2)),
+                                                                __builtin_bit_cast(float, __builtin_convertvector(b2, tnr_bf16x2))});
+                }
                 float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
                 *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
             }
@@ -1364,13 +1370,16 @@ __global__ void __launch_bounds__(256, 2) conv_s2_d4_kernel(const S2K c) {
                     const tnr_bf16x4 hh = __builtin_convertvector(rin[it], tnr_bf16x4);
                     *reinterpret_cast<tnr_f32x2 *>(s_a + buf * SW_A_FLOATS + a_dst[it]) = __builtin_bit_cast(tnr_f32x2, hh);
                 } else if constexpr (k == 0) {
-                    ih = __builtin_convertvector(rin[it], tnr_bf16x4);
-                    ir = rin[it] - __builtin_convertvector(ih, f32x4);
+                    tnr_pk_level(rin[it], ih, ir);       // (the packed-conversion form of the split, bit-identical)
                 } else if constexpr (k == 1) {
-                    im = __builtin_convertvector(ir, tnr_bf16x4);
-                    ir = ir - __builtin_convertvector(im, f32x4);
+                    const f32x4 r1 = ir;
+                    tnr_pk_level(r1, im, ir);
                 } else {
-                    if constexpr (k == 2) il = __builtin_convertvector(ir, tnr_bf16x4);
+                    if constexpr (k == 2) {
+                        const tnr_f32x2 a2 = {ir[0], ir[1]}, b2 = {ir[2], ir[3]};
+                        il = __builtin_bit_cast(tnr_bf16x4, tnr_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a2, tnr_bf16x2)),
+                                                                    __builtin_bit_cast(float, __builtin_convertvector(b2, tnr_bf16x2))});
+                    }
                     float *dst = s_a + buf * SW_A_FLOATS + a_dst[it] + 8 * (k - 2);
                     *reinterpret_cast<tnr_f32x2 *>(dst) = __builtin_bit_cast(tnr_f32x2, k == 2 ? ih : (k == 3 ? im : il));
                 }

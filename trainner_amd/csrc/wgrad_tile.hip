@@ -60,6 +60,21 @@ typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
 typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
 typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg_bf16x2 __attribute__((ext_vector_type(2)));
+// one level of the operand split for four channels with ONE v_cvt_pk_bf16_f32 per channel pair: the packed pair-of-pairs and the residual
+// x - float(pk) (conv_body.h's tnr_pk_level; __builtin_convertvector over four channels compiles to six conversions per level)
+__device__ __forceinline__ void wg_pk_level(const f32x4 x, wg_bf16x4 &pk, f32x4 &res) {
+    const wg_f32x2 a = {x[0], x[1]}, b = {x[2], x[3]};
+    const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(a, wg_bf16x2));
+    const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(b, wg_bf16x2));
+    pk = __builtin_bit_cast(wg_bf16x4, wg_f32x2{__builtin_bit_cast(float, p0), __builtin_bit_cast(float, p1)});
+    const f32x4 back = {__builtin_bit_cast(float, p0 << 16), __builtin_bit_cast(float, p0 & 0xffff0000u),
+                        __builtin_bit_cast(float, p1 << 16), __builtin_bit_cast(float, p1 & 0xffff0000u)};
+    res = x - back;
+}
+#ifndef WG_PK_SPLIT
+#define WG_PK_SPLIT 1       /* 0: the split through __builtin_convertvector (30 instead of 22 vector instructions per item; bit-identical) */
+#endif
 typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
 
 // ---- TNR_MMA_BF16X3: the LDS image is PRE-SPLIT -- three bf16 planes (hi, mid, lo) written once by the stager -- and pixel-major,
@@ -420,13 +435,30 @@ wgrad_tile_kernel(const WgK ga) {
         auto item_step = [&](auto kc, auto sc, char *set) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value, st = decltype(sc)::value;
             if constexpr (st == 0) {
+#if WG_PK_SPLIT
+                wg_pk_level(rr[k], ih, ir);
+#else
                 ih = __builtin_convertvector(rr[k], wg_bf16x4);
                 ir = rr[k] - __builtin_convertvector(ih, f32x4);
+#endif
             } else if constexpr (st == 1) {
+#if WG_PK_SPLIT
+                const f32x4 r1 = ir;
+                wg_pk_level(r1, im, ir);
+#else
                 im = __builtin_convertvector(ir, wg_bf16x4);
                 ir = ir - __builtin_convertvector(im, f32x4);
+#endif
             } else {
+#if WG_PK_SPLIT
+                if constexpr (st == 2) {
+                    const wg_f32x2 a = {ir[0], ir[1]}, b = {ir[2], ir[3]};
+                    il = __builtin_bit_cast(wg_bf16x4, wg_f32x2{__builtin_bit_cast(float, __builtin_convertvector(a, wg_bf16x2)),
+                                                                __builtin_bit_cast(float, __builtin_convertvector(b, wg_bf16x2))});
+                }
+#else
                 if constexpr (st == 2) il = __builtin_convertvector(ir, wg_bf16x4);
+#endif
                 *reinterpret_cast<wg_f32x2 *>(set + it_dst[k] + 256 * (st - 2)) = __builtin_bit_cast(wg_f32x2, st == 2 ? ih : (st == 3 ? im : il));
             }
         };
