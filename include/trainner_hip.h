@@ -42,9 +42,12 @@ enum {
     TNR_DGRAD_4x4_S2 = 3,  /* data-gradient of k4 s2 p1 (aten convolution_backward), parity-decomposed    */
     TNR_CONV_1x1 = 4,      /* k1 s1: the GEMM behind tnr_im2col for the small-spatial layers of the       */
                            /* discriminator tail (discriminators.py:24-36 at 16x16 and below)             */
-    TNR_CONV_3x3_C4 = 5    /* k3 s1 p1 over a <= 4-channel NHWC4 image (VGG conv1_1, D conv0, and the     */
+    TNR_CONV_3x3_C4 = 5,   /* k3 s1 p1 over a <= 4-channel NHWC4 image (VGG conv1_1, D conv0, and the     */
                            /* data-gradient of G's last conv): the 9 taps are folded into K = 36 -> 48    */
                            /* inside the stager instead of padding 3 channels to 16 per tap               */
+    TNR_CONV_7x7_C4 = 6    /* k7 s1 p3 over a <= 4-channel NHWC4 image (ResnetGenerator's first layer,    */
+                           /* ResNet_arch.py:52-55, and the data-gradient of its last, :86-88): the 49    */
+                           /* taps folded into K = 196 -> 208; pad_mode 1 = ReflectionPad2d(3)            */
 };
 
 /* weight packings produced by tnr_pack_weights */
@@ -58,6 +61,7 @@ enum {
                             /* (any square k: the stride-1 data-gradient as im2col(g, pad k-1-p) x this)   */
     TNR_PACK_C4_FWD = 6,    /* [1][KoutP][48]: column 4*t + ci (Cin <= 4)        for TNR_CONV_3x3_C4             */
     TNR_PACK_C4_DGRAD3 = 7  /* [1][KoutP=ci][48]: column 4*t + co (Cout <= 4), taps flipped                     */
+                            /* (both also with kh = kw = 7: [..][208] for TNR_CONV_7x7_C4)                     */
 };
 
 #define TNR_MMA_F32 0
@@ -271,6 +275,16 @@ int64_t tnr_conv_thin_pack_floats(int32_t reduce_channels);
 int tnr_conv_thin_pack(const float *w_oihw, float *wp, int32_t Cout, int32_t Cin, int32_t dgrad, void *stream);
 int tnr_conv_thin(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *wp, tnr_view y, int32_t Cout,
                   const float *bias, float alpha, void *stream);
+/* The same for the 7x7 image-side layers of ResnetGenerator (ResNet_arch.py:52-55, :86-88), one launch for the 49 taps:
+ *   y[n, oy, ox, c] = (sum_{t, ci} w[t][ci][c] * x[n, oy + ty - pad, ox + tx - pad, ci] + bias[c]) * alpha   (c < Cout <= 4)
+ * over an Ho x Wo output grid; reflect = 1: ReflectionPad2d(pad) borders (pad <= 3, Ho x Wo = H x W), reflect = 0: zeros outside
+ * the H x W input -- with pad = 6 and Ho x Wo = (H + 6) x (W + 6) that is the data-gradient of a 7x7 layer with respect to its
+ * reflection-padded input (fold it back with tnr_unpad2d).  Weights: tnr_conv_thin7_pack (dgrad as in tnr_conv_thin_pack) into
+ * tnr_conv_thin7_pack_floats(reduction channels) floats.                                                     */
+int64_t tnr_conv_thin7_pack_floats(int32_t reduce_channels);
+int tnr_conv_thin7_pack(const float *w_oihw, float *wp, int32_t Cout, int32_t Cin, int32_t dgrad, void *stream);
+int tnr_conv_thin7(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *wp, tnr_view y, int32_t Ho, int32_t Wo,
+                   int32_t Cout, int32_t pad, int32_t reflect, const float *bias, float alpha, void *stream);
 int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 /* Weight (+ bias) gradient of a 3x3 s1 p1 layer with <= 3 channels on one side, on the vector ALUs:
  * flip = 0: a Csmall -> Cbig layer (big = gradient of its output, small = its NHWC4 input image),
@@ -281,6 +295,18 @@ int64_t tnr_wgrad_workspace_bytes(const tnr_wgrad_desc *d);
 int64_t tnr_wgrad_thin_workspace_bytes(int32_t N, int32_t H, int32_t Cbig);
 int tnr_wgrad_thin(tnr_view big, tnr_view small, int32_t N, int32_t H, int32_t W, int32_t Cbig, int32_t Csmall, int32_t flip,
                    float *dw, float *db, float alpha, float beta, float *ws, int64_t ws_bytes, void *stream);
+/* The same for a 7x7 layer, one launch for the 49 taps (+ one reduce launch):
+ *   acc[cb][cs][ty][tx] = sum over the big grid q of big(q)[cb] * small[q + (ty, tx) + off][cs]      (small: zeros outside Hs x Ws)
+ * big grid = (H + 2 rpad) x (W + 2 rpad), big(q) = the H x W buffer at the ReflectionPad2d(rpad) image of q (rpad = 0: the buffer).
+ * flip = 0: dw[cb][cs][t] = acc[..][t]       -- an image -> Cbig layer: big = gradient of its output, small = its reflection-padded
+ *           NHWC4 input image ((H + 6) x (W + 6)), off = 0; db[cb] = sum of big (may be NULL);
+ * flip = 1: dw[cs][cb][t] = acc[..][48 - t]  -- a Cbig -> image layer: big = its input read through ReflectionPad2d(3) (rpad = 3),
+ *           small = the NHWC4 gradient of its output (H x W), off = -6; db must be NULL (sum the 4-channel gradient elsewhere).
+ * dw = beta*dw + alpha*acc.  Cbig in {16, 32, 64}, Csmall <= 3.  Deterministic.                               */
+int64_t tnr_wgrad_thin7_workspace_bytes(int32_t N, int32_t Hbig_grid, int32_t Cbig);
+int tnr_wgrad_thin7(tnr_view big, int32_t N, int32_t H, int32_t W, int32_t rpad, tnr_view small, int32_t Hs, int32_t Ws, int32_t off,
+                    int32_t Cbig, int32_t Csmall, int32_t flip, float *dw, float *db, float alpha, float beta, float *ws, int64_t ws_bytes,
+                    void *stream);
 int tnr_conv_wgrad(const tnr_wgrad_desc *d, void *stream);
 /* n <= TNR_WGRAD_GROUP_MAX layers in ONE launch (+ one reduce launch).  The layers must share mode and
  * N/H/W/Ho/Wo and fall into the same workgroup tile class (same Cout <= 32 | > 32 and the same number of

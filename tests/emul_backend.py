@@ -101,11 +101,12 @@ def conv(x, wp, y, mode=ops.CONV_3x3, bias=None, act=ops.ACT_NONE, slope=0.2, al
         xi = _fit(xin, w.shape[1])
         if mode == ops.CONV_3x3_UP2:
             xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
-        out = F.conv2d(F.pad(xi, (1, 1, 1, 1), mode="reflect"), w, None) if reflect else F.conv2d(xi, w, None, padding=1)
+        kp = w.shape[-1] // 2           # (3x3: 1; the 7x7 image layers of TNR_CONV_7x7_C4: 3)
+        out = F.conv2d(F.pad(xi, (kp, kp, kp, kp), mode="reflect"), w, None) if reflect else F.conv2d(xi, w, None, padding=kp)
     elif wp.kind == ops.PACK_FWD_S2D:
         out = F.conv2d(_fit(xin, w.shape[1]), w, None, stride=2, padding=1)
     elif wp.kind in (ops.PACK_DGRAD_3x3, ops.PACK_C4_DGRAD3):
-        out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, padding=1)
+        out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, padding=w.shape[-1] // 2)
     else:
         out = F.conv_transpose2d(_fit(xin, w.shape[0]), w, None, stride=2, padding=1)
     _epilogue(out, y, bias, act, slope, alpha, r1, r1_ch, beta1, r2, alpha2, mask, m_lo, m_hi, m_slope, noise)
@@ -185,6 +186,37 @@ def wgrad_thin(big, small4, dw, db, flip, alpha=1.0, beta=1.0):
     with torch.enable_grad():
         w0 = torch.zeros(O, I, 3, 3, requires_grad=True)
         (gw,) = torch.autograd.grad(F.conv2d(xin, w0, None, padding=1), w0, gin)
+    dw.copy_(beta * dw + alpha * gw)
+    if db is not None:
+        db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
+
+
+def conv_thin7(x, w, y, pad=3, reflect=True, bias=None, alpha=1.0, dgrad=False):
+    xin, wt = _nchw(x), w.detach()
+    if dgrad:       # out[q] = sum_t W^T[t] x[q + (6 - t) - pad]: the full correlation for pad = 6
+        out = F.conv_transpose2d(_fit(xin, wt.shape[0]), wt, None, padding=6 - pad)
+    else:
+        xi = _fit(xin, wt.shape[1])
+        out = F.conv2d(F.pad(xi, (pad,) * 4, mode="reflect"), wt, None) if reflect else F.conv2d(xi, wt, None, padding=pad)
+    assert out.shape[2] == y.H and out.shape[3] == y.W, (out.shape, y.H, y.W)
+    if bias is not None:
+        out = out + bias.detach().view(1, -1, 1, 1)
+    ops.View(y.buf, y.coff, out.shape[1]).dense().copy_((out * alpha).permute(0, 2, 3, 1))
+
+
+def wgrad_thin7(big, small4, dw, db, flip, rpad=0, off=0, alpha=1.0, beta=1.0):
+    """flip False: layer image -> big over the reflection-padded image small4;  flip True: layer big -> image, big read through
+    ReflectionPad2d(rpad), small4 = gradient of the output."""
+    O, I = dw.shape[0], dw.shape[1]
+    if flip:
+        assert rpad == 3 and off == -6 and db is None
+        xin, gin = F.pad(_nchw(big)[:, :I], (3, 3, 3, 3), mode="reflect"), _nchw(small4)[:, :O]
+    else:
+        assert rpad == 0 and off == 0
+        xin, gin = _nchw(small4)[:, :I], _nchw(big)[:, :O]
+    with torch.enable_grad():
+        w0 = torch.zeros(O, I, 7, 7, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(xin, w0, None), w0, gin)
     dw.copy_(beta * dw + alpha * gw)
     if db is not None:
         db.copy_(beta * db + alpha * gin.sum(dim=(0, 2, 3)))
@@ -524,7 +556,7 @@ def wgrad_group(items, mode=ops.CONV_3x3):
             wgrad(it["x"], it["g"], it["dw"], it.get("db"), **kw)
 
 
-_NAMES = ["gauss_mult", "bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
+_NAMES = ["gauss_mult", "bn_replay_running", "instnorm_fwd", "instnorm_bwd", "conv_col", "window2d", "conv_thin", "wgrad_thin", "conv_thin7", "wgrad_thin7", "bias_grad", "gconv_fwd", "gconv_dgrad", "gconv_wgrad", "pad2d", "unpad2d", "tanh_fwd", "tanh_bwd", "gan_loss", "bilinear2x_fwd", "bilinear2x_bwd", "add2", "mask_copy", "conv", "conv_chain", "wgrad", "wgrad_group", "nchw_to_nhwc", "nhwc_to_nchw", "upsample2x_bwd", "depth_to_space", "space_to_depth_bwd",
           "maxpool2_fwd", "maxpool2_bwd", "axpby", "mask_mul", "fill", "bn_train_fwd", "bn_train_bwd", "linear_fwd",
           "linear_bwd", "l1_mean_fwd", "l1_mean_bwd", "ragan_phase_a", "ragan_phase_b", "ragan_phase_c", "scale_by",
           "sumsq", "clip_by_norm", "adam_step"]

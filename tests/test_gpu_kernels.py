@@ -855,6 +855,90 @@ def test_wgrad_thin_image_layers(shape):
     close(db2.cpu(), img.sum(dim=(0, 2, 3)), tol=5e-5, what="thin wgrad C->3 bias")
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 64, 96, 32), (3, 9, 16, 16)])
+def test_conv7x7_image_channels_c4(shape):
+    """TNR_CONV_7x7_C4 (ResnetGenerator's image-side layers, ResNet_arch.py:52-55 / :86-88, 49 taps folded into K = 196 -> 208):
+    ReflectionPad2d(3) + conv7x7(3 -> C) with bias, and the C <- 3 data-gradient of a conv7x7(C -> 3) taken with respect to its
+    reflection-padded input (zero-embedded gradient, zero borders), against torch."""
+    ops = _ops()
+    N, H, W, C = shape
+    x = rnd(N, 3, H, W, seed=151)
+    w = rnd(C, 3, 7, 7, seed=152, lo=-0.1, hi=0.1)
+    b = rnd(C, seed=153)
+    ref = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w, b)
+    x4 = nhwc_buf(F.pad(x, (0, 0, 0, 0, 0, 1)), fill=0.0)
+    wp, _ = pack(ops, w.to(DEV), ops.PACK_C4_FWD)
+    y = torch.full((N, H, W, C + 8), 5.0, device=DEV)
+    ops.conv(ops.View(x4), wp, ops.View(y, 4, C), mode=ops.CONV_7x7_C4, bias=b.to(DEV), reflect=True)
+    close(to_nchw(y, 4, C), ref, what="7x7 c4 forward (reflect)")
+    assert (y[..., :4] == 5.0).all() and (y[..., 4 + C:] == 5.0).all()
+    # data-gradient of a C -> 3 layer with respect to its padded input: g embedded at offset 3 in an (H + 6) x (W + 6) canvas
+    w2 = rnd(3, C, 7, 7, seed=154, lo=-0.1, hi=0.1)
+    xp = rnd(N, C, H + 6, W + 6, seed=155).requires_grad_(True)
+    g = rnd(N, 3, H, W, seed=156)
+    (gref,) = torch.autograd.grad(F.conv2d(xp, w2, None), xp, g)
+    gc = nhwc_buf(F.pad(F.pad(g, (0, 0, 0, 0, 0, 1)), (3, 3, 3, 3)), fill=0.0)
+    wp2, _ = pack(ops, w2.to(DEV), ops.PACK_C4_DGRAD3)
+    gx = torch.zeros((N, H + 6, W + 6, C), device=DEV)
+    ops.conv(ops.View(gc), wp2, ops.View(gx), mode=ops.CONV_7x7_C4)
+    close(to_nchw(gx, 0, C), gref, what="7x7 c4 dgrad (padded domain)")
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 33, 16, 16), (1, 64, 96, 32)])
+def test_conv_thin7_small_cout(shape):
+    """tnr_conv_thin7: ReflectionPad2d(3) + conv7x7(C -> 3) (bias, alpha) in one launch, and the 3 <- C data-gradient of a
+    conv7x7(3 -> C) with respect to its reflection-padded input (pad 6, zero borders, (H + 6) x (W + 6) output)."""
+    ops = _ops()
+    N, H, W, C = shape
+    x = rnd(N, C, H, W, seed=161)
+    w = rnd(3, C, 7, 7, seed=162, lo=-0.05, hi=0.05)
+    b = rnd(3, seed=163)
+    ref = 0.5 * F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w, b)
+    y = torch.full((N, H, W, 4), 9.0, device=DEV)
+    ops.conv_thin7(ops.View(nhwc_buf(x, ctot=C + 8, coff=4), 4, C), w.to(DEV), ops.View(y, 0, 3), pad=3, reflect=True, bias=b.to(DEV), alpha=0.5)
+    close(to_nchw(y, 0, 3), ref, what="thin7 forward")
+    assert (y[..., 3] == 9.0).all()
+    w2 = rnd(C, 3, 7, 7, seed=164, lo=-0.05, hi=0.05)
+    xp = rnd(N, 3, H + 6, W + 6, seed=165).requires_grad_(True)
+    g = rnd(N, C, H, W, seed=166)
+    (gref,) = torch.autograd.grad(F.conv2d(xp, w2, None), xp, g)
+    gx = torch.full((N, H + 6, W + 6, 4), 9.0, device=DEV)
+    ops.conv_thin7(ops.View(nhwc_buf(g)), w2.to(DEV), ops.View(gx), pad=6, reflect=False, dgrad=True)
+    close(to_nchw(gx, 0, 3), gref, what="thin7 dgrad")
+    assert (gx[..., 3] == 0.0).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 9, 330, 16), (3, 33, 16, 32)])
+def test_wgrad_thin7_image_layers(shape):
+    """tnr_wgrad_thin7 against autograd: ReflectionPad2d(3) + conv7x7 with the image on the input side (flip=0: over the padded NHWC4
+    image, with bias, alpha, beta) and on the output side (flip=1: the wide input read through the reflection map, no padded copy);
+    W = 330 exercises the 320-column passes.  Deterministic."""
+    ops = _ops()
+    N, H, W, C = shape
+    img = rnd(N, 3, H, W, seed=171)
+    imgp4 = nhwc_buf(F.pad(F.pad(img, (3, 3, 3, 3), mode="reflect"), (0, 0, 0, 0, 0, 1)), fill=0.0)
+    w = torch.zeros(C, 3, 7, 7, requires_grad=True)
+    g = rnd(N, C, H, W, seed=172)
+    (ref_w,) = torch.autograd.grad(F.conv2d(F.pad(img, (3, 3, 3, 3), mode="reflect"), w, None), w, g)
+    dw0, db0 = rnd(C, 3, 7, 7, seed=173), rnd(C, seed=174)
+    dw, db = dw0.to(DEV), db0.to(DEV)
+    gbuf = nhwc_buf(g, ctot=C + 8, coff=4)
+    ops.wgrad_thin7(ops.View(gbuf, 4, C), ops.View(imgp4), dw, db, flip=False, alpha=0.5, beta=1.0)
+    close(dw.cpu(), dw0 + 0.5 * ref_w, tol=5e-5, what="thin7 wgrad 3->C weights")
+    close(db.cpu(), db0 + 0.5 * g.sum(dim=(0, 2, 3)), tol=5e-5, what="thin7 wgrad 3->C bias")
+    again = dw0.to(DEV)
+    ops.wgrad_thin7(ops.View(gbuf, 4, C), ops.View(imgp4), again, db0.to(DEV), flip=False, alpha=0.5, beta=1.0)
+    assert torch.equal(again, dw)
+    # flip = 1: y = conv7(reflect_pad(x[C]); w[3,C,7,7]) with gradient = a 3-channel image
+    x = rnd(N, C, H, W, seed=175)
+    img4 = nhwc_buf(F.pad(img, (0, 0, 0, 0, 0, 1)), fill=0.0)
+    w2 = torch.zeros(3, C, 7, 7, requires_grad=True)
+    (ref_w2,) = torch.autograd.grad(F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), w2, None), w2, img)
+    dw2 = torch.zeros(3, C, 7, 7, device=DEV)
+    ops.wgrad_thin7(ops.View(nhwc_buf(x)), ops.View(img4), dw2, None, flip=True, rpad=3, off=-6, alpha=1.0, beta=0.0)
+    close(dw2.cpu(), ref_w2, tol=5e-5, what="thin7 wgrad C->3 weights")
+
+
 def test_conv_direct_splitk():
     """The direct 3x3 kernel with a split-K workspace (512 -> 512 channels at 16x16: 16 tiles for 512 slots)."""
     ops = _ops()

@@ -10,5 +10,6 @@ FAMILIES = {
     "conv_tile_dgrad4x4s2": ("conv_tile_kernel<3,", "conv_s2_d4_kernel<3,"),
     "conv_tile_1x1": ("conv_tile_kernel<4,",),
     "conv_tile_3x3_c4": ("conv_tile_kernel<5,",),
+    "conv_tile_7x7_c4": ("conv_tile_kernel<6,",),       # config 5: ResnetGenerator's 7x7 image-side layers, 49 taps in K
     "wgrad_tile": ("wgrad_tile_kernel",),
 }

@@ -185,7 +185,9 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
     constexpr bool S2D = (MODE == TNR_CONV_4x4_S2);
     constexpr bool DG2 = (MODE == TNR_DGRAD_4x4_S2);
     constexpr bool UP = (MODE == TNR_CONV_3x3_UP2);
-    constexpr bool IMG4 = (MODE == TNR_CONV_3x3_C4);     // 3x3 over a 4-channel image: the 9 taps become K (36 -> 48)
+    constexpr bool IMG7 = (MODE == TNR_CONV_7x7_C4);     // 7x7 over a 4-channel image: 49 taps become K (196 -> 208)
+    constexpr bool IMG4 = (MODE == TNR_CONV_3x3_C4) || IMG7;     // 3x3 over a 4-channel image: the 9 taps become K (36 -> 48)
+    constexpr int IKW = IMG7 ? 7 : 3, ITAPS = IKW * IKW, IPAD = IKW / 2;
     constexpr bool P11 = (MODE == TNR_CONV_1x1) || IMG4;  // no halo, a single "tap"
     constexpr int KH = S2D ? 2 : (P11 ? 1 : 3);
     constexpr int NTAPS = (S2D || DG2) ? 4 : (P11 ? 1 : 9);
@@ -333,8 +335,12 @@ __device__ __forceinline__ void conv_tile_body(const ConvK a, const int cb, cons
                 const int pix = tnr_stage_row(i);
                 const int hr = pix / WT, hc = pix - hr * WT;
                 const int t = chunk * 4 + q;
-                const int Y = ty0 + hr + t / 3 - 1, X = tx0 + hc + t % 3 - 1;
-                const bool ok = (pix < IN_ROWS) & (t < 9) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
+                int Y = ty0 + hr + t / IKW - IPAD, X = tx0 + hc + t % IKW - IPAD;
+                if (IMG7 && a.reflect) {       // ReflectionPad2d(3) in front of the layer (tiles hanging over the image: masked by the store)
+                    Y = Y < 0 ? -Y : (Y >= a.H ? 2 * a.H - 2 - Y : Y);
+                    X = X < 0 ? -X : (X >= a.W ? 2 * a.W - 2 - X : X);
+                }
+                const bool ok = (pix < IN_ROWS) & (t < ITAPS) & (Y >= 0) & (Y < a.H) & (X >= 0) & (X < a.W);
                 off = ok ? (((n * a.H + Y) * a.W + X) * a.x_ct + a.x_co - c0) : -1;   // (+ c0 below cancels: whole pixel)
             } else {
                 off = in_off[it];

@@ -158,9 +158,12 @@ int tnr_launch_conv_s2_d4(const tnr_conv_desc *d, void *stream);      // conv_sw
 
 extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d != nullptr && d->x.ptr && d->y.ptr && d->wp, "conv: null pointer");
-    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_3x3_C4, "conv: bad mode %d", d->mode);
+    TNR_REQUIRE(d->mode >= TNR_CONV_3x3 && d->mode <= TNR_CONV_7x7_C4, "conv: bad mode %d", d->mode);
     if (d->mode == TNR_CONV_3x3_C4)
         TNR_REQUIRE(d->x.ctot == 4 && d->x.coff == 0 && d->Cin == 4 && d->KinP == 48, "conv3x3_c4: needs an NHWC4 input view and a C4 packing");
+    if (d->mode == TNR_CONV_7x7_C4)
+        TNR_REQUIRE(d->x.ctot == 4 && d->x.coff == 0 && d->Cin == 4 && d->KinP == 208 && d->wq == nullptr && d->ws == nullptr && d->shuffle == 0,
+                    "conv7x7_c4: needs an NHWC4 input view and a 7x7 C4 packing (no weight stream, no split-K)");
     TNR_REQUIRE((d->x.ctot % 4) == 0 && (d->x.coff % 4) == 0 && (d->Cin % 4) == 0,
                 "conv: input view must be 4-channel aligned (ctot %d coff %d Cin %d)", d->x.ctot, d->x.coff, d->Cin);
     TNR_REQUIRE((d->KinP % TNR_CK) == 0 && (d->KoutP % 32) == 0, "conv: bad packed dims %d %d", d->KinP, d->KoutP);
@@ -191,7 +194,8 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
         case TNR_CONV_3x3:
         case TNR_CONV_1x1:
         case TNR_CONV_3x3_C4:
-            TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3 / conv1x1: output must match input size");
+        case TNR_CONV_7x7_C4:
+            TNR_REQUIRE(d->Ho == d->H && d->Wo == d->W, "conv3x3 / conv1x1 / conv7x7_c4: output must match input size");
             sh = d->Ho; sw = d->Wo;
             break;
         case TNR_CONV_3x3_UP2:
@@ -225,7 +229,8 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
     TNR_REQUIRE(d->mma >= TNR_MMA_F32 && d->mma <= TNR_MMA_BF16X3, "conv: bad mma %d", d->mma);
     k.bf = d->mma;
     k.reflect = d->pad_mode == 1;
-    TNR_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->mode == TNR_CONV_3x3 && d->H >= 2 && d->W >= 2), "conv: pad_mode 1 (reflection) is for TNR_CONV_3x3");
+    TNR_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->mode == TNR_CONV_3x3 && d->H >= 2 && d->W >= 2) ||
+                (d->pad_mode == 1 && d->mode == TNR_CONV_7x7_C4 && d->H >= 4 && d->W >= 4), "conv: pad_mode 1 (reflection) is for TNR_CONV_3x3 and TNR_CONV_7x7_C4");
     k.ksplit = 1;
     k.split_stride = 0;
     SplitRedK red;
@@ -280,6 +285,7 @@ extern "C" int tnr_conv_forward(const tnr_conv_desc *d, void *stream) {
             case TNR_CONV_4x4_S2: rc = dispatch_conv<TNR_CONV_4x4_S2>(k, tw, nt, (int)tiles, s); break;
             case TNR_CONV_1x1: rc = dispatch_conv<TNR_CONV_1x1>(k, tw, nt, (int)tiles, s); break;
             case TNR_CONV_3x3_C4: rc = dispatch_conv<TNR_CONV_3x3_C4>(k, tw, nt, (int)tiles, s); break;
+            case TNR_CONV_7x7_C4: rc = dispatch_conv<TNR_CONV_7x7_C4>(k, tw, nt, (int)tiles, s); break;
             default: rc = dispatch_conv<TNR_DGRAD_4x4_S2>(k, tw, nt, (int)tiles, s); break;
         }
     }

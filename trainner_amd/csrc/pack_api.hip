@@ -65,13 +65,13 @@ extern "C" int tnr_pack_dims(int32_t Cout, int32_t Cin, int32_t kh, int32_t kw, 
             n = (int64_t)ko * ki;
             break;
         case TNR_PACK_C4_FWD:
-            TNR_REQUIRE(kh == 3 && kw == 3 && Cin <= 4, "pack c4: 3x3 kernel with Cin <= 4");
-            ko = tnr_round_up(Cout, 32); ki = 48;
+            TNR_REQUIRE(kh == kw && (kh == 3 || kh == 7) && Cin <= 4, "pack c4: 3x3 or 7x7 kernel with Cin <= 4");
+            ko = tnr_round_up(Cout, 32); ki = tnr_round_up(4 * kh * kw, TNR_CK);      // 48 | 208
             n = (int64_t)ko * ki;
             break;
         case TNR_PACK_C4_DGRAD3:
-            TNR_REQUIRE(kh == 3 && kw == 3 && Cout <= 4, "pack c4 dgrad: 3x3 kernel with Cout <= 4");
-            ko = tnr_round_up(Cin, 32); ki = 48;
+            TNR_REQUIRE(kh == kw && (kh == 3 || kh == 7) && Cout <= 4, "pack c4 dgrad: 3x3 or 7x7 kernel with Cout <= 4");
+            ko = tnr_round_up(Cin, 32); ki = tnr_round_up(4 * kh * kw, TNR_CK);
             n = (int64_t)ko * ki;
             break;
         default:
@@ -125,12 +125,12 @@ __global__ void pack_weights_kernel(const tnr_pack_item *items) {
             const int v_ = (int)(e % ki);
             const int co = (int)(e / ki);
             const int t = v_ >> 2, ci = v_ & 3;
-            if (co < Cout && t < 9 && ci < Cin) v = it.w[((size_t)co * Cin + ci) * 9 + t];
+            if (co < Cout && t < kh * kw && ci < Cin) v = it.w[((size_t)co * Cin + ci) * kh * kw + t];
         } else if (it.kind == TNR_PACK_C4_DGRAD3) {    // [ci][4*t + co], taps flipped
             const int v_ = (int)(e % ki);
             const int ci = (int)(e / ki);
             const int t = v_ >> 2, co = v_ & 3;
-            if (ci < Cin && t < 9 && co < Cout) v = it.w[(((size_t)co * Cin + ci) * 3 + (2 - t / 3)) * 3 + (2 - t % 3)];
+            if (ci < Cin && t < kh * kw && co < Cout) v = it.w[(((size_t)co * Cin + ci) * kh + (kh - 1 - t / kw)) * kw + (kw - 1 - t % kw)];
         } else {  // TNR_PACK_DGRAD_S2: [par][t][ci][co]
             const int co = (int)(e % ki);
             int64_t q = e / ki;

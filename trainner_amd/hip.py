@@ -18,7 +18,7 @@ c_p = C.c_void_p
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 MMA_F32, MMA_BF16, MMA_BF16X3 = 0, 1, 2
-CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2, CONV_1x1, CONV_3x3_C4 = 0, 1, 2, 3, 4, 5
+CONV_3x3, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2, CONV_1x1, CONV_3x3_C4, CONV_7x7_C4 = 0, 1, 2, 3, 4, 5, 6
 PACK_FWD, PACK_DGRAD_3x3, PACK_FWD_S2D, PACK_DGRAD_S2, PACK_COL_FWD, PACK_COL_DGRAD3 = 0, 1, 2, 3, 4, 5
 PACK_C4_FWD, PACK_C4_DGRAD3 = 6, 7
 PACK_DENSE_DGRAD = 16      # host-side tag of tnr_pack_dense_dgrad slabs (consumed like PACK_FWD by conv_tile)
@@ -95,6 +95,11 @@ _SIGS = {
     "tnr_conv_thin_pack": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "tnr_conv_thin": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_p, c_f, c_p]),
     "tnr_wgrad_workspace_bytes": (c_l, [C.POINTER(WgradDesc)]),
+    "tnr_conv_thin7_pack_floats": (c_l, [c_i]),
+    "tnr_conv_thin7_pack": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "tnr_conv_thin7": (c_i, [CView, c_i, c_i, c_i, c_i, c_p, CView, c_i, c_i, c_i, c_i, c_i, c_p, c_f, c_p]),
+    "tnr_wgrad_thin7_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "tnr_wgrad_thin7": (c_i, [CView, c_i, c_i, c_i, c_i, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_l, c_p]),
     "tnr_wgrad_thin_workspace_bytes": (c_l, [c_i, c_i, c_i]),
     "tnr_wgrad_thin": (c_i, [CView, CView, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_f, c_p, c_l, c_p]),
     "tnr_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),

@@ -14,13 +14,16 @@ Kernel mapping (all fp32 NHWC):
   * stride-2 3x3 convolutions and the transposed convolutions: the 4x4 stride-2 MFMA kernels with the 3x3 taps zero-extended
     to 4x4 (3x3 s2 p1 == 4x4 s2 p1 with a zero fourth row / column; ConvTranspose2d(k3,s2,p1,op1) == the data-gradient of
     that convolution, its input gradient == the forward, its weight gradient == the weight gradient with roles swapped);
-  * the two 7x7 reflection-padded image-side convolutions: nine 3x3 blocks of taps (_K7Image) on the 3x3 kernels built for
-    <= 4-channel image layers -- the taps-in-K MFMA mode on the feature side, the vector-ALU thin kernels on the image side --
-    over shifted copies of the 4-channel operand (tnr_window2d); the generic kernels of csrc/gconv.hip are the fallback for
-    channel counts those kernels do not take;
+  * the two 7x7 reflection-padded image-side convolutions (_K7Image): ONE launch per pass -- the taps-in-K MFMA mode
+    (TNR_CONV_7x7_C4: 49 taps x 4 image channels = K 196 -> 208) towards the feature side, the vector-ALU kernels tnr_conv_thin7 /
+    tnr_wgrad_thin7 towards the image side, reflection applied where the operand is gathered (no padded copy of a wide tensor);
+    TNR_K7_FUSED=0 keeps the earlier form, nine 3x3 blocks of taps over shifted copies of the 4-channel operand (A/B switch);
+    the generic kernels of csrc/gconv.hip are the fallback for channel counts those kernels do not take;
   * normalisation: the BatchNorm-train kernels (InstanceNorm: one statistics group per image in the same launches:
     tnr_instnorm_*), ReLU fused; Tanh as one pass.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -90,6 +93,7 @@ class _Padded4x4:
         self.weight.grad.add_(self.dw4[:, :, :3, :3])
 
 
+K7_FUSED = os.environ.get("TNR_K7_FUSED", "1") != "0"      # the 7x7 image-side layers as one launch per pass (0: nine 3x3 blocks; A/B switch)
 _K7_BLOCKS = tuple((by, bx) for by in (0, 3, 4) for bx in (0, 3, 4))     # first tap of each 3x3 block; a block at 4 owns tap 6 only
 
 
@@ -110,6 +114,10 @@ class _K7Image:
         self.mod, self.packer, self.side = conv, packer, side        # side: "in" (image -> features) | "out" (features -> image)
         w = conv.weight
         O, I = w.shape[0], w.shape[1]
+        self.fused = K7_FUSED
+        if self.fused:      # the layer's own 7x7 weight in the taps-in-K packing (repacked with the other weights after every step)
+            self.i_k7 = packer.add(w, ops.PACK_C4_FWD if side == "in" else ops.PACK_C4_DGRAD3)
+            return
         self.ws = torch.zeros((9, O, I, 3, 3), dtype=torch.float32, device=w.device)
         self.dws = torch.zeros_like(self.ws)
         self.db = torch.zeros(O, dtype=torch.float32, device=w.device)
@@ -117,6 +125,8 @@ class _K7Image:
         self.i_mma = [packer.add(self.ws[b], kind) for b in range(9)]
 
     def refresh(self):
+        if self.fused:
+            return
         w = self.mod.weight.detach()
         self.ws.zero_()
         for b, (by, bx) in enumerate(_K7_BLOCKS):
@@ -134,6 +144,9 @@ class _K7Image:
     # ---- image -> features (first layer): x4 [N,H,W,4] -> z [N,H,W,O]
     def fwd_in(self, x4, z):
         N, H, W, dev = x4.N, x4.H, x4.W, x4.buf.device
+        if self.fused:
+            ops.conv(x4, self.packer.get(self.i_k7), z, mode=ops.CONV_7x7_C4, bias=self.mod.bias, reflect=True)
+            return x4                                                 # (the image itself: the weight gradient pads it again, 4 channels)
         xp = View(new_act(N, H + 6, W + 6, 4, dev))
         ops.pad2d(x4, xp, 3, True)
         acc = View(new_act(N, H + 2, W + 2, z.C, dev))
@@ -150,6 +163,17 @@ class _K7Image:
     def bwd_in(self, shifted, gz, want_w, gx4):
         """gz: gradient of this layer's output; gx4 (or None): [N,H,W,4] gradient of the image."""
         N, H, W, dev = gz.N, gz.H, gz.W, gz.buf.device
+        if self.fused:
+            if want_w:
+                xp = View(new_act(N, H + 6, W + 6, 4, dev))
+                ops.pad2d(shifted, xp, 3, True)                       # (shifted: the NHWC4 image fwd_in returned)
+                ops.wgrad_thin7(gz, xp, self.mod.weight.grad, self.mod.bias.grad if self.mod.bias is not None else None, flip=False)
+            if gx4 is None:
+                return
+            gxp = View(new_act(N, H + 6, W + 6, 4, dev))
+            ops.conv_thin7(gz, self.mod.weight, gxp, pad=6, reflect=False, dgrad=True)      # gx_p[q] = sum_t W^T[t] gz[q - t]
+            ops.unpad2d(gxp, gx4, 3, True)
+            return
         g1 = View(new_act(N, H + 2, W + 2, gz.C, dev))
         ops.pad2d(gz, g1, 1, False)                                   # g1[u] = gz[u - 1]
         if want_w:
@@ -168,6 +192,9 @@ class _K7Image:
     # ---- features -> image (last layer): x [N,H,W,I] -> o4 [N,H,W,4] (no bias: it joins the tanh pass)
     def fwd_out(self, x, o4):
         N, H, W, dev = x.N, x.H, x.W, x.buf.device
+        if self.fused:
+            ops.conv_thin7(x, self.mod.weight, o4, pad=3, reflect=True)
+            return x                                                  # (the un-padded input: the weight gradient reflects its reads)
         xp = View(new_act(N, H + 6, W + 6, x.C, dev))
         ops.pad2d(x, xp, 3, True)
         for b, (by, bx) in enumerate(_K7_BLOCKS):
@@ -179,6 +206,19 @@ class _K7Image:
     def bwd_out(self, xp, go4, want_w, gx):
         """go4: [N,H,W,4] gradient of the image-side output; gx: [N,H,W,I] gradient of the layer's input."""
         N, H, W, dev = go4.N, go4.H, go4.W, go4.buf.device
+        if self.fused:
+            if want_w:
+                ops.wgrad_thin7(xp, go4, self.mod.weight.grad, None, flip=True, rpad=3, off=-6)      # (xp: the layer's input as fwd_out returned it)
+                if self.mod.bias is not None:
+                    db4 = torch.zeros(4, dtype=torch.float32, device=dev)
+                    ops.bias_grad(go4, db4, beta=0.0)
+                    self.mod.bias.grad.add_(db4[:self.mod.bias.numel()])
+            gc = View(new_act(N, H + 6, W + 6, 4, dev))
+            ops.pad2d(go4, gc, 3, False)                              # gc[u] = g[u - 3]
+            gxp = View(new_act(N, H + 6, W + 6, gx.C, dev))
+            ops.conv(gc, self.packer.get(self.i_k7), gxp, mode=ops.CONV_7x7_C4)      # gx_p[q] = sum_t W^T[t] g[q - t]
+            ops.unpad2d(gxp, gx, 3, True)
+            return
         gxp = View(new_act(N, H + 6, W + 6, gx.C, dev))
         for b, (by, bx) in enumerate(_K7_BLOCKS):
             sm = View(new_act(N, H + 6, W + 6, 4, dev))

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import hip
-from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_1x1, CONV_3x3, CONV_3x3_C4, CONV_3x3_UP2, CONV_4x4_S2, DGRAD_4x4_S2,  # noqa: F401
+from .hip import (ACT_LRELU, ACT_NONE, ACT_RELU, CONV_1x1, CONV_3x3, CONV_3x3_C4, CONV_3x3_UP2, CONV_4x4_S2, CONV_7x7_C4, DGRAD_4x4_S2,  # noqa: F401
                   PACK_C4_DGRAD3, PACK_C4_FWD, PACK_COL_DGRAD3, PACK_COL_FWD, PACK_DENSE_DGRAD, PACK_DGRAD_3x3, PACK_DGRAD_S2, PACK_FWD, PACK_FWD_S2D, CView,
                   ConvDesc,
                   DensePackItem, PackItem, WgradDesc)
@@ -437,10 +437,10 @@ def conv(x, wp, y, mode=CONV_3x3, wino=None, **epi):
         return
     t0 = PROFILE.begin()
     hip.check(hip.load().tnr_conv_forward(C.byref(d), hip.stream()), "conv_forward")
-    taps = {CONV_3x3: 9, CONV_3x3_UP2: 9, CONV_1x1: 1, CONV_3x3_C4: 9}.get(mode, 16)
+    taps = {CONV_3x3: 9, CONV_3x3_UP2: 9, CONV_1x1: 1, CONV_3x3_C4: 9, CONV_7x7_C4: 49}.get(mode, 16)
     opix = y.pixels if mode != DGRAD_4x4_S2 else y.pixels // 4     # each input-grad pixel sees 4 of the 16 taps
     fam = {CONV_3x3: "conv_tile_3x3", CONV_3x3_UP2: "conv_tile_3x3_up2", CONV_4x4_S2: "conv_tile_4x4s2",
-           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1", CONV_3x3_C4: "conv_tile_3x3_c4"}[mode]
+           DGRAD_4x4_S2: "conv_tile_dgrad4x4s2", CONV_1x1: "conv_tile_1x1", CONV_3x3_C4: "conv_tile_3x3_c4", CONV_7x7_C4: "conv_tile_7x7_c4"}[mode]
     if d.wq_form == 1:
         fam = "conv_wino_3x3"          # (algorithmic FLOP of the convolution it computes: 9 taps)
     PROFILE.end(fam, 2.0 * opix * taps * min(x.C, wp.KinP) * y.C, t0, (x.C, y.C, y.H, wp.kind))
@@ -745,6 +745,37 @@ def conv_thin(x, w, y, bias=None, alpha=1.0, dgrad=False):
     hip.check(lib.tnr_conv_thin(x.c(), x.N, x.H, x.W, x.C, wp.data_ptr(), y.c(), y.C, hip.ptr(bias), alpha, hip.stream()), "conv_thin")
     if PROFILE is not None:
         PROFILE.end("conv_thin", 2.0 * y.pixels * 9 * x.C * y.C, t0, (x.C, y.C, y.H, int(dgrad)))
+
+
+def conv_thin7(x, w, y, pad=3, reflect=True, bias=None, alpha=1.0, dgrad=False):
+    """7x7 stride-1 convolution with <= 4 output channels in one launch (tnr_conv_thin7): y[p] = sum_t w[t] x[p + t - pad] over y's own
+    grid; reflect: ReflectionPad2d(pad) borders (y the size of x), else zeros outside x.  dgrad=True: the data-gradient of a layer with
+    <= 4 INPUT channels (x = gradient of its output; pad = 6 and a (H + 6) x (W + 6) y give the gradient of its reflection-padded input)."""
+    lib = hip.load()
+    Cout, Cin = w.shape[0], w.shape[1]
+    n = lib.tnr_conv_thin7_pack_floats(Cout if dgrad else Cin)
+    wp = WS.get("thin7_w@%x" % hip.stream(), n * 4, x.buf.device)
+    hip.check(lib.tnr_conv_thin7_pack(w.data_ptr(), wp.data_ptr(), Cout, Cin, int(dgrad), hip.stream()), "conv_thin7_pack")
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_conv_thin7(x.c(), x.N, x.H, x.W, x.C, wp.data_ptr(), y.c(), y.H, y.W, y.C, pad, int(reflect), hip.ptr(bias), alpha,
+                                 hip.stream()), "conv_thin7")
+    if PROFILE is not None:
+        PROFILE.end("conv_thin", 2.0 * y.pixels * 49 * x.C * y.C, t0, (x.C, y.C, y.H, 70 + int(dgrad)))
+
+
+def wgrad_thin7(big, small4, dw, db, flip, rpad=0, off=0, alpha=1.0, beta=1.0):
+    """Weight gradient of a 7x7 layer with <= 3 channels on one side in one launch (tnr_wgrad_thin7):
+    flip=False: an image -> C layer (big = gradient of its output, small4 = its reflection-padded NHWC4 input, off = 0);
+    flip=True: a C -> image layer (big = its input, read through ReflectionPad2d(rpad = 3); small4 = NHWC4 gradient of its output, off = -6)."""
+    lib = hip.load()
+    cs = dw.shape[0] if flip else dw.shape[1]
+    need = lib.tnr_wgrad_thin7_workspace_bytes(big.N, big.H + 2 * rpad, big.C)
+    ws = WS.get("wgrad_thin7@%x" % hip.stream(), need, big.buf.device)
+    t0 = PROFILE.begin() if PROFILE is not None else None
+    hip.check(lib.tnr_wgrad_thin7(big.c(), big.N, big.H, big.W, rpad, small4.c(), small4.H, small4.W, off, big.C, cs, int(flip),
+                                  dw.data_ptr(), hip.ptr(db), alpha, beta, ws.data_ptr(), ws.numel() * 8, hip.stream()), "wgrad_thin7")
+    if PROFILE is not None:
+        PROFILE.end("wgrad_thin", 2.0 * big.N * (big.H + 2 * rpad) * (big.W + 2 * rpad) * 49 * big.C * cs, t0, (big.C, cs, big.H, 70 + int(flip)))
 
 
 def small_gemm_ok(x, y, k, stride, epi):
