@@ -3,7 +3,8 @@ cases do not enumerate (TNR_MMA=bf16x3, one GPU):
   * Winograd form (csrc/conv_wino.hip) vs the direct kernels: max |d| <= 3e-6 of the scale, nothing outside the channel window touched;
   * four-tap weight-stream kernel (conv_s2_d4_kernel) vs conv_tile_kernel: bit for bit;
   * pixel-shuffle store (tnr_conv_desc.shuffle) vs conv + tnr_depth_to_space: bit for bit;
-  * the dense-block sweep (packed operand split in its stagers) vs one launch per layer: bit for bit, ragged tilings, both shapes.
+  * the dense-block sweep (packed operand split in its stagers) vs one launch per layer: bit for bit, ragged tilings, both shapes;
+  * config 5's one-launch 7x7 image-side kernels vs torch in fp64 (2e-5 of the scale).
     TNR_MMA=bf16x3 python tools/probes/fuzz_round6.py [cases] [seed]
 Prints one line per failing case and a summary; exit status 1 on any failure."""
 import os
@@ -97,6 +98,65 @@ def sweep_case(rng, k):
         same, float((gb - rb).abs().max()), float((go - ro).abs().max()))
 
 
+def k7_case(rng, k):
+    """Config 5's one-launch 7x7 image-side kernels (TNR_CONV_7x7_C4, tnr_conv_thin7, tnr_wgrad_thin7) against torch in fp64 on the CPU."""
+    import torch.nn.functional as F
+    N = rng.choice((1, 2, 3))
+    H, W = rng.randint(4, 40), rng.randint(4, 70)
+    C = rng.choice((16, 32, 64))
+    g = torch.Generator().manual_seed(5000 + k)
+    img = torch.rand(N, 3, H, W, generator=g, dtype=torch.float64) * 2 - 1
+    feat = torch.rand(N, C, H, W, generator=g, dtype=torch.float64) * 2 - 1
+    w_in = (torch.rand(C, 3, 7, 7, generator=g, dtype=torch.float64) - 0.5) * 0.2
+    w_out = (torch.rand(3, C, 7, 7, generator=g, dtype=torch.float64) - 0.5) * 0.1
+    refl = lambda t: F.pad(t, (3, 3, 3, 3), mode="reflect")
+    nhwc = lambda t, c=None: (F.pad(t, (0, 0, 0, 0, 0, (c or t.shape[1]) - t.shape[1])).permute(0, 2, 3, 1).contiguous().float().to(dev))
+    V = ops.View
+    which = rng.choice(("c4_fwd", "c4_dgrad", "thin_fwd", "thin_dgrad", "wg_in", "wg_out"))
+    if which == "c4_fwd":
+        ref = F.conv2d(refl(img), w_in)
+        p = ops.WeightPacker(dev)
+        i = p.add(w_in.float().to(dev), ops.PACK_C4_FWD)
+        p.run()
+        y = torch.zeros(N, H, W, C, device=dev)
+        ops.conv(V(nhwc(img, 4)), p.get(i), V(y), mode=ops.CONV_7x7_C4, reflect=True)
+        got = y.permute(0, 3, 1, 2)
+    elif which == "c4_dgrad":
+        xp = torch.zeros(N, C, H + 6, W + 6, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(xp, w_out), xp, img)
+        p = ops.WeightPacker(dev)
+        i = p.add(w_out.float().to(dev), ops.PACK_C4_DGRAD3)
+        p.run()
+        y = torch.zeros(N, H + 6, W + 6, C, device=dev)
+        ops.conv(V(nhwc(F.pad(img, (3, 3, 3, 3)), 4)), p.get(i), V(y), mode=ops.CONV_7x7_C4)
+        got = y.permute(0, 3, 1, 2)
+    elif which == "thin_fwd":
+        ref = F.conv2d(refl(feat), w_out)
+        y = torch.zeros(N, H, W, 4, device=dev)
+        ops.conv_thin7(V(nhwc(feat)), w_out.float().to(dev), V(y), pad=3, reflect=True)
+        got = y.permute(0, 3, 1, 2)[:, :3]
+    elif which == "thin_dgrad":
+        xp = torch.zeros(N, 3, H + 6, W + 6, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(xp, w_in), xp, feat)
+        y = torch.zeros(N, H + 6, W + 6, 4, device=dev)
+        ops.conv_thin7(V(nhwc(feat)), w_in.float().to(dev), V(y), pad=6, reflect=False, dgrad=True)
+        got = y.permute(0, 3, 1, 2)[:, :3]
+    elif which == "wg_in":
+        w0 = torch.zeros(C, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(refl(img), w0), w0, feat)
+        dw = torch.zeros(C, 3, 7, 7, device=dev)
+        ops.wgrad_thin7(V(nhwc(feat)), V(nhwc(refl(img), 4)), dw, None, flip=False, beta=0.0)
+        got = dw
+    else:
+        w0 = torch.zeros(3, C, 7, 7, dtype=torch.float64, requires_grad=True)
+        (ref,) = torch.autograd.grad(F.conv2d(refl(feat), w0), w0, img)
+        dw = torch.zeros(3, C, 7, 7, device=dev)
+        ops.wgrad_thin7(V(nhwc(feat)), V(nhwc(img, 4)), dw, None, flip=True, rpad=3, off=-6, beta=0.0)
+        got = dw
+    err = float((got.double().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    return ("k7", (which, N, H, W, C)), err <= 2e-5, "err/scale %.2e" % err
+
+
 def main():
     assert ops.MMA == hip.MMA_BF16X3
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
@@ -104,7 +164,7 @@ def main():
     bad = 0
     counts = {}
     for k in range(n):
-        fn = (wino_case, sweep_case, s2_case, wino_case, shuffle_case, sweep_case)[k % 6]
+        fn = (wino_case, sweep_case, s2_case, k7_case, wino_case, shuffle_case, sweep_case, k7_case)[k % 8]
         try:
             name, ok, note = fn(rng, k)
         except Exception as e:          # (a refused launch is a finding too)
