@@ -1,49 +1,51 @@
-"""Where do the device-to-device copies of a training step come from?  One profiled step (torch.profiler with stacks), copy ops grouped by
-their Python call site.    python tools/probes/find_copies.py"""
+"""Does a step issue small device copies?  rocprofv3's kernel table of a short bench run lists ~1 300 `__amd_rocclr_copyBuffer` launches:
+this probe puts ONE warmed-up G+D step of BASELINE configs[1] under torch.profiler and counts memcpy / memset / tiny aten events.
+Finding (profiles/r13c_copies.txt): 2 hipMemcpyAsync per step (the two weight packers' item tables) -- the 1 300 belong to model
+construction (799 parameter tensors moved to the device once), not to the step.    python tools/probes/find_copies.py"""
 import collections
 import os
 import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
-import bench as B  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
 
-model = B.make_model(16, 512, 0)
-LR, HR = B.synthetic(16, 512, 1000, torch.device("cuda", 0))
-data = {"LR": LR, "HR": HR}
-for s in range(1, 3):
-    model.feed_data(data)
-    model.optimize_parameters(s)
-torch.cuda.synchronize()
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    model.feed_data(data)
-    model.optimize_parameters(3)
+def main():
+    dev = torch.device("cuda", 0)
+    model = bench.make_model(16, 512, 0)
+    pool = [bench.synthetic(16, 512, 100 + i, dev) for i in range(2)]
+    for s in range(1, 4):
+        lr, hr = pool[s % 2]
+        model.feed_data({"LR": lr, "HR": hr})
+        model.optimize_parameters(s)
     torch.cuda.synchronize()
-sites = collections.Counter()
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::add_", "aten::mul", "aten::add", "aten::sum", "aten::div", "aten::mul_"):
-        st = [f for f in (ev.stack or []) if "trainner_amd" in f]
-        sites[(ev.name, st[0] if st else "?")] += 1
-par = collections.Counter()
-for ev in prof.events():
-    if "Memcpy" in ev.name or "memcpy" in ev.name:
-        q, chain = ev.cpu_parent, []
-        while q is not None and len(chain) < 4:
-            chain.append(q.name[:40])
-            q = q.cpu_parent
-        par[(ev.name, " < ".join(chain))] += 1
-for k, n in par.most_common(25):
-    print("%5d  %s" % (n, k))
-names = collections.Counter(ev.name for ev in prof.events())
-for name, n in names.most_common(60):
-    print("%5d  %s" % (n, name[:100]))
-for ev in prof.events():
-    if "copyBuffer" in ev.name or "Memcpy" in ev.name or "memcpy" in ev.name:
-        print("COPY", ev.name[:60], ev.device_time, [f for f in (ev.stack or [])][:3])
-        break
-for (name, site), n in sites.most_common(40):
-    print("%4d  %-18s %s" % (n, name, site))
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        lr, hr = pool[0]
+        model.feed_data({"LR": lr, "HR": hr})
+        model.optimize_parameters(4)
+        torch.cuda.synchronize()
+    by = collections.Counter()
+    names = collections.Counter()
+    for ev in prof.events():
+        nm = ev.name
+        if not any(k in nm.lower() for k in ("memcpy", "copy_", "memset", "aten::to", "aten::fill_", "aten::zero_", "aten::add", "aten::mul", "aten::clone", "aten::contiguous", "aten::item", "aten::_local_scalar_dense")):
+            continue
+        if not nm.startswith("aten::") and "mem" not in nm.lower():
+            continue
+        names[nm] += 1
+        frame = "?"
+        for fr in (ev.stack or []):
+            if "trainner_amd" in fr or "bench.py" in fr:
+                frame = fr.strip()
+                break
+        by[(nm, frame)] += 1
+    print("event names:", names.most_common(20))
+    for (nm, frame), c in by.most_common(60):
+        print("%5d  %-28s %s" % (c, nm, frame[-150:]))
+
+
+if __name__ == "__main__":
+    main()
