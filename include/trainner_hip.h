@@ -280,7 +280,8 @@ int tnr_conv_thin(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, cons
  * over an Ho x Wo output grid; reflect = 1: ReflectionPad2d(pad) borders (pad <= 3, Ho x Wo = H x W), reflect = 0: zeros outside
  * the H x W input -- with pad = 6 and Ho x Wo = (H + 6) x (W + 6) that is the data-gradient of a 7x7 layer with respect to its
  * reflection-padded input (fold it back with tnr_unpad2d).  Weights: tnr_conv_thin7_pack (dgrad as in tnr_conv_thin_pack) into
- * tnr_conv_thin7_pack_floats(reduction channels) floats.                                                     */
+ * tnr_conv_thin7_pack_floats(reduction channels) floats.  Cout <= 3 and Cin <= 64 run with one lane per INPUT channel (weights in
+ * registers, coalesced input rows, per-pixel sums through LDS); a 4-channel output or more input channels with one lane per pixel.  */
 int64_t tnr_conv_thin7_pack_floats(int32_t reduce_channels);
 int tnr_conv_thin7_pack(const float *w_oihw, float *wp, int32_t Cout, int32_t Cin, int32_t dgrad, void *stream);
 int tnr_conv_thin7(tnr_view x, int32_t N, int32_t H, int32_t W, int32_t Cin, const float *wp, tnr_view y, int32_t Ho, int32_t Wo,

@@ -73,6 +73,10 @@ def test_i2i_step_vs_reference_golden(case, tmp_path):
     TI.test_i2i_step_matches_reference_golden(case, tmp_path)
 
 
+def test_i2i_step_nine_block_form_of_the_7x7_layers(tmp_path, monkeypatch):
+    TI.test_i2i_step_golden_with_the_nine_block_form_of_the_7x7_layers(tmp_path, monkeypatch)
+
+
 @pytest.mark.parametrize("d_type", ["discriminator_vgg", "unet"])
 def test_discriminator_forward_memoization(tmp_path, monkeypatch, d_type):
     TS.test_discriminator_forward_memoization_is_exact(tmp_path, monkeypatch, d_type)

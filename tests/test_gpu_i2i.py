@@ -77,6 +77,14 @@ def test_i2i_step_matches_reference_golden(case, tmp_path):
         assert e < (2e-3 if fx["spec"]["steps"] <= 2 else 1e-2), (n, "running stats", k, e)     # (carry the trajectory drift)
 
 
+def test_i2i_step_golden_with_the_nine_block_form_of_the_7x7_layers(tmp_path, monkeypatch):
+    """TNR_K7_FUSED=0 (ResNet_arch._K7Image: the 7x7 image-side layers as nine 3x3 blocks of taps instead of one launch per pass) stays a
+    working A/B switch: the same reference golden, the same bounds."""
+    from trainner_amd.models.modules.architectures import ResNet_arch
+    monkeypatch.setattr(ResNet_arch, "K7_FUSED", False)
+    test_i2i_step_matches_reference_golden("pix2pix_rn2_crop64", tmp_path)
+
+
 def _shipped_i2i_recipe(tmp_path, rel, edit=None):
     """The reference's options/<rel> (tests/golden/shipped_recipes.json: every key and value, locations re-rooted,
     oracle/make_golden_options.py) + the pretrained generators the recipe names, here seeded state_dicts of the recipe's nets."""

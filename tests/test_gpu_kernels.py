@@ -903,9 +903,15 @@ def test_conv_thin7_small_cout(shape):
     g = rnd(N, C, H, W, seed=166)
     (gref,) = torch.autograd.grad(F.conv2d(xp, w2, None), xp, g)
     gx = torch.full((N, H + 6, W + 6, 4), 9.0, device=DEV)
-    ops.conv_thin7(ops.View(nhwc_buf(g)), w2.to(DEV), ops.View(gx), pad=6, reflect=False, dgrad=True)
+    ops.conv_thin7(ops.View(nhwc_buf(g)), w2.to(DEV), ops.View(gx, 0, 3), pad=6, reflect=False, dgrad=True)
     close(to_nchw(gx, 0, 3), gref, what="thin7 dgrad")
-    assert (gx[..., 3] == 0.0).all()
+    assert (gx[..., 3] == 9.0).all()
+    # a 4-channel output view takes the lanes = pixels kernel: the same values, a zero 4th channel (no weights)
+    gx4 = torch.full((N, H + 6, W + 6, 4), 9.0, device=DEV)
+    ops.conv_thin7(ops.View(nhwc_buf(g)), w2.to(DEV), ops.View(gx4), pad=6, reflect=False, dgrad=True)
+    close(to_nchw(gx4, 0, 3), gref, what="thin7 dgrad (4-channel view)")
+    assert (gx4[..., 3] == 0.0).all()
+    assert float((gx4[..., :3] - gx[..., :3]).abs().max()) <= 2e-5 * (float(gref.abs().max()) + 1.0)
 
 
 @pytest.mark.parametrize("shape", [(2, 20, 37, 64), (1, 9, 330, 16), (3, 33, 16, 32)])

@@ -133,13 +133,13 @@ def k7_case(rng, k):
     elif which == "thin_fwd":
         ref = F.conv2d(refl(feat), w_out)
         y = torch.zeros(N, H, W, 4, device=dev)
-        ops.conv_thin7(V(nhwc(feat)), w_out.float().to(dev), V(y), pad=3, reflect=True)
+        ops.conv_thin7(V(nhwc(feat)), w_out.float().to(dev), V(y, 0, 3), pad=3, reflect=True)
         got = y.permute(0, 3, 1, 2)[:, :3]
     elif which == "thin_dgrad":
         xp = torch.zeros(N, 3, H + 6, W + 6, dtype=torch.float64, requires_grad=True)
         (ref,) = torch.autograd.grad(F.conv2d(xp, w_in), xp, feat)
         y = torch.zeros(N, H + 6, W + 6, 4, device=dev)
-        ops.conv_thin7(V(nhwc(feat)), w_in.float().to(dev), V(y), pad=6, reflect=False, dgrad=True)
+        ops.conv_thin7(V(nhwc(feat)), w_in.float().to(dev), V(y, 0, 3), pad=6, reflect=False, dgrad=True)
         got = y.permute(0, 3, 1, 2)[:, :3]
     elif which == "wg_in":
         w0 = torch.zeros(C, 3, 7, 7, dtype=torch.float64, requires_grad=True)

@@ -37,8 +37,8 @@ def main():
     rows = [
         ("conv 7x7_c4 fwd 3->64 (reflect)", lambda: ops.conv(V(x4), p.get(i_in), V(z), mode=ops.CONV_7x7_C4, reflect=True), 2.0 * px * 49 * 3 * C, px * C * 4),
         ("conv 7x7_c4 dgrad 3->64 (padded grid)", lambda: ops.conv(V(xp4), p.get(i_out), V(fp), mode=ops.CONV_7x7_C4), 2.0 * pxp * 49 * 3 * C, pxp * C * 4),
-        ("conv_thin7 fwd 64->3 (reflect)", lambda: ops.conv_thin7(V(f), w_out, V(o4), pad=3, reflect=True), 2.0 * px * 49 * 3 * C, px * C * 4),
-        ("conv_thin7 dgrad 64->3 (pad 6)", lambda: ops.conv_thin7(V(f), w_in, V(op4), pad=6, reflect=False, dgrad=True), 2.0 * pxp * 49 * 3 * C, px * C * 4),
+        ("conv_thin7 fwd 64->3 (reflect)", lambda: ops.conv_thin7(V(f), w_out, V(o4, 0, 3), pad=3, reflect=True), 2.0 * px * 49 * 3 * C, px * C * 4),
+        ("conv_thin7 dgrad 64->3 (pad 6)", lambda: ops.conv_thin7(V(f), w_in, V(op4, 0, 3), pad=6, reflect=False, dgrad=True), 2.0 * pxp * 49 * 3 * C, px * C * 4),
         ("wgrad_thin7 image->64", lambda: ops.wgrad_thin7(V(f), V(xp4), dw_in, db_in, flip=False, beta=0.0), 2.0 * px * 49 * 3 * C, px * C * 4),
         ("wgrad_thin7 64->image (reflected reads)", lambda: ops.wgrad_thin7(V(f), V(x4), dw_out, None, flip=True, rpad=3, off=-6, beta=0.0), 2.0 * pxp * 49 * 3 * C, px * C * 4),
     ]

@@ -297,7 +297,6 @@ __global__ void __launch_bounds__(64) conv_thin7c_kernel(const Thin7K a, const i
             if (ox < xe && oy < a.Ho && o < a.Cout) {
                 float *yp = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ct + a.y_co;
                 yp[o] = (sum + (o == 0 ? b0 : (o == 1 ? b1 : b2))) * a.alpha;
-                if (o == 2 && a.Cout == 4) yp[3] = (a.bias != nullptr ? a.bias[3] : 0.f) * a.alpha;      // (the 4th channel of an NHWC4 view: no weights)
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -353,7 +352,7 @@ extern "C" int tnr_conv_thin7(tnr_view x, int32_t N, int32_t H, int32_t W, int32
     const int64_t tiles = (int64_t)k.tiles_x * k.tiles_y * N;
     TNR_REQUIRE(tiles < (1LL << 31), "conv_thin7: grid too large");
     static const bool lanes_c = [] { const char *e = std::getenv("TNR_THIN7_LANES"); return e == nullptr || e[0] != 'p'; }();      // p: lanes = pixels (A/B switch)
-    if (lanes_c && Cin <= 64) {
+    if (lanes_c && Cin <= 64 && Cout <= 3) {      // (a lane keeps 49 x 3 weights: a 4-channel output takes the lanes = pixels kernel below)
         const int nseg = tnr_cdiv(Wo, T7C_SEG), seg = tnr_cdiv(Wo, nseg);
         const int64_t waves = (int64_t)N * tnr_cdiv(Ho, 2) * nseg;
         TNR_REQUIRE(waves < (1LL << 31), "conv_thin7: grid too large");

@@ -170,8 +170,8 @@ class _K7Image:
                 ops.wgrad_thin7(gz, xp, self.mod.weight.grad, self.mod.bias.grad if self.mod.bias is not None else None, flip=False)
             if gx4 is None:
                 return
-            gxp = View(new_act(N, H + 6, W + 6, 4, dev))
-            ops.conv_thin7(gz, self.mod.weight, gxp, pad=6, reflect=False, dgrad=True)      # gx_p[q] = sum_t W^T[t] gz[q - t]
+            gxp = View(torch.zeros((N, H + 6, W + 6, 4), dtype=torch.float32, device=dev))
+            ops.conv_thin7(gz, self.mod.weight, View(gxp.buf, 0, self.mod.weight.shape[1]), pad=6, reflect=False, dgrad=True)      # gx_p[q] = sum_t W^T[t] gz[q - t]
             ops.unpad2d(gxp, gx4, 3, True)
             return
         g1 = View(new_act(N, H + 2, W + 2, gz.C, dev))
@@ -193,7 +193,7 @@ class _K7Image:
     def fwd_out(self, x, o4):
         N, H, W, dev = x.N, x.H, x.W, x.buf.device
         if self.fused:
-            ops.conv_thin7(x, self.mod.weight, o4, pad=3, reflect=True)
+            ops.conv_thin7(x, self.mod.weight, View(o4.buf, o4.coff, self.mod.weight.shape[0]), pad=3, reflect=True)     # (<= 3 image channels: the register-resident form)
             return x                                                  # (the un-padded input: the weight gradient reflects its reads)
         xp = View(new_act(N, H + 6, W + 6, x.C, dev))
         ops.pad2d(x, xp, 3, True)
@@ -266,7 +266,8 @@ class ResnetGenerator(HipNet):
         m, nb = self.model, self.n_blocks
         self._c_in, self._c_out = m[1], m[17 + nb]
         # the thin / taps-in-K kernels take 16-, 32- or 64-channel wide sides; other widths keep the generic kernels
-        self._k7 = (_K7Image(self._c_in, packer, "in"), _K7Image(self._c_out, packer, "out")) if self.ngf in (16, 32, 64) else None
+        # (the image-side kernels take <= 3 image channels and 16 / 32 / 64 features; anything else: the generic kernels of csrc/gconv.hip)
+        self._k7 = (_K7Image(self._c_in, packer, "in"), _K7Image(self._c_out, packer, "out")) if (self.ngf in (16, 32, 64) and self.input_nc <= 3 and self.output_nc <= 3) else None
         self._downs = [_Padded4x4(m[4].weight, packer, False), _Padded4x4(m[7].weight, packer, False)]
         self._down_mods = [m[4], m[7]]
         self._ups = [_Padded4x4(m[10 + nb].weight, packer, True), _Padded4x4(m[13 + nb].weight, packer, True)]
