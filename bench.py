@@ -434,7 +434,8 @@ def main():
         raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("TNR_DP_DEVICE", os.environ.get("LOCAL_RANK", "0")))      # TNR_DP_DEVICE (+ TNR_DP_PG=gloo): the ranks share one device -- a plumbing run
+    shared_gpu = world > 1 and "TNR_DP_DEVICE" in os.environ
     if args.gpus != world:
         raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ["TNR_MMA"] = args.mma          # read by trainner_amd.ops at import
@@ -659,7 +660,7 @@ def main():
                        "world_size_observed": world_observed,
                        "mma": "bf16 operands (use_amp)" if args.amp else MMA_TEXT[args.mma],
                        "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
-                       "collectives": ("rccl" if not dry else "gloo") if world > 1 else "none",
+                       "collectives": ("gloo through the host, ranks sharing device %d" % local if shared_gpu else ("rccl" if not dry else "gloo")) if world > 1 else "none",
                        # per-box choice between the one-launch dense block and five per-layer launches (bit-identical; ops.SWEEP_AUTO)
                        # chosen ONCE at model set-up on a scratch block of this shape and agreed on by all ranks (all-reduce MAX); `per_rank`
                        # (N > 1) = every rank's own measurement, so a split vote or a slow box is visible in this one line
@@ -689,6 +690,8 @@ def main():
         if dry:
             out["value"] = None
             out["invalid"] = "dry run"
+        if shared_gpu:
+            out["invalid"] = "ranks share one GPU (TNR_DP_DEVICE): the driver's N > 1 command on real kernels, not a scaling measurement"
         if world == 1 and not args.no_cpu_baseline:
             print("BENCH_GPU_LINE " + json.dumps(out), file=sys.stderr, flush=True)    # safe before the CPU leg
             out["cpu_baseline"] = cpu_baseline(args.crop)

@@ -23,6 +23,20 @@ import torch.distributed as dist
 BUCKET_FLOATS = 8 * 1024 * 1024      # 32 MiB: a few buckets per network keeps xGMI rings busy
 
 
+def _host_staged(t, group):
+    """TNR_DP_PG=gloo on a GPU box (test mode: several ranks sharing ONE device, which RCCL refuses): device tensors travel through the host."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, op, group):
+    if _host_staged(t, group):
+        c = t.detach().cpu()                 # (synchronises the current stream: ordering as with a collective enqueued on it, no overlap)
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 class DPGroup:
     def __init__(self, group=None):
         self.group = group
@@ -89,19 +103,19 @@ class DPGroup:
             lib, comm = self._abi
             hip.check(lib.tnr_dp_allreduce_bucket(comm, t.data_ptr(), t.numel(), 0, torch.cuda.current_stream().cuda_stream), "dp_allreduce")
             return
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        _all_reduce(t, dist.ReduceOp.SUM, self.group)
 
     def all_reduce_max(self, t):
         """Element-wise MAX over the ranks, in place, on the current stream (the fault latch: one int32 word)."""
         if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            _all_reduce(t, dist.ReduceOp.MAX, self.group)
 
     def mean_scalar(self, t):
         """Global-batch mean of a per-rank mean (equal shards): what nn.DataParallel's gather-then-loss reports."""
         if not self.active:
             return t
         t = t.detach().clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        _all_reduce(t, dist.ReduceOp.SUM, self.group)
         return t / self.world_size
 
     # ---------------------------------------------------------------- replica start state
@@ -116,6 +130,10 @@ class DPGroup:
                 from . import hip
                 lib, comm = self._abi
                 hip.check(lib.tnr_dp_broadcast(comm, t.data_ptr(), t.numel(), 0, torch.cuda.current_stream().cuda_stream), "dp_broadcast")
+            elif _host_staged(t, self.group):
+                c = t.detach().cpu()
+                dist.broadcast(c, src=0, group=self.group)
+                t.copy_(c)
             else:
                 dist.broadcast(t, src=0, group=self.group)
 
@@ -148,6 +166,9 @@ class DPGroup:
                 from . import hip
                 lib, comm = self._abi
                 hip.check(lib.tnr_dp_allreduce_bucket(comm, seg.data_ptr(), seg.numel(), 1, side.cuda_stream), "dp_allreduce_bucket")
+            elif _host_staged(seg, self.group):
+                _all_reduce(seg, dist.ReduceOp.SUM, self.group)                  # (test mode: the side stream drains, the host adds)
+                seg.mul_(1.0 / self.world_size)
             else:
                 dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group)     # ncclAvg: mean in the collective
             done = torch.cuda.Event()
@@ -215,9 +236,9 @@ def init_from_env():
     selftest = os.environ.get("TNR_DP_SELFTEST") == "1" and "RANK" in os.environ
     if (world > 1 or selftest) and not dist.is_initialized():
         use_cuda = torch.cuda.is_available()
-        if use_cuda:
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if use_cuda:      # TNR_DP_DEVICE: the ranks of a test share one device (with TNR_DP_PG=gloo: RCCL refuses two ranks on a GPU)
+            torch.cuda.set_device(int(os.environ.get("TNR_DP_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: this driver's only mode (RCCL / tensor sharing across processes)
-        dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend=os.environ.get("TNR_DP_PG") or ("nccl" if use_cuda else "gloo"))
     return DPGroup()

@@ -60,7 +60,7 @@ class BaseModel:
         self.opt = opt
         if opt["gpu_ids"]:
             hip.require_device()
-            local = int(os.environ.get("LOCAL_RANK", "0"))
+            local = int(os.environ.get("TNR_DP_DEVICE", os.environ.get("LOCAL_RANK", "0")))      # (TNR_DP_DEVICE: see dp.init_from_env)
             self.device = hip.engine_device(local)
             if self.device.type == "cuda":
                 torch.cuda.set_device(self.device)
