@@ -315,7 +315,7 @@ def pmc_mfma_busy(family, mode):
 
 
 def driver_visible_variants(args, model, data, device, rank, barrier, step):
-    """variant_amp / variant_feed_paired / variant_config4 of the default line: {value, ms_per_step, steps, warmup, dominant}."""
+    """variant_amp / variant_feed_paired / variant_config4 / variant_config5 of the default line: {value, ms_per_step, steps, warmup, dominant | whole_step}."""
     from trainner_amd import ops
     from trainner_amd.data.feeder import DeviceFeeder
     n_feed = 2 + args.steps + 1
@@ -383,6 +383,38 @@ def driver_visible_variants(args, model, data, device, rank, barrier, step):
                                         "Real-ESRGAN degradations on the GPU")
     out["variant_config4"] = v
     feeder.close()
+    # (4) BASELINE configs[4] (image-to-image, 256 x 256): the workloads of tools/bench_i2i.py -- Pix2Pix and CycleGAN with the 9-block
+    # ResnetGenerator + PatchGAN, batch 16; value in images / s, the whole step's convolution FLOP against the split arithmetic's ceiling
+    del m4
+    torch.cuda.empty_cache()
+    sys.path.insert(0, ROOT)
+    from tools import bench_i2i
+    out["variant_config5"] = {}
+    for name in ("pix2pix", "cyclegan"):
+        mdl, batch_i = bench_i2i.build(name, "resnet", 16, 256, False, device)
+        s_i = 0
+        for _ in range(2):
+            s_i += 1
+            mdl.feed_data(batch_i)
+            mdl.optimize_parameters(s_i)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s_i += 1
+            mdl.feed_data(batch_i)
+            mdl.optimize_parameters(s_i)
+        barrier()
+        dtv = time.perf_counter() - t0
+        if ops.chain_error_flag():
+            raise SystemExit("bench: a conv_chain dependency wait timed out -- results are invalid")
+        tf = bench_i2i.step_flop(name, 256) * 16 * args.steps / dtv / 1e12
+        out["variant_config5"][name] = {"value": round(16 * args.steps / dtv, 2), "unit": "img/s", "ms_per_step": round(1e3 * dtv / args.steps, 2),
+                                        "steps": args.steps, "warmup": 2, "dtype": "f32 (bf16x3)",
+                                        "whole_step": {"tflops": round(tf, 2), "peak": round(PEAK_BF16X3_TFLOPS, 1), "frac": round(tf / PEAK_BF16X3_TFLOPS, 4),
+                                                       "scope": "every convolution of G and D, forward and both gradients; wall clock"},
+                                        "what": "%s, ResnetGenerator-9 (ngf 64, InstanceNorm) + PatchGAN, batch 16, 256 x 256 (tools/bench_i2i.py)" % name}
+        del mdl, batch_i
+        torch.cuda.empty_cache()
     return out
 
 
@@ -678,6 +710,7 @@ def main():
             "variant_amp": extra.get("variant_amp"),
             "variant_feed_paired": extra.get("variant_feed_paired"),
             "variant_config4": extra.get("variant_config4"),
+            "variant_config5": extra.get("variant_config5"),
             "losses": {k: round(v, 6) for k, v in log.items()},
         }
         if feeder is not None:

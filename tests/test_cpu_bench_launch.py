@@ -25,7 +25,7 @@ def test_bench_self_launches_two_ranks():
     for k in ("metric", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "variant_f32_mfma"):
         assert k in j, k
     assert j["variant_f32_mfma"] is None and j["dtype"] == "f32 (bf16x3)" and j["config"]["mma"].startswith("fp32 arithmetic on the bf16 matrix core")
-    for k in ("variant_amp", "variant_feed_paired", "variant_config4"):      # 1-GPU-only measurements: present, null here
+    for k in ("variant_amp", "variant_feed_paired", "variant_config4", "variant_config5"):      # 1-GPU-only measurements: present, null here
         assert k in j and j[k] is None, k
     check_first_multi_gpu_run_keys(j, 2)
 

@@ -111,6 +111,29 @@ def step_flop(model, size):
     return 6 * 3 * g + 2 * (2 * d3 + 2 * 3 * d3)
 
 
+def build(model_name, netg="resnet", batch=16, size=256, amp=False, device=None):
+    """(model, batch dict): the reference's options/i2i/train_{pix2pix,cyclegan}.yml shape with synthetic images (also used by bench.py's
+    `variant_config5` leg)."""
+    from trainner_amd.models import create_model
+    from trainner_amd.options import options
+    dev = device or torch.device("cuda", 0)
+    root = tempfile.mkdtemp(prefix="tnr_bench_i2i_")
+    cyc = model_name == "cyclegan"
+    yml = os.path.join(root, "bench.yml")
+    with open(yml, "w") as f:          # the reference's options/i2i/train_{pix2pix,cyclegan}.yml with the ResNet generator
+        g_txt = ("  which_model_G: resnet_net\n  n_blocks: 9\n  ngf: 64\n  norm_type: instance\n" if netg == "resnet" else
+                 "  which_model_G: unet_net\n  ngf: 64\n  norm_type: batch\n")
+        f.write(YAML.format(netg=g_txt, model=model_name, amp="true" if amp else "false", pool=50 if cyc else 0, batch=batch, crop=size,
+                            root=root, d_in=3 if cyc else 6, pixel_weight=10 if cyc else 100,
+                            idt="  lambda_identity: 0.5\n" if cyc else ""))
+    torch.manual_seed(1234)
+    model = create_model(options.parse(yml, is_train=True), verbose=False)
+    g = torch.Generator().manual_seed(7)
+    data = {"A": (torch.rand(batch, 3, size, size, generator=g) * 2 - 1).to(dev),
+            "B": (torch.rand(batch, 3, size, size, generator=g) * 2 - 1).to(dev), "A_path": ["a"] * batch}
+    return model, data
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=["pix2pix", "cyclegan"], default="pix2pix")
@@ -123,24 +146,8 @@ def main():
                     help="resnet: ResnetGenerator-9 (BASELINE configs[4]); unet: the reference's Pix2Pix default unet_net (8 downs at 256, BatchNorm)")
     args = ap.parse_args()
     from trainner_amd import hip, ops
-    from trainner_amd.models import create_model
-    from trainner_amd.options import options
     hip.require_device()
-    dev = torch.device("cuda", 0)
-    root = tempfile.mkdtemp(prefix="tnr_bench_i2i_")
-    cyc = args.model == "cyclegan"
-    yml = os.path.join(root, "bench.yml")
-    with open(yml, "w") as f:          # the reference's options/i2i/train_{pix2pix,cyclegan}.yml with the ResNet generator
-        netg = ("  which_model_G: resnet_net\n  n_blocks: 9\n  ngf: 64\n  norm_type: instance\n" if args.netg == "resnet" else
-                "  which_model_G: unet_net\n  ngf: 64\n  norm_type: batch\n")
-        f.write(YAML.format(netg=netg, model=args.model, amp="true" if args.amp else "false", pool=50 if cyc else 0, batch=args.batch, crop=args.size,
-                            root=root, d_in=3 if cyc else 6, pixel_weight=10 if cyc else 100,
-                            idt="  lambda_identity: 0.5\n" if cyc else ""))
-    torch.manual_seed(1234)
-    model = create_model(options.parse(yml, is_train=True), verbose=False)
-    g = torch.Generator().manual_seed(7)
-    data = {"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev),
-            "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g) * 2 - 1).to(dev), "A_path": ["a"] * args.batch}
+    model, data = build(args.model, args.netg, args.batch, args.size, args.amp)
     step = 0
     for _ in range(args.warmup):
         step += 1
